@@ -1,0 +1,196 @@
+"""TEST INFRASTRUCTURE -- generates tests/golden/*.npz by EXECUTING THE REAL REFERENCE (modules.modeling.UniVL,
+modules.optimization.BertAdam imported from /root/reference) on the procedural parameters and synthetic inputs
+defined in oracle/univl_oracle.py.  Run in the build container only:
+
+    python oracle/make_golden.py            # all cases
+    python oracle/make_golden.py joint_full # one case
+
+The fixtures are small (sampled tensors, per-parameter gradient norms + leading elements); parameters and
+inputs are re-derived from seeds by the tests, so no state_dict is shipped.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_harness as H          # noqa: E402
+import univl_oracle as O          # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+# name -> (OracleConfig kwargs, rows, data seed)
+CASES = {
+    # cfg1/cfg2 of BASELINE.json: YouCookII retrieval FT-Joint, 12+6 layers, 48x48, bs=4
+    "joint_full": (dict(batch_size=4), 4, 1234),
+    # same path, 2+1 layers, ragged non-multiple-of-16 lengths
+    "joint_small": (dict(batch_size=3, text_num_hidden_layers=2, visual_num_hidden_layers=1,
+                         max_words=20, max_frames=12), 3, 7),
+    # all-ones masks (throughput shape) on a shallow stack
+    "joint_ones": (dict(batch_size=4, text_num_hidden_layers=1, visual_num_hidden_layers=1), 4, 11),
+    # FT-Align: --train_sim_after_cross (B^2 pairs through the 2-layer cross encoder, chunks of 5 text rows)
+    "align_small": (dict(batch_size=6, text_num_hidden_layers=1, visual_num_hidden_layers=1,
+                         cross_num_hidden_layers=2, train_sim_after_cross=True,
+                         max_words=16, max_frames=16), 6, 21),
+    # caption stage-two: cross + causal decoder + tied vocab classifier
+    "caption_small": (dict(batch_size=2, text_num_hidden_layers=1, visual_num_hidden_layers=1,
+                           cross_num_hidden_layers=1, decoder_num_hidden_layers=2, stage_two=True,
+                           task_type="caption", max_words=24, max_frames=16), 2, 31),
+    # pretrain stage-two: 5 losses, MIL-NCE, n_pair=3
+    "pretrain_small": (dict(batch_size=2, n_pair=3, text_num_hidden_layers=1, visual_num_hidden_layers=1,
+                            cross_num_hidden_layers=1, decoder_num_hidden_layers=1, stage_two=True,
+                            do_pretrain=True, use_mil=True, task_type="retrieval",
+                            max_words=16, max_frames=16), 2, 41),
+}
+
+
+def case_config(name):
+    kw, rows, seed = CASES[name]
+    return O.OracleConfig(**kw), rows, seed
+
+
+def _task_ns(cfg):
+    return H.task_namespace(
+        max_words=cfg.max_words, max_frames=cfg.max_frames, video_dim=cfg.video_dim, batch_size=cfg.batch_size,
+        n_gpu=cfg.n_gpu, n_pair=cfg.n_pair, margin=cfg.margin, negative_weighting=cfg.negative_weighting,
+        hard_negative_rate=cfg.hard_negative_rate, use_mil=cfg.use_mil, do_pretrain=cfg.do_pretrain,
+        task_type=cfg.task_type, stage_two=cfg.stage_two, train_sim_after_cross=cfg.train_sim_after_cross,
+        text_num_hidden_layers=cfg.text_num_hidden_layers, visual_num_hidden_layers=cfg.visual_num_hidden_layers,
+        cross_num_hidden_layers=cfg.cross_num_hidden_layers,
+        decoder_num_hidden_layers=cfg.decoder_num_hidden_layers)
+
+
+def load_procedural_into_reference(model, cfg, seed=0):
+    P = O.procedural_params(cfg, seed)
+    named = dict(model.named_parameters())
+    assert list(named.keys()) == list(P.keys()), "oracle param inventory != reference named_parameters()"
+    with torch.no_grad():
+        for n, p in named.items():
+            assert tuple(p.shape) == tuple(P[n].shape), (n, p.shape, P[n].shape)
+            p.copy_(P[n])
+    return P
+
+
+def reference_forward(model, cfg, batch):
+    kw = {}
+    if cfg.stage_two and (cfg.do_pretrain or cfg.task_type == "caption"):
+        kw = dict(input_caption_ids=batch["input_caption_ids"], decoder_mask=batch["decoder_mask"],
+                  output_caption_ids=batch["output_caption_ids"])
+    return model(batch["input_ids"], batch["token_type_ids"], batch["attention_mask"], batch["video"],
+                 batch["video_mask"], pairs_masked_text=batch["pairs_masked_text"],
+                 pairs_token_labels=batch["pairs_token_labels"], masked_video=batch["masked_video"],
+                 video_labels_index=batch["video_labels_index"], **kw)
+
+
+def sample(t, n=4096):
+    """Deterministic strided subsample of a tensor (flattened)."""
+    f = t.detach().reshape(-1)
+    if f.numel() <= n:
+        return f.to(torch.float32).numpy().copy()
+    idx = torch.linspace(0, f.numel() - 1, n).long()
+    return f[idx].to(torch.float32).numpy().copy()
+
+
+def generate(name):
+    cfg, rows, dseed = case_config(name)
+    model = H.build_reference_model(_task_ns(cfg), vocab_size=cfg.vocab_size, zero_dropout=True)
+    load_procedural_into_reference(model, cfg, seed=0)
+    batch = O.synthetic_batch(cfg, rows, seed=dseed)
+    out = {}
+    # eval-mode public surface (modeling.py:299-313, 377-391)
+    model.eval()
+    with torch.no_grad():
+        seq, vis = model.get_sequence_visual_output(batch["input_ids"], batch["token_type_ids"],
+                                                    batch["attention_mask"], batch["video"], batch["video_mask"])
+        sim = model.get_similarity_logits(seq, vis, batch["attention_mask"], batch["video_mask"])
+        if cfg.has_decoder:
+            logits = model.decoder_caption(seq, vis, batch["input_ids"], batch["attention_mask"],
+                                           batch["video_mask"], batch["input_caption_ids"],
+                                           batch["decoder_mask"], shaped=False, get_logits=True)
+            out["decoder_logits_sample"] = sample(logits)
+    out["sequence_output_sample"] = sample(seq)
+    out["visual_output_sample"] = sample(vis)
+    if seq.numel() <= 200000:
+        out["sequence_output"] = seq.numpy().copy()
+        out["visual_output"] = vis.numpy().copy()
+    out["sim_matrix"] = sim.numpy().copy()
+    # train-mode loss + grads (dropout p = 0)
+    model.train()
+    loss = reference_forward(model, cfg, batch)
+    loss.backward()
+    out["loss"] = np.array(float(loss), dtype=np.float64)
+    names, norms, heads, sums, nograd = [], [], [], [], []
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            nograd.append(n)
+            continue
+        names.append(n)
+        norms.append(float(p.grad.norm()))
+        sums.append(float(p.grad.double().sum()))
+        h = torch.zeros(8)
+        k = min(8, p.grad.numel())
+        h[:k] = p.grad.reshape(-1)[:k]
+        heads.append(h.numpy())
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array(norms, dtype=np.float64)
+    out["grad_sums"] = np.array(sums, dtype=np.float64)
+    out["grad_heads"] = np.stack(heads).astype(np.float32)
+    out["nograd_names"] = np.array(nograd)
+    # one optimizer step exactly as main_task_retrieval.py:347-353 + prep_optimizer :168-195
+    BertAdam = H.reference_bert_adam()
+    groups = O.param_groups([n for n, _ in model.named_parameters()], lr=3e-5, coef_lr=0.1)
+    pg = [{"params": [p], "weight_decay": groups[n]["weight_decay"], "lr": groups[n]["lr"]}
+          for n, p in model.named_parameters()]
+    opt = BertAdam(pg, lr=3e-5, warmup=0.1, schedule='warmup_linear', t_total=100, weight_decay=0.01,
+                   max_grad_norm=1.0)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    for _ in range(2):   # two steps: step 0 has lr_scheduled = 0 under warmup_linear (optimization.py:156-159)
+        total = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+    out["clip_total_norm"] = np.array(float(total), dtype=np.float64)
+    dn, dh = [], []
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        d = (p.detach() - before[n])
+        dn.append(float(d.double().norm()))
+        h = torch.zeros(8)
+        k = min(8, d.numel())
+        h[:k] = d.reshape(-1)[:k]
+        dh.append(h.numpy())
+    out["adam_delta_norms"] = np.array(dn, dtype=np.float64)
+    out["adam_delta_heads"] = np.stack(dh).astype(np.float32)
+    out["config_json"] = np.array(json.dumps(cfg.to_dict()))
+    out["rows"] = np.array(rows)
+    out["data_seed"] = np.array(dseed)
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[golden] {name}: loss={float(loss):.6f} params_with_grad={len(names)} no_grad={nograd} -> {path} "
+          f"({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def dump_param_inventory():
+    """Key lists of the reference's named_parameters()/state_dict per stage -> tests/golden/param_inventory.json."""
+    inv = {}
+    for name in ("joint_small", "align_small", "caption_small", "pretrain_small"):
+        cfg, _, _ = case_config(name)
+        model = H.build_reference_model(_task_ns(cfg), vocab_size=cfg.vocab_size)
+        inv[name] = dict(named_parameters=[[n, list(p.shape)] for n, p in model.named_parameters()],
+                         state_dict_keys=list(model.state_dict().keys()))
+    with open(os.path.join(GOLDEN_DIR, "param_inventory.json"), "w") as f:
+        json.dump(inv, f)
+    print("[golden] param_inventory.json written")
+
+
+if __name__ == "__main__":
+    assert H.reference_available(), "reference not mounted; golden vectors can only be made in the build container"
+    torch.set_num_threads(os.cpu_count())
+    which = sys.argv[1:] or list(CASES)
+    for nm in which:
+        generate(nm)
+    if not sys.argv[1:]:
+        dump_param_inventory()

@@ -1,0 +1,102 @@
+"""Pins the oracle (oracle/univl_oracle.py) to golden vectors produced by the REAL reference classes
+(oracle/make_golden.py).  CPU only.  Tolerance: fp32 re-association noise only (the oracle restates the same
+fp32 arithmetic in a different op order) -> 2e-5 relative on loss / logits, 1e-4 relative on gradient norms."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import univl_oracle as O
+from make_golden import CASES, case_config
+
+ALL = list(CASES)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def _sample(t, n=4096):
+    f = t.detach().reshape(-1)
+    if f.numel() <= n:
+        return f.float().numpy()
+    idx = torch.linspace(0, f.numel() - 1, n).long()
+    return f[idx].float().numpy()
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_oracle_matches_reference_golden(golden_dir, name):
+    g = _load(golden_dir, name)
+    cfg, rows, dseed = case_config(name)
+    assert json.loads(str(g["config_json"])) == cfg.to_dict()
+    P = {k: v.requires_grad_(True) for k, v in O.procedural_params(cfg, 0).items()}
+    batch = O.synthetic_batch(cfg, rows, seed=dseed)
+    # eval surface
+    with torch.no_grad():
+        seq, vis = O.get_sequence_visual_output(P, cfg, batch["input_ids"], batch["token_type_ids"],
+                                                batch["attention_mask"], batch["video"], batch["video_mask"])
+        v = lambda t: t.view(-1, t.shape[-1])
+        sim = O.similarity_logits(seq, vis, v(batch["attention_mask"]), v(batch["video_mask"]), P, cfg, False)
+    np.testing.assert_allclose(_sample(seq), g["sequence_output_sample"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(_sample(vis), g["visual_output_sample"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(sim.numpy(), g["sim_matrix"], rtol=2e-4, atol=2e-5)
+    if cfg.has_decoder:
+        with torch.no_grad():
+            logits = O.decoder_caption(P, cfg, seq, vis, batch["attention_mask"], batch["video_mask"],
+                                       batch["input_caption_ids"], batch["decoder_mask"])
+        np.testing.assert_allclose(_sample(logits), g["decoder_logits_sample"], rtol=2e-4, atol=5e-5)
+    # training loss + grads
+    loss = O.univl_forward(P, cfg, batch, training=True)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 2e-5 * max(1.0, abs(float(g["loss"])))
+    names = [str(s) for s in g["grad_names"]]
+    nograd = set(str(s) for s in g["nograd_names"])
+    for n, p in P.items():
+        if n in nograd:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+    for i, n in enumerate(names):
+        gr = P[n].grad
+        assert gr is not None, n
+        ref = float(g["grad_norms"][i])
+        assert abs(float(gr.norm()) - ref) <= 2e-4 * ref + 1e-7, (n, float(gr.norm()), ref)
+        k = min(8, gr.numel())
+        np.testing.assert_allclose(gr.reshape(-1)[:k].numpy(), g["grad_heads"][i][:k], rtol=2e-3, atol=2e-7,
+                                   err_msg=n)
+
+
+@pytest.mark.parametrize("name", ["joint_small", "caption_small"])
+def test_oracle_bert_adam_matches_reference(golden_dir, name):
+    """clip_grad_norm_ + BertAdam (optimization.py:103-168), two steps, vs the reference's own optimizer."""
+    g = _load(golden_dir, name)
+    cfg, rows, dseed = case_config(name)
+    P = {k: v.requires_grad_(True) for k, v in O.procedural_params(cfg, 0).items()}
+    batch = O.synthetic_batch(cfg, rows, seed=dseed)
+    O.univl_forward(P, cfg, batch, training=True).backward()
+    names = [str(s) for s in g["grad_names"]]
+    groups = O.param_groups(names, lr=3e-5, coef_lr=0.1)
+    with torch.no_grad():
+        before = {n: P[n].detach().clone() for n in names}
+        state = {n: dict(m=torch.zeros_like(P[n]), v=torch.zeros_like(P[n]), step=0) for n in names}
+        for _ in range(2):
+            total = O.clip_grad_norm_([P[n].grad for n in names], 1.0)
+            for n in names:
+                st = state[n]
+                st["step"] = O.bert_adam_step(P[n], P[n].grad, st["m"], st["v"], st["step"], groups[n]["lr"],
+                                              0.1, 100, groups[n]["weight_decay"])
+        assert abs(float(total) - float(g["clip_total_norm"])) <= 1e-4 * float(g["clip_total_norm"])
+        for i, n in enumerate(names):
+            d = (P[n].detach() - before[n])
+            ref = float(g["adam_delta_norms"][i])
+            assert abs(float(d.double().norm()) - ref) <= 2e-3 * ref + 1e-10, (n, float(d.norm()), ref)
+
+
+def test_param_inventory_matches_reference(golden_dir):
+    inv = json.load(open(os.path.join(golden_dir, "param_inventory.json")))
+    for name, rec in inv.items():
+        cfg, _, _ = case_config(name)
+        shapes = O.param_shapes(cfg)
+        assert [[n, list(s)] for n, s in shapes.items()] == rec["named_parameters"], name
+        keys = set(shapes) | set(O.tied_aliases(cfg))
+        assert keys == set(rec["state_dict_keys"]), name
