@@ -1,0 +1,225 @@
+/* libunivl_hip.so -- C ABI of the MI355X (gfx950) kernels behind the UniVL hot path.
+ *
+ * The reference (microsoft/UniVL) has NO native layer: its "operator API" is the Python class
+ * modules/modeling.py::UniVL and all arithmetic is delegated to PyTorch ATen.  Each entry
+ * point below therefore replaces an ATen op SEQUENCE at a cited call site of the reference; the Python host
+ * (univl_amd/) mirrors the reference's module surface and calls these through ctypes.
+ *
+ * Contract (SURVEY.md section 8b "C-ABI"):
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (PyTorch's caching
+ *     allocator on the Python side).  The library never allocates, frees or synchronises on the hot path.
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t) of the CURRENT device and returns
+ *     0 on success, <0 for an argument error (UNIVL_E*), >0 for a hipError_t; univl_last_error() describes it.
+ *   - re-entrant; no global mutable state besides the thread-local error string.
+ *   - dtype: UNIVL_F32 (parity mode, exact-fp32 MFMA) or UNIVL_BF16 (production: bf16 operands, fp32
+ *     accumulate, fp32 LayerNorm/softmax/residual stream).
+ *   - RNG for dropout is (seed, offset) supplied by the caller; offsets distinguish call sites.  The effective
+ *     seed is seed + *seed_dev when seed_dev (a device pointer) is given, so that a captured hipGraph draws a
+ *     fresh mask on every replay (univl_bump_counter advances the device word inside the graph).
+ */
+#ifndef UNIVL_HIP_H
+#define UNIVL_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define UNIVL_DT_F32 0
+#define UNIVL_DT_BF16 1
+
+const char* univl_last_error(void);
+int univl_version(void);
+/* sizeof of ABI struct #which (0 Gemm, 1 LayerNorm, 2 Attention, 3 EmbedText, 4 Pool, 5 Seg, 6 Adam) -- lets a
+ * foreign-language binding verify its struct mirrors at load time */
+int univl_struct_size(int which);
+/* number of CUs / name of the current device, for host-side launch heuristics; returns 0 or hipError_t */
+int univl_device_info(int* cu_count, char* name, int name_len);
+
+/* ------------------------------------------------------------------------------------------------ GEMM
+ * C[M,N] = epi( alpha * A_op[M,K] . B_op[N,K]^T ).   trans_x = 0: operand stored [rows][K] (row-major, ld);
+ * trans_x = 1: operand stored [K][rows].  Replaces nn.Linear forward (module_bert.py:172-174,207,233,246 and
+ * the Visual/Cross/Decoder copies), its autograd dgrad (trans_b=1) and wgrad (trans_a=trans_b=1), the tied
+ * vocabulary classifier (module_bert.py:327-330), torch.matmul of the similarity (modeling.py:389) and torch.mm
+ * of the MFM logits (modeling.py:285). */
+#define UNIVL_GEMM_ACCUM 1        /* C32 (and dbias) += result                                             */
+#define UNIVL_GEMM_GELU_FWD 2     /* aux <- pre-activation (T), result <- gelu(result)  (until_module.py:28) */
+#define UNIVL_GEMM_GELU_BWD 4     /* result *= gelu'(aux)                                                  */
+#define UNIVL_GEMM_ATOMIC 8       /* internal: split-K atomics                                             */
+#define UNIVL_GEMM_DBIAS_ATOMIC 16 /* dbias accumulated with atomics (several row tiles share a bias)       */
+typedef struct UnivlGemm {
+    int32_t dtype, trans_a, trans_b;
+    int32_t M, N, K;
+    const void* A; int64_t lda;
+    const void* B; int64_t ldb;
+    float* C32;            /* optional fp32 output                      */
+    void* C16;             /* optional output in the compute type       */
+    int64_t ldc;
+    const float* bias;     /* optional [N]                              */
+    const float* R;        /* optional fp32 residual [M,ldr]            */
+    int64_t ldr;
+    void* aux;             /* GELU pre-activation buffer (compute type) */
+    int64_t ldaux;
+    float* dbias;          /* optional, wgrad only: [M] sums of A_op rows over K */
+    float alpha;
+    int32_t flags;
+    int32_t ksplit;        /* >1: split the contraction over gridDim.z, fp32 atomics into pre-zeroed C32 */
+    int32_t tile;          /* 0 auto, 64, 128 */
+} UnivlGemm;
+int univl_gemm(const UnivlGemm* desc, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------ LayerNorm
+ * TF-style LayerNorm (until_module.py:40-53: biased variance, eps inside the sqrt) fused with what surrounds it
+ * in the reference:  out = dropout_post( LN( dropout_pre(x) + residual + pos[row % period] ) ).
+ *   BertSelfOutput/BertOutput (module_bert.py:207-211,246-250): x = dense output, residual, p_pre.
+ *   Visual/Cross embeddings  (module_visual.py:118-131, module_cross.py:123-138): pos (+type via residual), p_post.
+ *   NormalizeVideo (modeling.py:88-92): x is float64 (x_f64 = 1), no residual/dropout. */
+typedef struct UnivlLayerNorm {
+    int32_t dtype;         /* type of out16 / dxd16                                                       */
+    int32_t rows, N;       /* N in {768, 1024}                                                             */
+    int32_t x_f64;         /* forward input is float64                                                     */
+    const void* x;         /* fwd: [rows,N] fp32 (or f64)                                                  */
+    const float* residual; /* fwd: optional [rows,N]                                                       */
+    const float* pos;      /* fwd: optional [period,N] added to row (row % period)                         */
+    int32_t pos_period;
+    const float* gamma; const float* beta;
+    float eps;
+    float* y;              /* fwd out / bwd in: pre-LN sum [rows,N] (may alias x)                          */
+    float* stats;          /* fwd out / bwd in: [rows,2] = mean, rstd                                      */
+    float* out32;          /* fwd: optional fp32 output                                                    */
+    void* out16;           /* fwd: optional output in compute type                                         */
+    float p_pre, p_post;
+    uint64_t seed, off_pre, off_post;
+    const uint64_t* seed_dev;
+    /* backward */
+    const float* dout;     /* [rows,N] grad wrt out                                                        */
+    float* dx32;           /* optional: grad wrt the pre-LN sum (= grad of residual / pos inputs)           */
+    float* dxd32;          /* optional: grad wrt x (dropout_pre backward applied), fp32                    */
+    void* dxd16;           /* optional: same in compute type (operand of the following dgrad/wgrad)        */
+    float* dgamma; float* dbeta;   /* [N], accumulated with atomics                                        */
+    float* dbias;          /* optional [N]: column sums of the grad wrt x (bias grad of the producing GEMM) */
+    float* dpos;           /* optional [period,N], accumulated with atomics                                */
+} UnivlLayerNorm;
+int univl_layernorm_fwd(const UnivlLayerNorm* d, hipStream_t stream);
+int univl_layernorm_bwd(const UnivlLayerNorm* d, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------- attention
+ * softmax(Q K^T / sqrt(d) + mask) -> dropout -> .V   (module_bert.py:181-197 and its three copies).  The additive
+ * mask is built in-kernel from the {0,1} key mask exactly as module_bert.py:429-437 ((1-m)*-10000, added AFTER
+ * the scaling) and, with `causal`, as module_decoder.py:389-396 (((1-answer_mask)+triu(1))>0)*-10000.
+ * Head h of row r lives at  ptr + r*ld + h*64.  d is fixed to 64.  Forward saves the row log-sum-exp. */
+typedef struct UnivlAttention {
+    int32_t dtype;
+    int32_t B, H, Sq, Sk;
+    const void* q; int64_t ldq;
+    const void* k; int64_t ldk;
+    const void* v; int64_t ldv;
+    const int64_t* key_mask;  /* optional [B,Sk], 1 = attend */
+    int32_t causal;
+    void* out; int64_t ldo;   /* [B*Sq, ldo] compute type */
+    float* lse;               /* [B,H,Sq] */
+    float p_drop; uint64_t seed, offset;
+    const uint64_t* seed_dev;
+    /* backward */
+    const void* dout; int64_t lddo;
+    void* dq; int64_t lddq;
+    void* dk; int64_t lddk;
+    void* dv; int64_t lddv;
+} UnivlAttention;
+int univl_attention_fwd(const UnivlAttention* d, hipStream_t stream);
+int univl_attention_bwd(const UnivlAttention* d, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------- text embeddings
+ * BertEmbeddings / DecoderEmbeddings (module_bert.py:132-146, module_decoder.py:309-320):
+ * gather word + position (+ token type) -> LayerNorm -> dropout.  Backward scatter-adds into the tables. */
+typedef struct UnivlEmbedText {
+    int32_t dtype;
+    int32_t B, S, N;
+    const int64_t* ids; const int64_t* type_ids;   /* type_ids optional */
+    const float* word; const float* pos; const float* type;   /* type optional */
+    const float* gamma; const float* beta; float eps;
+    float* y; float* stats; float* out32; void* out16;
+    float p_post; uint64_t seed, off_post;
+    const uint64_t* seed_dev;
+    const float* dout;
+    float* dword; float* dpos; float* dtype_emb; float* dgamma; float* dbeta;
+} UnivlEmbedText;
+int univl_embed_text_fwd(const UnivlEmbedText* d, hipStream_t stream);
+int univl_embed_text_bwd(const UnivlEmbedText* d, hipStream_t stream);
+
+/* ------------------------------------------------------------------------- pooling / similarity / loss
+ * _mean_pooling_for_similarity + F.normalize (modeling.py:327-339, 385-388): masked mean over tokens
+ * (skip_first: position 0 excluded for text; zero-count guard), optional L2 normalisation (eps 1e-12). */
+typedef struct UnivlPool {
+    int32_t B, S, N;
+    const float* x; int64_t ldx_row;   /* x[(b*S+s)*ldx_row + c] */
+    const int64_t* mask;
+    int32_t skip_first, normalize;
+    float* mean;        /* [B,N] saved pre-normalisation mean */
+    float* out;         /* [B,N] */
+    const float* dout;  /* bwd: [B,N] */
+    float* dx;          /* bwd: [B,S,N] (written, not accumulated) */
+} UnivlPool;
+int univl_pool_fwd(const UnivlPool* d, hipStream_t stream);
+int univl_pool_bwd(const UnivlPool* d, hipStream_t stream);
+
+/* MaxMarginRankingLoss (until_module.py:245-251): loss = mean(w * (relu(m + x - diag_col) + relu(m + x - diag_row))).
+ * `sim` and `dsim` are [n, ld] row-major (ld >= n).  Writes the scalar loss and d loss / d x (for an upstream
+ * gradient of 1). */
+int univl_maxmargin_loss(const float* sim, int32_t n, int32_t ld, float margin, const float* weight, float* loss,
+                         float* dsim, hipStream_t stream);
+/* CrossEn (until_module.py:186-191): mean(-diag(log_softmax(x, -1))) and its gradient. */
+int univl_crossen_loss(const float* sim, int32_t n, int32_t ld, float* loss, float* dsim, hipStream_t stream);
+/* MILNCELoss (until_module.py:201-221) for batch_size x n_pair blocks; n = batch_size*n_pair. */
+int univl_milnce_loss(const float* sim, int32_t batch_size, int32_t n_pair, int32_t ld, float* loss, float* dsim,
+                      hipStream_t stream);
+/* x[0..n) *= s[0] with s on the device (applies loss.backward()'s upstream gradient without a host sync) */
+int univl_scale_by_device_scalar(float* x, int64_t n, const float* s, hipStream_t stream);
+
+/* -------------------------------------------------------------------------------------------- optimizer
+ * Fused multi-tensor BertAdam (modules/optimization.py:103-168) + clip_grad_norm_ (main_task_retrieval.py:347)
+ * over FLAT parameter / gradient / moment buffers.  `segs` describes the parameter tensors (device array). */
+typedef struct UnivlSeg {
+    int64_t offset, numel;      /* element range in the flat buffers                                     */
+    float lr, weight_decay;     /* group hyper-parameters (main_task_retrieval.py:185-190)               */
+    float max_grad_norm;        /* per-parameter clip of optimization.py:135-136 (<=0: off)              */
+    int32_t active;             /* 0: parameter has no gradient this step (skipped, as `p.grad is None`) */
+} UnivlSeg;
+/* sumsq[s] = sum of squares of segment s of g (fp32 atomics; sumsq must be zeroed by the caller). */
+int univl_grad_sumsq(const float* g, const UnivlSeg* segs, int32_t nseg, const int32_t* chunk_seg,
+                     const int64_t* chunk_off, const int32_t* chunk_len, int32_t nchunk, float* sumsq,
+                     hipStream_t stream);
+/* total-norm clip coefficient: coef[0] = min(1, max_norm / (sqrt(sum_active sumsq) + 1e-6)), coef[1] = total norm */
+int univl_clip_coef(const float* sumsq, const UnivlSeg* segs, int32_t nseg, float max_norm, float* coef, hipStream_t stream);
+/* g *= coef[0] over all active segments (in-place form of clip_grad_norm_) */
+int univl_scale_grads(float* g, const UnivlSeg* segs, const int32_t* chunk_seg, const int64_t* chunk_off,
+                      const int32_t* chunk_len, int32_t nchunk, const float* coef, hipStream_t stream);
+typedef struct UnivlAdam {
+    float* p; const float* g; float* m; float* v;   /* flat fp32 buffers                                  */
+    void* p16;                   /* optional bf16 shadow of p (same offsets), rewritten by the step       */
+    const UnivlSeg* segs; int32_t nseg;
+    const int32_t* chunk_seg; const int64_t* chunk_off; const int32_t* chunk_len; int32_t nchunk;
+    const float* sumsq;          /* per-segment sum of squares of the UNSCALED g                          */
+    const float* coef;           /* optional global clip coefficient still to be applied (deferred clip)  */
+    int32_t* step;               /* [nseg] per-parameter step counters (state['step'])                    */
+    float b1, b2, eps;
+    float warmup; int32_t t_total;   /* warmup_linear schedule (optimization.py:38-43), t_total -1: constant */
+    float* seg_scalars;          /* scratch [nseg*2]                                                       */
+} UnivlAdam;
+int univl_bert_adam(const UnivlAdam* d, hipStream_t stream);
+/* *ctr += 1 (device word; used for per-replay dropout seeds) */
+int univl_bump_counter(uint64_t* ctr, hipStream_t stream);
+/* p16 <- bf16(p) over n elements */
+int univl_cast_bf16(const float* p, void* p16, int64_t n, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------- hardware probes */
+int univl_probe_layouts(float* out, int32_t n_out, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,103 @@
+"""CPU-side checks (no GPU, no compute calls into the HIP library): the C-ABI library loads and exports every symbol
+include/univl_hip.h declares, the ctypes struct mirrors match the library's sizeof(), the static plans build, the
+flat parameter layout fuses q/k/v and covers every parameter once, and the product path refuses to run on CPU."""
+import argparse
+import os
+import re
+
+import pytest
+import torch
+
+import univl_oracle as O
+from univl_amd import UniVL, BertAdam, _lib
+from univl_amd.engine import FlatParams
+from univl_amd.parallel import layer_buckets
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(dt="bf16", **kw):
+    cfg = O.OracleConfig(batch_size=2, text_num_hidden_layers=2, visual_num_hidden_layers=1, max_words=16, max_frames=16, **kw)
+    ns = argparse.Namespace(**cfg.to_dict(), local_rank=0, compute_dtype=dt)
+    m = UniVL.from_pretrained("bert-base-uncased", "visual-base", "cross-base", "decoder-base", task_config=ns)
+    return m, cfg
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()          # also verifies sizeof() of the 7 ABI structs against the ctypes mirrors
+    header = open(os.path.join(ROOT, "include", "univl_hip.h")).read()
+    declared = set(re.findall(r"\b(univl_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(L, name), "libunivl_hip.so does not export " + name
+    assert declared == set(_lib.EXPORTED)
+    assert L.univl_version() >= 100
+
+
+def test_state_dict_keys_match_reference_inventory():
+    m, cfg = _model()
+    assert list(dict(m.named_parameters())) == list(O.param_shapes(cfg))
+    for n, p in m.named_parameters():
+        assert tuple(p.shape) == O.param_shapes(cfg)[n], n
+
+
+def test_flat_layout_and_plans_build_on_cpu():
+    m, cfg = _model("fp32")
+    m.load_state_dict(O.procedural_params(cfg, 0))
+    fl = FlatParams(list(m.named_parameters()), "cpu", torch.float32)
+    m._flat, m._seed_dev = fl, torch.zeros(1, dtype=torch.int64)
+    # parameters are views of the flat buffer and kept their values
+    P = O.procedural_params(cfg, 0)
+    for n, p in m.named_parameters():
+        assert torch.equal(p.detach(), P[n]), n
+        lo = fl.p32.data_ptr()
+        assert lo <= p.data_ptr() < lo + fl.total * 4
+    # q/k/v are contiguous -> one fused [2304,768] operand
+    a = "bert.encoder.layer.1.attention.self."
+    w = fl.w32_fused([a + "query.weight", a + "key.weight", a + "value.weight"])
+    assert w.shape == (2304, 768) and torch.equal(w[768:1536], P[a + "key.weight"])
+    m.train()
+    st = m._build_joint_step(2, 16, 16, True)
+    assert len(st.fwd) >= 3 * 7 + 4 + 4 and len(st.bwd_fresh) > len(st.fwd)
+    # data-parallel buckets: disjoint, cover every parameter that gets a gradient
+    b = layer_buckets(fl, m.used_parameter_names())
+    sl = sorted(list(b["layers"].values()) + b["tail"])
+    for (s0, e0), (s1, e1) in zip(sl, sl[1:]):
+        assert e0 <= s1
+    for n in m.used_parameter_names():
+        o, k, _ = fl.index[n]
+        assert any(s <= o and o + k <= e for s, e in sl), n
+
+
+def test_product_path_fails_loudly_without_gpu():
+    m, cfg = _model()
+    batch = O.synthetic_batch(cfg, 2, seed=1)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m.train()
+        m(batch["input_ids"], batch["token_type_ids"], batch["attention_mask"], batch["video"], batch["video_mask"])
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m.get_similarity_logits(torch.zeros(2, 16, 768), torch.zeros(2, 16, 768), batch["attention_mask"], batch["video_mask"])
+    opt = BertAdam(m.parameters(), lr=1e-3)
+    for p in m.parameters():
+        p.grad = torch.zeros_like(p)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        opt.step()
+
+
+def test_unbuilt_stages_are_explicit():
+    with pytest.raises(NotImplementedError):
+        _model(train_sim_after_cross=True)
+    with pytest.raises(NotImplementedError):
+        _model(stage_two=True, task_type="caption")
+
+
+def test_bert_adam_argument_validation():
+    m, _ = _model()
+    with pytest.raises(ValueError):
+        BertAdam(m.parameters(), lr=-1.0)
+    with pytest.raises(ValueError):
+        BertAdam(m.parameters(), lr=1e-3, warmup=1.5)
+    with pytest.raises(ValueError):
+        BertAdam(m.parameters(), lr=1e-3, b1=1.0)

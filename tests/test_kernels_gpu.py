@@ -1,0 +1,372 @@
+"""Per-kernel parity: every C-ABI entry point against the oracle's restatement of the reference op sequence it
+replaces (oracle/univl_oracle.py), on seeded inputs.  Needs a real MI355X (`-m gpu`).
+
+Tolerances: fp32 mode 1e-3 absolute on O(1) quantities as BASELINE.json's north_star states (observed ~1e-5);
+bf16 mode 1e-2 on quantities of O(1) after normalising by the tensor's scale (bf16 operands, fp32 accumulate)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import univl_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from univl_amd import ops, _lib
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def tol(dtype):
+    return 1e-3 if dtype == torch.float32 else 1e-2
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------------ probes
+def _tv(a, b, salt):
+    return float(((a * 7 + b * 13 + salt * 5 + a * b) % 5) - 2)
+
+
+def test_probe_layouts():
+    """MFMA operand / accumulator lane maps and the transpose read, as assumed by csrc/common.h."""
+    out = ops.probe_layouts().cpu().numpy()
+    for (CH, base_k, base_t, base_c) in ((32, 0, 256, 1024), (16, 512, 768, 1280)):
+        X = np.array([[_tv(r, k, 1) for k in range(CH)] for r in range(32)])
+        Y = np.array([[_tv(r, k, 2) for k in range(CH)] for r in range(16)])
+        Z = np.array([[_tv(r, k, 3) for k in range(CH)] for r in range(16)])
+        Cref = X[:16] @ Y.T
+        np.testing.assert_array_equal(out[base_k:base_k + 256].reshape(16, 16), Cref, err_msg=f"K-major CH={CH}")
+        np.testing.assert_array_equal(out[base_t:base_t + 256].reshape(16, 16), Cref, err_msg=f"T-major CH={CH}")
+        S = X[:CH] @ Y.T               # [CH,16]: rows are the contraction index of the chained product
+        np.testing.assert_array_equal(out[base_c:base_c + 256].reshape(16, 16), Z @ S, err_msg=f"chain CH={CH}")
+    # raw transpose-read dump: lane l (group g = l>>4, i = l&15) must receive img[4g + e][i], e = 0..3
+    raw = out[1536:1792].reshape(64, 4)
+    exp = np.array([[64 * (4 * (l >> 4) + e) + (l & 15) for e in range(4)] for l in range(64)], dtype=np.float32)
+    np.testing.assert_array_equal(raw, exp)
+
+
+# -------------------------------------------------------------------------------------------------- GEMM
+GEMM_SHAPES = [(192, 768, 768), (60, 2304, 768), (192, 1000, 768), (200, 768, 3072), (4, 4, 768), (36, 1, 768),
+               (300, 264, 100)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("tile", [64, 128])
+def test_gemm_forward_bias(dtype, M, N, K, tile):
+    Kp = (K + 7) // 8 * 8
+    A = torch.zeros(M, Kp); A[:, :K] = gen(M, K, seed=1)
+    B = torch.zeros(N, Kp); B[:, :K] = gen(N, K, seed=2, scale=0.05)
+    bias = gen(N, seed=3)
+    Ad, Bd = A.to(DEV, dtype), B.to(DEV, dtype)
+    ldc = (N + 7) // 8 * 8
+    out32 = torch.zeros(M, ldc, device=DEV)
+    out16 = torch.zeros(M, ldc, device=DEV, dtype=dtype)
+    ops.gemm(Ad, Bd, M, N, K, out32=out32, out16=out16, bias=bias.to(DEV), tile=tile)
+    ref = Ad.double().cpu()[:, :K] @ Bd.double().cpu()[:, :K].T + bias.double()
+    assert rel_err(out32[:, :N], ref) < (1e-5 if dtype == torch.float32 else 2e-3)
+    assert rel_err(out16[:, :N].float(), ref) < tol(dtype)
+    assert float(out32[:, N:].abs().max() if ldc > N else 0.0) == 0.0      # padding untouched
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [64, 128])
+def test_gemm_dgrad_wgrad(dtype, tile):
+    T, N, K = 100, 768, 3072                   # Y[T,N] = X[T,K] W[N,K]^T
+    X = gen(T, K, seed=4).to(DEV, dtype)
+    W = gen(N, K, seed=5, scale=0.05).to(DEV, dtype)
+    dY = gen(T, N, seed=6).to(DEV, dtype)
+    res = gen(T, K, seed=7).to(DEV)
+    # dgrad dX[T,K] = dY[T,N] . W[N,K]  (B T-major) + residual
+    dX = torch.zeros(T, K, device=DEV)
+    ops.gemm(dY, W, T, K, N, trans_b=True, out32=dX, residual=res, tile=tile)
+    ref = dY.double().cpu() @ W.double().cpu() + res.double().cpu()
+    assert rel_err(dX, ref) < (1e-5 if dtype == torch.float32 else 2e-3)
+    # wgrad dW[N,K] = dY^T[N,T] . X[T,K]  (both T-major), with bias grad and accumulate
+    dW = torch.ones(N, K, device=DEV)
+    db = torch.ones(N, device=DEV)
+    ops.gemm(dY, X, N, K, T, trans_a=True, trans_b=True, out32=dW, dbias=db, accumulate=True, tile=tile)
+    ref = dY.double().cpu().T @ X.double().cpu() + 1.0
+    assert rel_err(dW, ref) < (1e-5 if dtype == torch.float32 else 2e-3)
+    assert rel_err(db, dY.double().cpu().sum(0) + 1.0) < (1e-5 if dtype == torch.float32 else 2e-3)
+    # T-major A with K-major B (not used by the model but part of the ABI)
+    C = torch.zeros(N, T, device=DEV)
+    ops.gemm(dY, X, N, T, 64, trans_a=True, trans_b=False, out32=C, tile=tile)
+    ref = dY.double().cpu()[:64].T @ X.double().cpu()[:, :64].T
+    assert rel_err(C, ref) < (1e-5 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_gelu_epilogues_and_splitk(dtype):
+    T, N, K = 192, 3072, 768
+    X = gen(T, K, seed=8).to(DEV, dtype)
+    W = gen(N, K, seed=9, scale=0.05).to(DEV, dtype)
+    b = gen(N, seed=10).to(DEV)
+    u = torch.zeros(T, N, device=DEV, dtype=dtype)
+    f = torch.zeros(T, N, device=DEV, dtype=dtype)
+    ops.gemm(X, W, T, N, K, out16=f, bias=b, aux=u, gelu="fwd")
+    uref = X.double().cpu() @ W.double().cpu().T + b.double().cpu()
+    assert rel_err(u.float(), uref) < tol(dtype)
+    assert rel_err(f.float(), O.gelu(uref)) < tol(dtype)
+    # gelu backward epilogue: dU = (dF . W2) * gelu'(u)
+    dZ = gen(T, 768, seed=11).to(DEV, dtype)
+    W2 = gen(768, N, seed=12, scale=0.05).to(DEV, dtype)
+    dU = torch.zeros(T, N, device=DEV, dtype=dtype)
+    ops.gemm(dZ, W2, T, N, 768, trans_b=True, out16=dU, aux=u, gelu="bwd")
+    uu = u.double().cpu().requires_grad_(True)
+    O.gelu(uu).backward(dZ.double().cpu() @ W2.double().cpu())
+    assert rel_err(dU.float(), uu.grad) < tol(dtype)
+    # split-K (fp32 atomics into a zeroed buffer), bias + residual applied exactly once
+    Y = torch.zeros(T, 768, device=DEV)
+    res = gen(T, 768, seed=13).to(DEV)
+    b2 = gen(768, seed=14).to(DEV)
+    ops.gemm(f, W2, T, 768, N, out32=Y, bias=b2, residual=res, ksplit=4)
+    ref = f.double().cpu() @ W2.double().cpu().T + b2.double().cpu() + res.double().cpu()
+    assert rel_err(Y, ref) < (1e-5 if dtype == torch.float32 else 2e-3)
+
+
+def test_gemm_argument_errors():
+    A = torch.zeros(8, 12, device=DEV)           # ld 12 not a multiple of 4? (12 % 4 == 0) -> use misaligned view
+    B = torch.zeros(8, 12, device=DEV)
+    out = torch.zeros(8, 8, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.gemm(A[:, 1:], B[:, 1:], 8, 8, 8, out32=out)          # pointer not 16-byte aligned
+    with pytest.raises(RuntimeError):
+        ops.gemm(A, B, 8, 8, 12, out16=out, ksplit=2)             # split-K needs fp32 output
+    with pytest.raises(RuntimeError):
+        ops.gemm(A.cpu(), B.cpu(), 8, 8, 12, out32=out)           # CPU tensors: no fallback
+
+
+# --------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,rows", [(768, 192), (768, 61), (1024, 100)])
+def test_layernorm_fwd_bwd(dtype, N, rows):
+    dt = ops.dtype_code(dtype)
+    x, res = gen(rows, N, seed=1), gen(rows, N, seed=2)
+    period = 7
+    pos = gen(period, N, seed=3)
+    gamma, beta = 1 + 0.1 * gen(N, seed=4), 0.1 * gen(N, seed=5)
+    dout = gen(rows, N, seed=6)
+    xd = x.to(DEV)
+    y = torch.empty(rows, N, device=DEV); stats = torch.empty(rows, 2, device=DEV)
+    out32 = torch.empty(rows, N, device=DEV); out16 = torch.empty(rows, N, device=DEV, dtype=dtype)
+    ops.layernorm_fwd(dtype=dt, rows=rows, N=N, x=xd, residual=res.to(DEV), pos=pos.to(DEV), pos_period=period,
+                      gamma=gamma.to(DEV), beta=beta.to(DEV), y=y, stats=stats, out32=out32, out16=out16)
+    xr = x.double().requires_grad_(True); rr = res.double().requires_grad_(True); pr = pos.double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True); br = beta.double().requires_grad_(True)
+    rowpos = pr[torch.arange(rows) % period]
+    ref = O.layer_norm(xr + rr + rowpos, gr, br)
+    assert rel_err(out32, ref) < 1e-5
+    assert rel_err(out16.float(), ref) < tol(dtype)
+    ref.backward(dout.double())
+    dx32 = torch.empty(rows, N, device=DEV); dxd16 = torch.empty(rows, N, device=DEV, dtype=dtype)
+    dg = torch.zeros(N, device=DEV); db = torch.zeros(N, device=DEV); dbias = torch.zeros(N, device=DEV)
+    dpos = torch.zeros(period, N, device=DEV)
+    ops.layernorm_bwd(dtype=dt, rows=rows, N=N, gamma=gamma.to(DEV), y=y, stats=stats, dout=dout.to(DEV), dx32=dx32,
+                      dxd16=dxd16, dgamma=dg, dbeta=db, dbias=dbias, dpos=dpos, pos_period=period)
+    assert rel_err(dx32, xr.grad) < 1e-4
+    assert rel_err(dxd16.float(), xr.grad) < tol(dtype)
+    assert rel_err(dg, gr.grad) < 1e-4 and rel_err(db, br.grad) < 1e-4
+    assert rel_err(dbias, xr.grad.sum(0)) < 1e-4
+    assert rel_err(dpos, pr.grad) < 1e-4
+
+
+def test_layernorm_f64_input_and_zero_rows():
+    """NormalizeVideo (modeling.py:88-92): float64 in, all-zero padded frames must give exactly `bias`."""
+    rows, N = 50, 1024
+    x = gen(rows, N, seed=1).double()
+    x[10:20] = 0.0
+    gamma, beta = 1 + 0.1 * gen(N, seed=2), 0.1 * gen(N, seed=3)
+    out = torch.empty(rows, N, device=DEV)
+    ops.layernorm_fwd(dtype=_lib.DT_F32, rows=rows, N=N, x=x.to(DEV), x_f64=True, gamma=gamma.to(DEV), beta=beta.to(DEV), out32=out)
+    ref = O.layer_norm(x.float(), gamma, beta)
+    assert rel_err(out, ref) < 1e-5
+    assert torch.equal(out[10:20].cpu(), beta.expand(10, N))
+
+
+def test_layernorm_dropout_mask_consistency():
+    """dropout masks regenerated in the backward equal the forward's (both p_pre and p_post); keep-rate ~ 1-p."""
+    rows, N, p = 64, 768, 0.1
+    x = gen(rows, N, seed=1).to(DEV)
+    ones, zeros = torch.ones(N, device=DEV), torch.zeros(N, device=DEV)
+    y = torch.empty(rows, N, device=DEV); stats = torch.empty(rows, 2, device=DEV); out = torch.empty(rows, N, device=DEV)
+    kw = dict(dtype=_lib.DT_F32, rows=rows, N=N, gamma=ones, beta=zeros, p_pre=p, p_post=p, seed=5, off_pre=11, off_post=12)
+    ops.layernorm_fwd(x=x, y=y, stats=stats, out32=out, **kw)
+    kept_pre = (y != 0).float().mean().item()
+    kept_post = (out != 0).float().mean().item()
+    assert abs(kept_pre - 0.9) < 0.01 and abs(kept_post - 0.9) < 0.01
+    assert rel_err(y[y != 0], (x / 0.9)[y != 0]) < 1e-6
+    dout = torch.ones(rows, N, device=DEV)
+    dxd = torch.empty(rows, N, device=DEV); dg = torch.zeros(N, device=DEV); db = torch.zeros(N, device=DEV)
+    ops.layernorm_bwd(y=y, stats=stats, dout=dout, dxd32=dxd, dgamma=dg, dbeta=db, **kw)
+    # dbeta = column sums of the post-dropout-masked upstream gradient: equals count of kept outputs / 0.9
+    assert rel_err(db, (out != 0).float().sum(0) / 0.9) < 1e-5
+    assert torch.equal(dxd == 0, y == 0) or ((dxd == 0) & (y != 0)).float().mean().item() < 1e-3
+
+
+# --------------------------------------------------------------------------------------------- attention
+ATTN_CASES = [(2, 48, 48, False), (3, 20, 20, False), (2, 12, 12, False), (2, 96, 96, False), (2, 40, 56, False),
+              (1, 128, 224, False), (2, 24, 24, True), (1, 128, 128, True), (1, 224, 224, False)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Sq,Sk,causal", ATTN_CASES)
+def test_attention_fwd_bwd(dtype, B, Sq, Sk, causal):
+    H, D = 12, 64
+    dt = ops.dtype_code(dtype)
+    qkv_q = gen(B * Sq, H * D, seed=1).to(DEV, dtype)
+    kv = gen(B * Sk, 2 * H * D, seed=2).to(DEV, dtype)
+    g = torch.Generator().manual_seed(3)
+    lens = torch.randint(1, Sk + 1, (B,), generator=g)
+    lens[0] = Sk
+    mask = (torch.arange(Sk)[None] < lens[:, None]).long()
+    if B > 1 and not causal:
+        mask[1] = 0                                     # a fully masked row (reference: finite, not NaN)
+    out = torch.zeros(B * Sq, H * D, device=DEV, dtype=dtype)
+    lse = torch.zeros(B, H, Sq, device=DEV)
+    args = (dt, B, H, Sq, Sk, qkv_q, H * D, (kv, 0), 2 * H * D, (kv, H * D), 2 * H * D, out, H * D, lse)
+    ops.attention_fwd(*args, key_mask=mask.to(DEV), causal=causal)
+    q = qkv_q.double().cpu().view(B, Sq, H * D).requires_grad_(True)
+    k = kv.double().cpu()[:, :H * D].reshape(B, Sk, H * D).requires_grad_(True)
+    v = kv.double().cpu()[:, H * D:].reshape(B, Sk, H * D).requires_grad_(True)
+    add = O.extended_mask(mask, torch.float64)
+    if causal:
+        sub = torch.triu(torch.ones(Sq, Sk, dtype=torch.float64), diagonal=1)
+        add = ((1.0 - mask[:, None, None, :].double()) + sub[None, None]).gt(0).double() * -10000.0
+    ref = O.attention_core(q, k, v, add, H)
+    assert rel_err(out.float().view(B, Sq, -1), ref) < tol(dtype)
+    dout = gen(B * Sq, H * D, seed=4).to(DEV, dtype)
+    ref.backward(dout.double().cpu().view(B, Sq, -1))
+    dq = torch.zeros_like(qkv_q); dkv = torch.zeros_like(kv)
+    ops.attention_bwd(*args, key_mask=mask.to(DEV), causal=causal, dout=dout, lddo=H * D, dq=dq, lddq=H * D,
+                      dk=(dkv, 0), lddk=2 * H * D, dv=(dkv, H * D), lddv=2 * H * D)
+    t = tol(dtype) * (2 if dtype == torch.bfloat16 else 1)
+    assert rel_err(dq.float().view(B, Sq, -1), q.grad) < t
+    assert rel_err(dkv.float()[:, :H * D].reshape(B, Sk, -1), k.grad) < t
+    assert rel_err(dkv.float()[:, H * D:].reshape(B, Sk, -1), v.grad) < t
+
+
+def test_attention_dropout_statistics():
+    """p_drop = 0.1: E[out] matches the no-dropout output within sampling noise and fwd/bwd masks agree
+    (checked through dV = P_drop^T dO with dO = 1, whose column sums equal sum of dropped probabilities)."""
+    B, H, S, D = 2, 12, 48, 64
+    qkv = gen(B * S, 3 * H * D, seed=1).to(DEV)
+    out0 = torch.zeros(B * S, H * D, device=DEV); out1 = torch.zeros_like(out0); lse = torch.zeros(B, H, S, device=DEV)
+    a = (_lib.DT_F32, B, H, S, S, (qkv, 0), 3 * H * D, (qkv, H * D), 3 * H * D, (qkv, 2 * H * D), 3 * H * D)
+    ops.attention_fwd(*a, out0, H * D, lse)
+    ops.attention_fwd(*a, out1, H * D, lse, p_drop=0.1, seed=7, offset=3)
+    assert not torch.equal(out0, out1)
+    assert abs(float((out1 - out0).mean())) < 0.01
+    out2 = torch.zeros_like(out0)
+    ops.attention_fwd(*a, out2, H * D, lse, p_drop=0.1, seed=7, offset=3)
+    assert torch.equal(out1, out2)                      # same (seed, offset) -> same mask
+
+
+# -------------------------------------------------------------------------------------------- embeddings
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embed_text_fwd_bwd(dtype):
+    B, S, V = 3, 20, 500
+    dt = ops.dtype_code(dtype)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(0, V, (B, S), generator=g)
+    ids[0, :4] = 7                                        # repeated ids: scatter-add collisions
+    tts = torch.randint(0, 2, (B, S), generator=g)
+    word, pos, typ = gen(V, 768, seed=2, scale=0.02), gen(64, 768, seed=3, scale=0.02), gen(2, 768, seed=4, scale=0.02)
+    gamma, beta = 1 + 0.1 * gen(768, seed=5), 0.1 * gen(768, seed=6)
+    y = torch.empty(B * S, 768, device=DEV); stats = torch.empty(B * S, 2, device=DEV)
+    out32 = torch.empty(B * S, 768, device=DEV); out16 = torch.empty(B * S, 768, device=DEV, dtype=dtype)
+    a = (dt, B, S, ids.to(DEV), word.to(DEV), pos.to(DEV), gamma.to(DEV), beta.to(DEV))
+    ops.embed_text_fwd(*a, type_ids=tts.to(DEV), type_emb=typ.to(DEV), y=y, stats=stats, out32=out32, out16=out16)
+    wr, pr, tr = word.double().requires_grad_(True), pos.double().requires_grad_(True), typ.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = O.layer_norm(wr[ids] + pr[torch.arange(S)][None] + tr[tts], gr, br)
+    assert rel_err(out32.view(B, S, -1), ref) < 1e-5
+    assert rel_err(out16.float().view(B, S, -1), ref) < tol(dtype)
+    dout = gen(B * S, 768, seed=7)
+    ref.backward(dout.double().view(B, S, -1))
+    dw, dp, dty = torch.zeros(V, 768, device=DEV), torch.zeros(64, 768, device=DEV), torch.zeros(2, 768, device=DEV)
+    dg, db = torch.zeros(768, device=DEV), torch.zeros(768, device=DEV)
+    ops.embed_text_bwd(*a, type_ids=tts.to(DEV), type_emb=typ.to(DEV), y=y, stats=stats, dout=dout.to(DEV), dword=dw,
+                       dpos=dp, dtype_emb=dty, dgamma=dg, dbeta=db)
+    for got, want in ((dw, wr.grad), (dp, pr.grad), (dty, tr.grad), (dg, gr.grad), (db, br.grad)):
+        assert rel_err(got, want) < 1e-4
+
+
+# ------------------------------------------------------------------------------------- pooling and losses
+def test_pool_fwd_bwd():
+    B, S = 5, 20
+    x = gen(B, S, 768, seed=1)
+    g = torch.Generator().manual_seed(2)
+    mask = (torch.arange(S)[None] < torch.randint(2, S + 1, (B, 1), generator=g)).long()
+    vmask = mask.clone(); vmask[2] = 0                    # a video with zero valid frames (guarded count)
+    xr = x.double().requires_grad_(True)
+    t_ref, v_ref = O.mean_pooling_for_similarity(xr, xr, mask, vmask)
+    t_ref, v_ref = torch.nn.functional.normalize(t_ref, dim=-1), torch.nn.functional.normalize(v_ref, dim=-1)
+    dout = gen(B, 768, seed=3)
+    for skip_first, m, ref in ((True, mask, t_ref), (False, vmask, v_ref)):
+        mean = torch.empty(B, 768, device=DEV); out = torch.empty(B, 768, device=DEV); dx = torch.empty(B, S, 768, device=DEV)
+        ops.pool_fwd(B, S, x.to(DEV), m.to(DEV), skip_first=skip_first, normalize=True, mean=mean, out=out)
+        assert rel_err(out, ref) < 1e-5
+        xr.grad = None
+        ref.backward(dout.double(), retain_graph=True)
+        ops.pool_bwd(B, S, x.to(DEV), m.to(DEV), skip_first=skip_first, normalize=True, mean=mean, out=out, dout=dout.to(DEV), dx=dx)
+        assert rel_err(dx, xr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("n", [4, 16, 37])
+def test_maxmargin_and_crossen_losses(n):
+    sim = gen(n, n, seed=1, scale=0.5)
+    for name in ("maxmargin", "crossen"):
+        s = sim.double().requires_grad_(True)
+        ref = O.max_margin_ranking_loss(s, 0.1, 1, n, 1, 0.5) if name == "maxmargin" else O.cross_en(s)
+        ref.backward()
+        loss = torch.zeros(1, device=DEV); ds = torch.zeros(n, n, device=DEV)
+        if name == "maxmargin":
+            ops.maxmargin_loss(sim.to(DEV), 0.1, None, loss, ds)
+        else:
+            ops.crossen_loss(sim.to(DEV), loss, ds)
+        assert abs(float(loss) - float(ref)) < 1e-5 * max(1, abs(float(ref)))
+        assert rel_err(ds, s.grad) < 1e-5
+
+
+@pytest.mark.parametrize("bs,npair", [(2, 3), (4, 1), (5, 2)])
+def test_milnce_loss(bs, npair):
+    n = bs * npair
+    sim = gen(n, n, seed=2, scale=2.0)
+    s = sim.double().requires_grad_(True)
+    ref = O.mil_nce_loss(s, bs, npair)
+    ref.backward()
+    loss = torch.zeros(1, device=DEV); ds = torch.zeros(n, n, device=DEV)
+    ops.milnce_loss(sim.to(DEV), bs, npair, loss, ds)
+    assert abs(float(loss) - float(ref)) < 1e-5 * max(1, abs(float(ref)))
+    assert rel_err(ds, s.grad) < 1e-5
+
+
+def test_maxmargin_weighted():
+    """negative_weighting with n_pair > 1 (until_module.py:238-243, 249-250)."""
+    bs, npair = 3, 2
+    n = bs * npair
+    sim = gen(n, n, seed=3, scale=0.5)
+    s = sim.double().requires_grad_(True)
+    ref = O.max_margin_ranking_loss(s, 0.1, 1, bs, npair, 0.5)
+    ref.backward()
+    easy = 0.5
+    alpha = easy / ((bs - 1) * (1 - easy))
+    mm = np.kron((1 - alpha) * np.eye(bs) + alpha, np.ones((npair, npair))) * (bs * (1 - easy))
+    w = torch.tensor(mm, dtype=torch.float32)
+    loss = torch.zeros(1, device=DEV); ds = torch.zeros(n, n, device=DEV)
+    ops.maxmargin_loss(sim.to(DEV), 0.1, w.to(DEV), loss, ds)
+    assert abs(float(loss) - float(ref)) < 1e-5
+    assert rel_err(ds, s.grad) < 1e-5

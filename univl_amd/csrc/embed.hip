@@ -1,0 +1,169 @@
+// Text / decoder embeddings (reference: BertEmbeddings.forward modules/module_bert.py:132-146, DecoderEmbeddings
+// module_decoder.py:309-320): gather word + position (+ token-type) rows, TF-style LayerNorm, dropout.
+// One wave per token; the 768-wide row lives in registers.  Backward: LayerNorm backward in registers, then
+// scatter-add (fp32 atomics) into the word / position / type tables -- tied tables (decoder <-> BERT,
+// modeling.py:137-138) simply receive several scatter passes.
+#include "common.h"
+#include "univl_hip.h"
+
+namespace {
+
+constexpr int N = 768;
+constexpr int NV = N / 256;
+
+template <typename TO>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(UnivlEmbedText p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= p.B * p.S) return;
+    const int s = row % p.S;
+    const long id = p.ids[row];
+    const long tt = (p.type && p.type_ids) ? p.type_ids[row] : 0;
+    float v[NV][4];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int col = 4 * lane + 256 * j;
+        const float4 a = *reinterpret_cast<const float4*>(p.word + id * N + col);
+        const float4 b = *reinterpret_cast<const float4*>(p.pos + (long)s * N + col);
+        v[j][0] = a.x + b.x; v[j][1] = a.y + b.y; v[j][2] = a.z + b.z; v[j][3] = a.w + b.w;
+        if (p.type) {
+            const float4 c = *reinterpret_cast<const float4*>(p.type + tt * N + col);
+            v[j][0] += c.x; v[j][1] += c.y; v[j][2] += c.z; v[j][3] += c.w;
+        }
+        if (p.y) *reinterpret_cast<float4*>(p.y + (long)row * N + col) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+    }
+    float sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) sm += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    const float mean = wave_sum(sm) * (1.0f / N);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float c = v[j][e] - mean; q += c * c; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / N) + p.eps);
+    if (p.stats && lane == 0) { p.stats[2 * (long)row] = mean; p.stats[2 * (long)row + 1] = rstd; }
+    const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+    const float inv_keep = p.p_post > 0.f ? 1.0f / (1.0f - p.p_post) : 1.0f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int col = 4 * lane + 256 * j;
+        const long o = (long)row * N + col;
+        const float4 ga = *reinterpret_cast<const float4*>(p.gamma + col);
+        const float4 be = *reinterpret_cast<const float4*>(p.beta + col);
+        float r[4];
+        r[0] = (v[j][0] - mean) * rstd * ga.x + be.x;
+        r[1] = (v[j][1] - mean) * rstd * ga.y + be.y;
+        r[2] = (v[j][2] - mean) * rstd * ga.z + be.z;
+        r[3] = (v[j][3] - mean) * rstd * ga.w + be.w;
+        if (p.p_post > 0.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] *= dropout_scale(seed, p.off_post, (uint64_t)(o + e), p.p_post, inv_keep);
+        }
+        if (p.out32) *reinterpret_cast<float4*>(p.out32 + o) = make_float4(r[0], r[1], r[2], r[3]);
+        if (p.out16) {
+            TO* d = reinterpret_cast<TO*>(p.out16) + o;
+            if (sizeof(TO) == 2) {
+                bf16x4_t w;
+                w[0] = (__bf16)r[0]; w[1] = (__bf16)r[1]; w[2] = (__bf16)r[2]; w[3] = (__bf16)r[3];
+                *reinterpret_cast<bf16x4_t*>(d) = w;
+            } else {
+                *reinterpret_cast<float4*>(d) = make_float4(r[0], r[1], r[2], r[3]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(UnivlEmbedText p) {
+    __shared__ float red[4][N];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    const bool valid = row < p.B * p.S;
+    float dgm[NV][4], dbt[NV][4];
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dgm[j][e] = 0.f; dbt[j][e] = 0.f; }
+    if (valid) {
+        const int s = row % p.S;
+        const long id = p.ids[row];
+        const long tt = (p.dtype_emb && p.type_ids) ? p.type_ids[row] : 0;
+        const float mean = p.stats[2 * (long)row], rstd = p.stats[2 * (long)row + 1];
+        const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+    const float inv_keep = p.p_post > 0.f ? 1.0f / (1.0f - p.p_post) : 1.0f;
+        float dy[NV][4], xh[NV][4], ga[NV][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int col = 4 * lane + 256 * j;
+            const long o = (long)row * N + col;
+            const float4 a = *reinterpret_cast<const float4*>(p.dout + o);
+            const float4 yy = *reinterpret_cast<const float4*>(p.y + o);
+            const float4 gg = *reinterpret_cast<const float4*>(p.gamma + col);
+            dy[j][0] = a.x; dy[j][1] = a.y; dy[j][2] = a.z; dy[j][3] = a.w;
+            ga[j][0] = gg.x; ga[j][1] = gg.y; ga[j][2] = gg.z; ga[j][3] = gg.w;
+            xh[j][0] = (yy.x - mean) * rstd; xh[j][1] = (yy.y - mean) * rstd;
+            xh[j][2] = (yy.z - mean) * rstd; xh[j][3] = (yy.w - mean) * rstd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (p.p_post > 0.f) dy[j][e] *= dropout_scale(seed, p.off_post, (uint64_t)(o + e), p.p_post, inv_keep);
+                const float gq = dy[j][e] * ga[j][e];
+                s1 += gq; s2 += gq * xh[j][e];
+                dgm[j][e] = dy[j][e] * xh[j][e];
+                dbt[j][e] = dy[j][e];
+            }
+        }
+        s1 = wave_sum(s1) * (1.0f / N);
+        s2 = wave_sum(s2) * (1.0f / N);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int col = 4 * lane + 256 * j;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dx = rstd * (dy[j][e] * ga[j][e] - s1 - xh[j][e] * s2);
+                unsafeAtomicAdd(p.dword + id * N + col + e, dx);
+                unsafeAtomicAdd(p.dpos + (long)s * N + col + e, dx);
+                if (p.dtype_emb) unsafeAtomicAdd(p.dtype_emb + tt * N + col + e, dx);
+            }
+        }
+    }
+    // dgamma / dbeta: combine the 4 rows of the block, one atomic per column per block
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wave][4 * lane + 256 * j + e] = t == 0 ? dgm[j][e] : dbt[j][e];
+        __syncthreads();
+        float* dst = t == 0 ? p.dgamma : p.dbeta;
+        for (int c = threadIdx.x; c < N; c += 256)
+            unsafeAtomicAdd(dst + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+    }
+}
+
+}  // namespace
+
+extern "C" int univl_embed_text_fwd(const UnivlEmbedText* d, hipStream_t stream) {
+    UNIVL_CHECK_ARG(d != nullptr, UNIVL_EINVAL, "univl_embed_text_fwd: null descriptor");
+    UNIVL_CHECK_ARG(d->N == 768, UNIVL_EUNSUPPORTED, "univl_embed_text_fwd: N=%d (768 supported)", d->N);
+    UNIVL_CHECK_ARG(d->B > 0 && d->S > 0 && d->ids && d->word && d->pos && d->gamma && d->beta && (d->out32 || d->out16),
+                    UNIVL_EINVAL, "univl_embed_text_fwd: null / empty argument");
+    dim3 grid((d->B * d->S + 3) / 4), block(256);
+    if (d->dtype == UNIVL_DT_BF16) hipLaunchKernelGGL((embed_fwd_kernel<__bf16>), grid, block, 0, stream, *d);
+    else hipLaunchKernelGGL((embed_fwd_kernel<float>), grid, block, 0, stream, *d);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+extern "C" int univl_embed_text_bwd(const UnivlEmbedText* d, hipStream_t stream) {
+    UNIVL_CHECK_ARG(d != nullptr, UNIVL_EINVAL, "univl_embed_text_bwd: null descriptor");
+    UNIVL_CHECK_ARG(d->N == 768, UNIVL_EUNSUPPORTED, "univl_embed_text_bwd: N=%d (768 supported)", d->N);
+    UNIVL_CHECK_ARG(d->B > 0 && d->S > 0 && d->ids && d->dout && d->y && d->stats && d->gamma && d->dword && d->dpos &&
+                        d->dgamma && d->dbeta,
+                    UNIVL_EINVAL, "univl_embed_text_bwd: null / empty argument");
+    dim3 grid((d->B * d->S + 3) / 4), block(256);
+    hipLaunchKernelGGL(embed_bwd_kernel, grid, block, 0, stream, *d);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}

@@ -1,0 +1,241 @@
+// TF-style LayerNorm (reference: modules/until_module.py:40-53) fused with the elementwise work that surrounds it
+// at every call site of the reference (residual add, dropout before / after, position-embedding add, the
+// float64 -> float32 cast of NormalizeVideo, modeling.py:88-92).  HBM-bound: one wave per row, the row lives in
+// registers (N/64 = 12 or 16 floats per lane), 16-byte coalesced accesses, wave-shuffle reductions, two-pass
+// (mean, then centred variance) exactly as the reference computes it.
+#include "common.h"
+#include "univl_hip.h"
+
+namespace {
+
+template <int N, typename TO, bool F64>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(UnivlLayerNorm p) {
+    constexpr int NV = N / 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= p.rows) return;
+    float v[NV][4];
+    const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+    const float inv_keep_pre = p.p_pre > 0.f ? 1.0f / (1.0f - p.p_pre) : 1.0f;
+    const float inv_keep_post = p.p_post > 0.f ? 1.0f / (1.0f - p.p_post) : 1.0f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int col = 4 * lane + 256 * j;
+        const long o = (long)row * N + col;
+        if (F64) {
+            const double* x = reinterpret_cast<const double*>(p.x) + o;
+            const double2 a = *reinterpret_cast<const double2*>(x);
+            const double2 b = *reinterpret_cast<const double2*>(x + 2);
+            v[j][0] = (float)a.x; v[j][1] = (float)a.y; v[j][2] = (float)b.x; v[j][3] = (float)b.y;
+        } else {
+            const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.x) + o);
+            v[j][0] = a.x; v[j][1] = a.y; v[j][2] = a.z; v[j][3] = a.w;
+        }
+        if (p.p_pre > 0.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] *= dropout_scale(seed, p.off_pre, (uint64_t)(o + e), p.p_pre, inv_keep_pre);
+        }
+        if (p.residual) {
+            const float4 r = *reinterpret_cast<const float4*>(p.residual + o);
+            v[j][0] += r.x; v[j][1] += r.y; v[j][2] += r.z; v[j][3] += r.w;
+        }
+        if (p.pos) {
+            const float4 r = *reinterpret_cast<const float4*>(p.pos + (long)(row % p.pos_period) * N + col);
+            v[j][0] += r.x; v[j][1] += r.y; v[j][2] += r.z; v[j][3] += r.w;
+        }
+        if (p.y) *reinterpret_cast<float4*>(p.y + o) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    const float mean = wave_sum(s) * (1.0f / N);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float c = v[j][e] - mean; q += c * c; }
+    const float var = wave_sum(q) * (1.0f / N);
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+    if (p.stats && lane == 0) { p.stats[2 * (long)row] = mean; p.stats[2 * (long)row + 1] = rstd; }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int col = 4 * lane + 256 * j;
+        const long o = (long)row * N + col;
+        const float4 ga = *reinterpret_cast<const float4*>(p.gamma + col);
+        const float4 be = *reinterpret_cast<const float4*>(p.beta + col);
+        float r[4];
+        r[0] = (v[j][0] - mean) * rstd * ga.x + be.x;
+        r[1] = (v[j][1] - mean) * rstd * ga.y + be.y;
+        r[2] = (v[j][2] - mean) * rstd * ga.z + be.z;
+        r[3] = (v[j][3] - mean) * rstd * ga.w + be.w;
+        if (p.p_post > 0.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] *= dropout_scale(seed, p.off_post, (uint64_t)(o + e), p.p_post, inv_keep_post);
+        }
+        if (p.out32) *reinterpret_cast<float4*>(p.out32 + o) = make_float4(r[0], r[1], r[2], r[3]);
+        if (p.out16) {
+            TO* d = reinterpret_cast<TO*>(p.out16) + o;
+            if (sizeof(TO) == 2) {
+                bf16x4_t w;
+                w[0] = (__bf16)r[0]; w[1] = (__bf16)r[1]; w[2] = (__bf16)r[2]; w[3] = (__bf16)r[3];
+                *reinterpret_cast<bf16x4_t*>(d) = w;
+            } else {
+                *reinterpret_cast<float4*>(d) = make_float4(r[0], r[1], r[2], r[3]);
+            }
+        }
+    }
+}
+
+// Backward.  Each wave walks RPW rows, keeps per-column partial sums of dgamma / dbeta / dbias in registers, the
+// block combines its 4 waves through LDS and issues one fp32 atomic per column per block.
+constexpr int LN_RPW = 4;
+
+template <int N>
+__device__ __forceinline__ void block_colsum(float (*red)[N], const float (&part)[N / 256][4], float* dst, int lane, int wave) {
+    if (dst == nullptr) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < N / 256; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave][4 * lane + 256 * j + e] = part[j][e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < N; c += 256) {
+        const float s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        unsafeAtomicAdd(dst + c, s);
+    }
+}
+
+template <int N, typename TO>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(UnivlLayerNorm p) {
+    constexpr int NV = N / 256;
+    __shared__ float red[4][N];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+    const float inv_keep_pre = p.p_pre > 0.f ? 1.0f / (1.0f - p.p_pre) : 1.0f;
+    const float inv_keep_post = p.p_post > 0.f ? 1.0f / (1.0f - p.p_post) : 1.0f;
+    float dg[NV][4], db[NV][4], dbi[NV][4];
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dg[j][e] = 0.f; db[j][e] = 0.f; dbi[j][e] = 0.f; }
+    float ga[NV][4];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const float4 t = *reinterpret_cast<const float4*>(p.gamma + 4 * lane + 256 * j);
+        ga[j][0] = t.x; ga[j][1] = t.y; ga[j][2] = t.z; ga[j][3] = t.w;
+    }
+    for (int rr = 0; rr < LN_RPW; ++rr) {
+        const int row = (blockIdx.x * 4 + wave) * LN_RPW + rr;
+        if (row >= p.rows) break;
+        const float mean = p.stats[2 * (long)row], rstd = p.stats[2 * (long)row + 1];
+        float dy[NV][4], xh[NV][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const long o = (long)row * N + 4 * lane + 256 * j;
+            const float4 a = *reinterpret_cast<const float4*>(p.dout + o);
+            const float4 yy = *reinterpret_cast<const float4*>(p.y + o);
+            dy[j][0] = a.x; dy[j][1] = a.y; dy[j][2] = a.z; dy[j][3] = a.w;
+            xh[j][0] = (yy.x - mean) * rstd; xh[j][1] = (yy.y - mean) * rstd;
+            xh[j][2] = (yy.z - mean) * rstd; xh[j][3] = (yy.w - mean) * rstd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (p.p_post > 0.f) dy[j][e] *= dropout_scale(seed, p.off_post, (uint64_t)(o + e), p.p_post, inv_keep_post);
+                const float gq = dy[j][e] * ga[j][e];
+                s1 += gq; s2 += gq * xh[j][e];
+                dg[j][e] += dy[j][e] * xh[j][e];
+                db[j][e] += dy[j][e];
+            }
+        }
+        s1 = wave_sum(s1) * (1.0f / N);
+        s2 = wave_sum(s2) * (1.0f / N);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int col = 4 * lane + 256 * j;
+            const long o = (long)row * N + col;
+            float dx[4], dd[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dx[e] = rstd * (dy[j][e] * ga[j][e] - s1 - xh[j][e] * s2);
+                dd[e] = dx[e];
+                if (p.p_pre > 0.f) dd[e] *= dropout_scale(seed, p.off_pre, (uint64_t)(o + e), p.p_pre, inv_keep_pre);
+                dbi[j][e] += dd[e];
+            }
+            if (p.dx32) *reinterpret_cast<float4*>(p.dx32 + o) = make_float4(dx[0], dx[1], dx[2], dx[3]);
+            if (p.dxd32) *reinterpret_cast<float4*>(p.dxd32 + o) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+            if (p.dxd16) {
+                TO* d = reinterpret_cast<TO*>(p.dxd16) + o;
+                if (sizeof(TO) == 2) {
+                    bf16x4_t w;
+                    w[0] = (__bf16)dd[0]; w[1] = (__bf16)dd[1]; w[2] = (__bf16)dd[2]; w[3] = (__bf16)dd[3];
+                    *reinterpret_cast<bf16x4_t*>(d) = w;
+                } else {
+                    *reinterpret_cast<float4*>(d) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+                }
+            }
+            if (p.dpos) {
+                float* dp = p.dpos + (long)(row % p.pos_period) * N + col;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dp + e, dx[e]);
+            }
+        }
+    }
+    // block reduction of the three column sums, one LDS pass each (pointers are block-uniform)
+    block_colsum<N>(red, dg, p.dgamma, lane, wave);
+    block_colsum<N>(red, db, p.dbeta, lane, wave);
+    block_colsum<N>(red, dbi, p.dbias, lane, wave);
+}
+
+int check_common(const UnivlLayerNorm* d, const char* who) {
+    UNIVL_CHECK_ARG(d != nullptr, UNIVL_EINVAL, "%s: null descriptor", who);
+    UNIVL_CHECK_ARG(d->N == 768 || d->N == 1024, UNIVL_EUNSUPPORTED, "%s: N=%d (768 or 1024 supported)", who, d->N);
+    UNIVL_CHECK_ARG(d->rows > 0, UNIVL_EINVAL, "%s: rows=%d", who, d->rows);
+    UNIVL_CHECK_ARG(d->dtype == UNIVL_DT_F32 || d->dtype == UNIVL_DT_BF16, UNIVL_EUNSUPPORTED, "%s: dtype %d", who, d->dtype);
+    UNIVL_CHECK_ARG(d->gamma != nullptr, UNIVL_EINVAL, "%s: gamma is null", who);
+    UNIVL_CHECK_ARG(!(d->pos || d->dpos) || d->pos_period > 0, UNIVL_EINVAL, "%s: pos_period must be > 0", who);
+    return UNIVL_OK;
+}
+
+}  // namespace
+
+extern "C" int univl_layernorm_fwd(const UnivlLayerNorm* d, hipStream_t stream) {
+    int rc = check_common(d, "univl_layernorm_fwd");
+    if (rc) return rc;
+    UNIVL_CHECK_ARG(d->x && d->beta && (d->out32 || d->out16), UNIVL_EINVAL, "univl_layernorm_fwd: null x/beta/out");
+    UNIVL_CHECK_ARG(aligned16(d->x) && aligned16(d->out32) && aligned16(d->out16) && aligned16(d->y) &&
+                        aligned16(d->residual) && aligned16(d->pos) && aligned16(d->gamma) && aligned16(d->beta),
+                    UNIVL_EALIGN, "univl_layernorm_fwd: pointers must be 16-byte aligned");
+    dim3 grid((d->rows + 3) / 4), block(256);
+#define LN_FWD(NN, TT, FF) hipLaunchKernelGGL((ln_fwd_kernel<NN, TT, FF>), grid, block, 0, stream, *d)
+    const bool bf = d->dtype == UNIVL_DT_BF16;
+    if (d->N == 768) {
+        if (d->x_f64) { if (bf) LN_FWD(768, __bf16, true); else LN_FWD(768, float, true); }
+        else          { if (bf) LN_FWD(768, __bf16, false); else LN_FWD(768, float, false); }
+    } else {
+        if (d->x_f64) { if (bf) LN_FWD(1024, __bf16, true); else LN_FWD(1024, float, true); }
+        else          { if (bf) LN_FWD(1024, __bf16, false); else LN_FWD(1024, float, false); }
+    }
+#undef LN_FWD
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+extern "C" int univl_layernorm_bwd(const UnivlLayerNorm* d, hipStream_t stream) {
+    int rc = check_common(d, "univl_layernorm_bwd");
+    if (rc) return rc;
+    UNIVL_CHECK_ARG(d->dout && d->y && d->stats, UNIVL_EINVAL, "univl_layernorm_bwd: null dout/y/stats");
+    UNIVL_CHECK_ARG(aligned16(d->dout) && aligned16(d->y) && aligned16(d->dx32) && aligned16(d->dxd32) &&
+                        aligned16(d->dxd16) && aligned16(d->gamma),
+                    UNIVL_EALIGN, "univl_layernorm_bwd: pointers must be 16-byte aligned");
+    dim3 grid((d->rows + 4 * LN_RPW - 1) / (4 * LN_RPW)), block(256);
+    const bool bf = d->dtype == UNIVL_DT_BF16;
+    if (d->N == 768) {
+        if (bf) hipLaunchKernelGGL((ln_bwd_kernel<768, __bf16>), grid, block, 0, stream, *d);
+        else hipLaunchKernelGGL((ln_bwd_kernel<768, float>), grid, block, 0, stream, *d);
+    } else {
+        if (bf) hipLaunchKernelGGL((ln_bwd_kernel<1024, __bf16>), grid, block, 0, stream, *d);
+        else hipLaunchKernelGGL((ln_bwd_kernel<1024, float>), grid, block, 0, stream, *d);
+    }
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}

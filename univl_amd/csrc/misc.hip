@@ -1,0 +1,126 @@
+// Error string, version, device info and the hardware-layout probes that pin the assumptions of common.h
+// (MFMA operand / accumulator lane maps and the ds_read_b64_tr_b16 transpose read) on the real gfx950.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "common.h"
+#include "univl_hip.h"
+
+static thread_local char g_err[512] = "";
+
+void univl_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* univl_last_error(void) { return g_err; }
+extern "C" int univl_version(void) { return 100; }
+
+// sizeof() of the ABI structs so that the ctypes mirrors on the Python side can be verified at load time
+extern "C" int univl_struct_size(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(UnivlGemm);
+        case 1: return (int)sizeof(UnivlLayerNorm);
+        case 2: return (int)sizeof(UnivlAttention);
+        case 3: return (int)sizeof(UnivlEmbedText);
+        case 4: return (int)sizeof(UnivlPool);
+        case 5: return (int)sizeof(UnivlSeg);
+        case 6: return (int)sizeof(UnivlAdam);
+        default: return -1;
+    }
+}
+
+extern "C" int univl_device_info(int* cu_count, char* name, int name_len) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { univl_set_error("hipGetDevice: %s", hipGetErrorString(e)); return (int)e; }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) { univl_set_error("hipGetDeviceProperties: %s", hipGetErrorString(e)); return (int)e; }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (name && name_len > 0) { strncpy(name, prop.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
+    return 0;
+}
+
+namespace {
+
+// deterministic small-integer test matrices (exact in bf16 and fp32)
+__device__ __forceinline__ float tv(int a, int b, int salt) {
+    int h = (a * 7 + b * 13 + salt * 5 + a * b) % 5;
+    return (float)(h - 2);
+}
+
+// out layout (floats):
+//   [0,256)      bf16  C = X.Y^T, X,Y K-major 16x32          (C[r][c] at r*16+c)
+//   [256,512)    bf16  same product with X staged T-major ([32][16]) and read with the transpose read
+//   [512,768)    f32   C = X.Y^T, 16x16 contraction, K-major
+//   [768,1024)   f32   same with X T-major
+//   [1024,1280)  bf16  chained: D = Z . S,  S[32x16] = [X1;X2].Y^T fed through Mma::from_acc
+//   [1280,1536)  f32   chained: D = Z . S,  S[16x16] = X.Y^T
+//   [1536,1792)  raw ds_read_b64_tr_b16 dump: lane l, element e at 1536 + 4*l + e, image value = 64*row + col
+template <typename T>
+__device__ void probe_mma(float* out_k, float* out_t, float* out_chain, T* lds) {
+    constexpr int CH = Mma<T>::CH;
+    const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+    constexpr int PK = CH + Mma<T>::kpad, PT = 16 + Mma<T>::tpad;
+    T* xk = lds;                 // [16][PK]   X K-major
+    T* yk = xk + 16 * PK;        // [16][PK]   Y K-major
+    T* xt = yk + 16 * PK;        // [CH][PT]   X T-major
+    T* zk = xt + CH * PT;        // [16][PK]   Z K-major (chain)
+    for (int e = lane; e < 16 * CH; e += 64) {
+        const int r = e / CH, k = e % CH;
+        xk[r * PK + k] = from_f32<T>(tv(r, k, 1));
+        yk[r * PK + k] = from_f32<T>(tv(r, k, 2));
+        xt[k * PT + r] = from_f32<T>(tv(r, k, 1));
+        zk[r * PK + k] = from_f32<T>(tv(r, k, 3));
+    }
+    __syncthreads();
+    typename Mma<T>::frag fy = Mma<T>::lds_kmajor(yk + i * PK, g);
+    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+    c = Mma<T>::mma(Mma<T>::lds_kmajor(xk + i * PK, g), fy, c);
+    for (int r = 0; r < 4; ++r) out_k[(4 * g + r) * 16 + i] = c[r];
+    f32x4_t ct = {0.f, 0.f, 0.f, 0.f};
+    ct = Mma<T>::mma(Mma<T>::lds_tmajor(xt, PT, lane), fy, ct);
+    for (int r = 0; r < 4; ++r) out_t[(4 * g + r) * 16 + i] = ct[r];
+    // chain: S tiles = X{1,2}.Y^T with rows = contraction index of the next product
+    f32x4_t s0 = c, s1 = {0.f, 0.f, 0.f, 0.f};
+    if (CH == 32) {
+        // second stacked tile: X2[r][k] = tv(r+16, k, 1)
+        __syncthreads();
+        for (int e = lane; e < 16 * CH; e += 64) { const int r = e / CH, k = e % CH; xk[r * PK + k] = from_f32<T>(tv(r + 16, k, 1)); }
+        __syncthreads();
+        s1 = Mma<T>::mma(Mma<T>::lds_kmajor(xk + i * PK, g), fy, s1);
+    }
+    typename Mma<T>::frag fs = Mma<T>::from_acc(s0, s1);     // operand B: [contraction CH][16 cols]
+    f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+    d = Mma<T>::mma(Mma<T>::lds_kmajor(zk + i * PK, g), fs, d);
+    for (int r = 0; r < 4; ++r) out_chain[(4 * g + r) * 16 + i] = d[r];
+}
+
+__global__ void probe_kernel(float* out) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[16384];
+    probe_mma<__bf16>(out, out + 256, out + 1024, reinterpret_cast<__bf16*>(lds));
+    __syncthreads();
+    probe_mma<float>(out + 512, out + 768, out + 1280, reinterpret_cast<float*>(lds));
+    __syncthreads();
+    short* img = reinterpret_cast<short*>(lds);   // 16 rows x 64 cols, value = 64*row + col
+    const int lane = threadIdx.x & 63;
+    for (int e = lane; e < 16 * 64; e += 64) img[e] = (short)e;
+    __syncthreads();
+    // each lane supplies the 8-byte piece (row = lane>>2 within 16 rows, cols 4*(lane&3)..) -> dump what it gets
+    typedef __attribute__((address_space(3))) short4_t lds_s4;
+    const int row = (lane >> 2) & 15, cc = 4 * (lane & 3);
+    short4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(img + row * 64 + cc));
+    for (int e = 0; e < 4; ++e) out[1536 + 4 * lane + e] = (float)r[e];
+}
+
+}  // namespace
+
+extern "C" int univl_probe_layouts(float* out, int32_t n_out, hipStream_t stream) {
+    UNIVL_CHECK_ARG(out && n_out >= 1792, UNIVL_EINVAL, "univl_probe_layouts: need 1792 floats");
+    hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, stream, out);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}

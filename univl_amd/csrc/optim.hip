@@ -1,0 +1,208 @@
+// Fused multi-tensor BertAdam + gradient clipping over FLAT fp32 buffers.
+//
+// Reference semantics (per parameter tensor, modules/optimization.py:103-168 and main_task_retrieval.py:347-353):
+//   1. torch.nn.utils.clip_grad_norm_(all params, 1.0): coef = min(1, 1/(||g||_2 + 1e-6)), g *= coef
+//   2. per parameter: clip_grad_norm_(p, max_grad_norm) again                       optimization.py:135-136
+//   3. m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; update = m / (sqrt(v) + e)     :141-144 (no bias correction)
+//   4. update += weight_decay * p                                                   :153-154
+//   5. p -= lr * warmup_linear(step / t_total, warmup) * update ; step += 1         :156-166
+// The reference runs this as a Python loop of ~12 tiny kernels per tensor (3-4 k launches per step); here it is
+// three launches: per-tensor sum of squares (one streaming read of g), a 1-block scalar kernel, and one streaming
+// update kernel (reads p,g,m,v; writes p,m,v and the bf16 shadow of p used by the GEMMs): 30 B/param, HBM-bound.
+//
+// Work decomposition: the host splits every tensor into chunks of <= CHUNK elements (chunk_seg/off/len arrays);
+// one workgroup per chunk, so no chunk straddles two tensors and per-tensor scalars are workgroup-uniform.
+#include "common.h"
+#include "univl_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, const UnivlSeg* segs, const int32_t* chunk_seg,
+                                                    const int64_t* chunk_off, const int32_t* chunk_len, float* sumsq) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, seg = chunk_seg[c];
+    if (!segs[seg].active) return;
+    const float* p = g + chunk_off[c];
+    const int len = chunk_len[c];
+    float acc = 0.f;
+    const int nv = ((((uintptr_t)p) & 15) == 0) ? len / 4 : 0;
+    for (int i = threadIdx.x; i < nv; i += 256) {
+        const float4 v = reinterpret_cast<const float4*>(p)[i];
+        acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    for (int i = nv * 4 + threadIdx.x; i < len; i += 256) acc += p[i] * p[i];
+    const float s = block_sum256(acc, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(sumsq + seg, s);
+}
+
+__global__ __launch_bounds__(256) void clip_coef_kernel(const float* sumsq, const UnivlSeg* segs, int nseg, float max_norm,
+                                                        float* coef) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int s = threadIdx.x; s < nseg; s += 256) if (segs[s].active) acc += sumsq[s];
+    const float total = sqrtf(block_sum256(acc, red));
+    if (threadIdx.x == 0) {
+        coef[0] = fminf(1.0f, max_norm / (total + 1e-6f));
+        coef[1] = total;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* g, const UnivlSeg* segs, const int32_t* chunk_seg,
+                                                    const int64_t* chunk_off, const int32_t* chunk_len, const float* coef) {
+    const int c = blockIdx.x;
+    if (!segs[chunk_seg[c]].active) return;
+    const float k = coef[0];
+    if (k == 1.0f) return;
+    float* p = g + chunk_off[c];
+    const int len = chunk_len[c];
+    for (int i = threadIdx.x; i < len; i += 256) p[i] *= k;
+}
+
+__device__ __forceinline__ float warmup_linear_f(float x, float warmup) {
+    // optimization.py:38-43
+    if (x < warmup) return x / warmup;
+    return fmaxf((x - 1.0f) / (warmup - 1.0f), 0.0f);
+}
+
+// per-tensor scalars: scal[2s] = total gradient scale (global clip x per-parameter clip), scal[2s+1] = scheduled lr
+__global__ void adam_prep_kernel(UnivlAdam a) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.nseg) return;
+    const UnivlSeg sg = a.segs[s];
+    if (!sg.active) return;
+    const float gc = a.coef ? a.coef[0] : 1.0f;
+    float scale = gc;
+    if (sg.max_grad_norm > 0.f) {
+        const float nrm = sqrtf(a.sumsq[s]) * gc;
+        scale *= fminf(1.0f, sg.max_grad_norm / (nrm + 1e-6f));
+    }
+    const int st = a.step[s];
+    float lr = sg.lr;
+    if (a.t_total != -1) lr *= warmup_linear_f((float)st / (float)a.t_total, a.warmup);
+    a.seg_scalars[2 * s] = scale;
+    a.seg_scalars[2 * s + 1] = lr;
+    a.step[s] = st + 1;
+}
+
+__global__ __launch_bounds__(256) void adam_apply_kernel(UnivlAdam a) {
+    const int c = blockIdx.x, seg = a.chunk_seg[c];
+    const UnivlSeg sg = a.segs[seg];
+    if (!sg.active) return;
+    const float gs = a.seg_scalars[2 * seg], lr = a.seg_scalars[2 * seg + 1], wd = sg.weight_decay;
+    const float b1 = a.b1, b2 = a.b2, eps = a.eps;
+    const int64_t off = a.chunk_off[c];
+    const int len = a.chunk_len[c];
+    float* p = a.p + off; const float* g = a.g + off; float* m = a.m + off; float* v = a.v + off;
+    __bf16* p16 = a.p16 ? reinterpret_cast<__bf16*>(a.p16) + off : nullptr;
+    const int nv = ((off & 3) == 0) ? len / 4 : 0;
+    for (int i = threadIdx.x; i < nv; i += 256) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* pe = reinterpret_cast<float*>(&pp); const float* ge = reinterpret_cast<const float*>(&gg);
+        float* me = reinterpret_cast<float*>(&mm); float* ve = reinterpret_cast<float*>(&vv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = ge[e] * gs;
+            me[e] = me[e] * b1 + (1.0f - b1) * gr;
+            ve[e] = ve[e] * b2 + (1.0f - b2) * gr * gr;
+            const float upd = me[e] / (sqrtf(ve[e]) + eps) + wd * pe[e];
+            pe[e] -= lr * upd;
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        if (p16) {
+            bf16x4_t w;
+            w[0] = (__bf16)pe[0]; w[1] = (__bf16)pe[1]; w[2] = (__bf16)pe[2]; w[3] = (__bf16)pe[3];
+            reinterpret_cast<bf16x4_t*>(p16)[i] = w;
+        }
+    }
+    for (int i = nv * 4 + threadIdx.x; i < len; i += 256) {
+        const float gr = g[i] * gs;
+        const float mi = m[i] * b1 + (1.0f - b1) * gr;
+        const float vi = v[i] * b2 + (1.0f - b2) * gr * gr;
+        const float upd = mi / (sqrtf(vi) + eps) + wd * p[i];
+        const float pi = p[i] - lr * upd;
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (p16) p16[i] = (__bf16)pi;
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* p, __bf16* o, int64_t n) {
+    const int64_t nv = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(p)[i];
+        bf16x4_t w;
+        w[0] = (__bf16)v.x; w[1] = (__bf16)v.y; w[2] = (__bf16)v.z; w[3] = (__bf16)v.w;
+        reinterpret_cast<bf16x4_t*>(o)[i] = w;
+    }
+    if (blockIdx.x == 0) for (int64_t i = nv * 4 + threadIdx.x; i < n; i += 256) o[i] = (__bf16)p[i];
+}
+
+}  // namespace
+
+extern "C" int univl_grad_sumsq(const float* g, const UnivlSeg* segs, int32_t nseg, const int32_t* chunk_seg,
+                                const int64_t* chunk_off, const int32_t* chunk_len, int32_t nchunk, float* sumsq,
+                                hipStream_t stream) {
+    UNIVL_CHECK_ARG(g && segs && chunk_seg && chunk_off && chunk_len && sumsq && nseg > 0 && nchunk > 0, UNIVL_EINVAL,
+                    "univl_grad_sumsq: bad argument");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nchunk), dim3(256), 0, stream, g, segs, chunk_seg, chunk_off, chunk_len, sumsq);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+extern "C" int univl_clip_coef(const float* sumsq, const UnivlSeg* segs, int32_t nseg, float max_norm, float* coef,
+                               hipStream_t stream) {
+    UNIVL_CHECK_ARG(sumsq && segs && coef && nseg > 0, UNIVL_EINVAL, "univl_clip_coef: bad argument");
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, stream, sumsq, segs, nseg, max_norm, coef);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+extern "C" int univl_scale_grads(float* g, const UnivlSeg* segs, const int32_t* chunk_seg, const int64_t* chunk_off,
+                                 const int32_t* chunk_len, int32_t nchunk, const float* coef, hipStream_t stream) {
+    UNIVL_CHECK_ARG(g && segs && chunk_seg && chunk_off && chunk_len && coef && nchunk > 0, UNIVL_EINVAL,
+                    "univl_scale_grads: bad argument");
+    hipLaunchKernelGGL(scale_kernel, dim3(nchunk), dim3(256), 0, stream, g, segs, chunk_seg, chunk_off, chunk_len, coef);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+extern "C" int univl_bert_adam(const UnivlAdam* d, hipStream_t stream) {
+    UNIVL_CHECK_ARG(d && d->p && d->g && d->m && d->v && d->segs && d->chunk_seg && d->chunk_off && d->chunk_len &&
+                        d->sumsq && d->step && d->seg_scalars && d->nseg > 0 && d->nchunk > 0,
+                    UNIVL_EINVAL, "univl_bert_adam: bad argument");
+    hipLaunchKernelGGL(adam_prep_kernel, dim3((d->nseg + 255) / 256), dim3(256), 0, stream, *d);
+    hipLaunchKernelGGL(adam_apply_kernel, dim3(d->nchunk), dim3(256), 0, stream, *d);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+__global__ void bump_kernel(uint64_t* c) { c[0] += 1; }
+
+extern "C" int univl_bump_counter(uint64_t* ctr, hipStream_t stream) {
+    UNIVL_CHECK_ARG(ctr != nullptr, UNIVL_EINVAL, "univl_bump_counter: null");
+    hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, stream, ctr);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+extern "C" int univl_cast_bf16(const float* p, void* p16, int64_t n, hipStream_t stream) {
+    UNIVL_CHECK_ARG(p && p16 && n > 0 && aligned16(p) && ((((uintptr_t)p16) & 7) == 0), UNIVL_EINVAL, "univl_cast_bf16: bad argument");
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(cast_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, reinterpret_cast<__bf16*>(p16), n);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}

@@ -1,0 +1,326 @@
+"""Flat parameter storage and static execution plans for the UniVL hot path.
+
+Design (MI355X-first):
+  * all parameters live in ONE flat fp32 buffer (plus a flat fp32 gradient buffer and, in bf16 mode, a flat bf16
+    shadow the GEMMs read); `nn.Parameter`s are views into it, so the reference's names/shapes/state_dict are
+    preserved while query/key/value become one [2304,768] operand, the optimizer is one streaming kernel, and a
+    data-parallel bucket is one contiguous slice.
+  * shapes on this path are static (fixed max_words/max_frames, drop_last batches), so a forward/backward is a
+    STATIC PLAN: a list of pre-built C descriptors pointing into a persistent workspace.  Running a plan only
+    enqueues kernels on the current HIP stream; it is what gets captured into a hipGraph.
+"""
+import ctypes as C
+import weakref
+
+import torch
+
+from . import _lib, ops
+from ._lib import DT_BF16, DT_F32
+
+_ALIGN = 64  # elements; keeps every tensor 256-byte aligned in fp32 and 128-byte in bf16
+FLAT_REGISTRY = weakref.WeakSet()   # lets the fused optimizer find the flat buffers that own a Parameter
+
+
+def _is_atomic_region(name, shape):
+    """Region V: tensors whose gradients are produced by atomics / scatter-add (embedding tables, all vectors)."""
+    if len(shape) == 1:
+        return True
+    if "embeddings" in name and not name.startswith("visual.embeddings.word_embeddings"):
+        return True
+    if name.startswith("similarity_dense"):
+        return True
+    return False
+
+
+class FlatParams:
+    """Owns p32 / g32 (/ p16) and re-points the module's Parameters at views of p32."""
+
+    def __init__(self, named_params, device, compute_dtype):
+        self.device = torch.device(device)
+        self.compute_dtype = compute_dtype
+        self.dt = ops.dtype_code(compute_dtype)
+        names_v = [(n, p) for n, p in named_params if _is_atomic_region(n, tuple(p.shape))]
+        names_m = [(n, p) for n, p in named_params if not _is_atomic_region(n, tuple(p.shape))]
+        self.index = {}
+        off = 0
+        for n, p in names_v + names_m:
+            if n == (names_m[0][0] if names_m else None):
+                self.v_end = off
+            self.index[n] = (off, p.numel(), tuple(p.shape))
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        if not names_m:
+            self.v_end = off
+        self.total = off
+        self.order = [n for n, _ in names_v + names_m]
+        self.p32 = torch.zeros(self.total, device=self.device, dtype=torch.float32)
+        self.g32 = torch.zeros(self.total, device=self.device, dtype=torch.float32)
+        self.p16 = torch.zeros(self.total, device=self.device, dtype=torch.bfloat16) if compute_dtype == torch.bfloat16 else None
+        self.params = {}
+        with torch.no_grad():
+            for n, p in names_v + names_m:
+                o, k, shp = self.index[n]
+                view = self.p32[o:o + k].view(shp)
+                view.copy_(p.detach().to(self.device, torch.float32))
+                p.data = view
+                self.params[n] = p
+        self.shadow_valid = False
+        self.grad_version = 0        # bumped by every backward; pairs a clip measurement with the gradients it saw
+        self._clip = None
+        self._pending = None
+        FLAT_REGISTRY.add(self)
+
+    # ---- views
+    def w32(self, name):
+        o, k, shp = self.index[name]
+        return self.p32[o:o + k].view(shp)
+
+    def g(self, name):
+        o, k, shp = self.index[name]
+        return self.g32[o:o + k].view(shp)
+
+    def wop(self, name):
+        """compute-type view of a weight (bf16 shadow or the fp32 master itself)."""
+        o, k, shp = self.index[name]
+        src = self.p16 if self.p16 is not None else self.p32
+        return src[o:o + k].view(shp)
+
+    def _fused(self, buf, names):
+        o0, _, shp0 = self.index[names[0]]
+        rows, o = 0, o0
+        for n in names:
+            on, k, shp = self.index[n]
+            assert on == o and shp[1:] == shp0[1:], "parameters %s are not contiguous in the flat buffer" % (names,)
+            assert k % _ALIGN == 0
+            o += k
+            rows += shp[0]
+        return buf[o0:o].view((rows,) + tuple(shp0[1:]))
+
+    def wop_fused(self, names):
+        return self._fused(self.p16 if self.p16 is not None else self.p32, names)
+
+    def w32_fused(self, names):
+        return self._fused(self.p32, names)
+
+    def g_fused(self, names):
+        return self._fused(self.g32, names)
+
+    def refresh_shadow(self, force=False):
+        if self.p16 is not None and (force or not self.shadow_valid):
+            ops.cast_bf16(self.p32, self.p16)
+        self.shadow_valid = True
+
+    def attach_grads(self, used_names):
+        """p.grad <- view of g32 for every parameter that receives a gradient in this configuration."""
+        for n in used_names:
+            p = self.params[n]
+            if p.grad is None or p.grad.data_ptr() != self.g(n).data_ptr():
+                p.grad = self.g(n)
+
+
+class Plan:
+    """A static list of kernel enqueues."""
+
+    def __init__(self):
+        self.calls = []
+        self.keep = []
+
+    def add(self, fn_name, desc):
+        fn = getattr(_lib.lib(), fn_name)
+        self.keep.append(desc)
+        self.calls.append((fn, C.byref(desc), fn_name))
+
+    def add_callable(self, f):
+        self.calls.append((f, None, getattr(f, "__name__", "callable")))
+
+    def run(self):
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for fn, ref, name in self.calls:
+            if ref is None:
+                fn()
+            else:
+                rc = fn(ref, s)
+                if rc != 0:
+                    _lib.check(rc, name)
+
+    def __len__(self):
+        return len(self.calls)
+
+
+def _gemm_desc(dt, A, lda, B, ldb, M, N, K, *, trans_a=0, trans_b=0, out32=None, out16=None, ldc=0, bias=None,
+               residual=None, ldr=0, aux=None, ldaux=0, gelu=None, accumulate=False, dbias=None, ksplit=1, tile=0):
+    d = _lib.Gemm()
+    d.dtype, d.trans_a, d.trans_b, d.M, d.N, d.K = dt, trans_a, trans_b, M, N, K
+    d.A, d.lda, d.B, d.ldb = A.data_ptr(), lda, B.data_ptr(), ldb
+    d.C32 = out32.data_ptr() if out32 is not None else None
+    d.C16 = out16.data_ptr() if out16 is not None else None
+    d.ldc = ldc
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.R, d.ldr = (residual.data_ptr() if residual is not None else None), ldr
+    d.aux, d.ldaux = (aux.data_ptr() if aux is not None else None), ldaux
+    d.dbias = dbias.data_ptr() if dbias is not None else None
+    d.alpha = 1.0
+    flags = _lib.GEMM_DBIAS_ATOMIC if dbias is not None else 0
+    if accumulate:
+        flags |= _lib.GEMM_ACCUM
+    if gelu == "fwd":
+        flags |= _lib.GEMM_GELU_FWD
+    elif gelu == "bwd":
+        flags |= _lib.GEMM_GELU_BWD
+    d.flags, d.ksplit, d.tile = flags, ksplit, tile
+    return d
+
+
+class _SiteCounter:
+    """Distinct dropout stream offsets per call site."""
+
+    def __init__(self):
+        self.n = 0
+
+    def next(self):
+        self.n += 1
+        return self.n << 40
+
+
+class EncoderStack:
+    """BertEncoder / VisualEncoder / CrossEncoder (module_bert.py:253-281 and copies): L post-LN transformer
+    layers over T = B*S tokens.  Builds forward and backward plans over a persistent workspace."""
+
+    H, NH, I = 768, 12, 3072
+
+    def __init__(self, flat, prefix, n_layers, B, S, key_mask, p_drop, seed_dev, sites, splitk=True):
+        self.flat, self.prefix, self.L, self.B, self.S = flat, prefix, n_layers, B, S
+        self.T = B * S
+        self.key_mask = key_mask            # int64 [B,S] device tensor (static buffer)
+        self.p = float(p_drop)
+        self.seed_dev = seed_dev
+        dev, T, H, I = flat.device, self.T, self.H, self.I
+        ct = flat.compute_dtype
+        self.bf = ct == torch.bfloat16
+        f32 = torch.float32
+        e = lambda *s, dtype=f32: torch.empty(*s, device=dev, dtype=dtype)
+        self.layers = []
+        # fp32 GEMM outputs that may be produced by split-K atomics live in two arenas zeroed ONCE per pass
+        self.yarena = e(n_layers, 2, T, H)
+        self.garena = e(n_layers, 2, T, H)
+        for l in range(n_layers):
+            ws = dict(qkv=e(T, 3 * H, dtype=ct), lse=e(B, self.NH, S), ctx=e(T, H, dtype=ct),
+                      y1=self.yarena[l, 0], st1=e(T, 2), a32=e(T, H), u=e(T, I, dtype=ct), f=e(T, I, dtype=ct),
+                      y2=self.yarena[l, 1], st2=e(T, 2), o32=e(T, H))
+            ws["a16"] = e(T, H, dtype=ct) if self.bf else ws["a32"]
+            ws["o16"] = e(T, H, dtype=ct) if self.bf else ws["o32"]
+            ws["off"] = [sites.next() for _ in range(3)]     # attention probs, self-output, output dropout
+            self.layers.append(ws)
+        # backward scratch shared by all layers
+        self.gbuf = e(T, H)
+        self.dxd = e(T, H, dtype=ct)
+        self.du = e(T, I, dtype=ct)
+        self.dctx = e(T, H, dtype=ct)
+        self.dqkv = e(T, 3 * H, dtype=ct)
+        # split-K for the N=768 products when the grid would not fill the chip
+        tiles = ((T + 63) // 64) * (H // 64)
+        self.ks_h = 1
+        if splitk and tiles < 128:
+            self.ks_h = 4 if tiles * 4 <= 512 else 2
+
+    def _names(self, l):
+        p = "%s.encoder.layer.%d" % (self.prefix, l)
+        a = p + ".attention.self."
+        return dict(qkv_w=[a + "query.weight", a + "key.weight", a + "value.weight"],
+                    qkv_b=[a + "query.bias", a + "key.bias", a + "value.bias"],
+                    o_w=p + ".attention.output.dense.weight", o_b=p + ".attention.output.dense.bias",
+                    ln1_g=p + ".attention.output.LayerNorm.weight", ln1_b=p + ".attention.output.LayerNorm.bias",
+                    w1=p + ".intermediate.dense.weight", b1=p + ".intermediate.dense.bias",
+                    w2=p + ".output.dense.weight", b2=p + ".output.dense.bias",
+                    ln2_g=p + ".output.LayerNorm.weight", ln2_b=p + ".output.LayerNorm.bias")
+
+    def param_names(self):
+        out = []
+        for l in range(self.L):
+            nm = self._names(l)
+            out += nm["qkv_w"] + nm["qkv_b"] + [nm[k] for k in ("o_w", "o_b", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b")]
+        return out
+
+    def output(self):
+        ws = self.layers[-1]
+        return ws["o32"], ws["o16"]
+
+    # ------------------------------------------------------------------------------------------ forward
+    def build_forward(self, plan, x32, x16, training):
+        fl, dt, T, H, I, S, B = self.flat, self.flat.dt, self.T, self.H, self.I, self.S, self.B
+        p = self.p if training else 0.0
+        if self.ks_h > 1:
+            plan.add_callable(self.yarena.zero_)
+        for l, ws in enumerate(self.layers):
+            nm = self._names(l)
+            wqkv, bqkv = fl.wop_fused(nm["qkv_w"]), fl.w32_fused(nm["qkv_b"])
+            plan.add("univl_gemm", _gemm_desc(dt, x16, H, wqkv, H, T, 3 * H, H, out16=ws["qkv"], ldc=3 * H, bias=bqkv))
+            qkv = ws["qkv"]
+            plan.add("univl_attention_fwd", ops.attention_desc(
+                dt, B, self.NH, S, S, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx"], H, ws["lse"],
+                key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev))
+            plan.add("univl_gemm", _gemm_desc(dt, ws["ctx"], H, fl.wop(nm["o_w"]), H, T, H, H, out32=ws["y1"], ldc=H,
+                                              bias=fl.w32(nm["o_b"]), ksplit=self.ks_h))
+            plan.add("univl_layernorm_fwd", ops.layernorm_desc(
+                dt, T, H, x=ws["y1"], residual=x32, gamma=fl.w32(nm["ln1_g"]), beta=fl.w32(nm["ln1_b"]), y=ws["y1"],
+                stats=ws["st1"], out32=ws["a32"], out16=ws["a16"] if self.bf else None, p_pre=p, off_pre=ws["off"][1],
+                seed_dev=self.seed_dev))
+            plan.add("univl_gemm", _gemm_desc(dt, ws["a16"], H, fl.wop(nm["w1"]), H, T, I, H, out16=ws["f"], ldc=I,
+                                              bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd"))
+            plan.add("univl_gemm", _gemm_desc(dt, ws["f"], I, fl.wop(nm["w2"]), I, T, H, I, out32=ws["y2"], ldc=H,
+                                              bias=fl.w32(nm["b2"]), ksplit=self.ks_h))
+            plan.add("univl_layernorm_fwd", ops.layernorm_desc(
+                dt, T, H, x=ws["y2"], residual=ws["a32"], gamma=fl.w32(nm["ln2_g"]), beta=fl.w32(nm["ln2_b"]), y=ws["y2"],
+                stats=ws["st2"], out32=ws["o32"], out16=ws["o16"] if self.bf else None, p_pre=p, off_pre=ws["off"][2],
+                seed_dev=self.seed_dev))
+            x32, x16 = ws["o32"], ws["o16"]
+
+    # ----------------------------------------------------------------------------------------- backward
+    def build_backward(self, plan, gin, x0_32, x0_16, fresh, training, layer_hook=None):
+        """gin: fp32 [T,H] gradient wrt the last layer's output.  Returns the buffer holding the gradient wrt the
+        stack input.  `fresh`: matrix gradients are written (beta = 0) instead of accumulated."""
+        fl, dt, T, H, I, S, B = self.flat, self.flat.dt, self.T, self.H, self.I, self.S, self.B
+        p = self.p if training else 0.0
+        acc = not fresh
+        if self.ks_h > 1:
+            plan.add_callable(self.garena.zero_)
+        for l in range(self.L - 1, -1, -1):
+            ws, nm = self.layers[l], self._names(l)
+            xin32, xin16 = (x0_32, x0_16) if l == 0 else (self.layers[l - 1]["o32"], self.layers[l - 1]["o16"])
+            dz, da = self.gbuf, self.garena[l, 0]
+            # output LayerNorm / dropout backward (BertOutput, module_bert.py:246-250)
+            plan.add("univl_layernorm_bwd", ops.layernorm_desc(
+                dt, T, H, gamma=fl.w32(nm["ln2_g"]), y=ws["y2"], stats=ws["st2"], dout=gin, dx32=dz, dxd16=self.dxd,
+                dgamma=fl.g(nm["ln2_g"]), dbeta=fl.g(nm["ln2_b"]), dbias=fl.g(nm["b2"]), p_pre=p, off_pre=ws["off"][2],
+                seed_dev=self.seed_dev))
+            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, ws["f"], I, H, I, T, trans_a=1, trans_b=1,
+                                              out32=fl.g(nm["w2"]), ldc=I, accumulate=acc))
+            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, fl.wop(nm["w2"]), I, T, I, H, trans_b=1, out16=self.du,
+                                              ldc=I, aux=ws["u"], ldaux=I, gelu="bwd"))
+            plan.add("univl_gemm", _gemm_desc(dt, self.du, I, ws["a16"], H, I, H, T, trans_a=1, trans_b=1,
+                                              out32=fl.g(nm["w1"]), ldc=H, accumulate=acc, dbias=fl.g(nm["b1"])))
+            plan.add("univl_gemm", _gemm_desc(dt, self.du, I, fl.wop(nm["w1"]), H, T, H, I, trans_b=1, out32=da, ldc=H,
+                                              residual=dz, ldr=H, ksplit=self.ks_h))
+            # attention-output LayerNorm / dropout backward (BertSelfOutput, module_bert.py:207-211)
+            dy = self.gbuf
+            plan.add("univl_layernorm_bwd", ops.layernorm_desc(
+                dt, T, H, gamma=fl.w32(nm["ln1_g"]), y=ws["y1"], stats=ws["st1"], dout=da, dx32=dy, dxd16=self.dxd,
+                dgamma=fl.g(nm["ln1_g"]), dbeta=fl.g(nm["ln1_b"]), dbias=fl.g(nm["o_b"]), p_pre=p, off_pre=ws["off"][1],
+                seed_dev=self.seed_dev))
+            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
+                                              out32=fl.g(nm["o_w"]), ldc=H, accumulate=acc))
+            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, fl.wop(nm["o_w"]), H, T, H, H, trans_b=1, out16=self.dctx, ldc=H))
+            qkv, dqkv = ws["qkv"], self.dqkv
+            plan.add("univl_attention_bwd", ops.attention_desc(
+                dt, B, self.NH, S, S, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx"], H, ws["lse"],
+                key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev, dout=self.dctx, lddo=H,
+                dq=(dqkv, 0), lddq=3 * H, dk=(dqkv, H), lddk=3 * H, dv=(dqkv, 2 * H), lddv=3 * H))
+            plan.add("univl_gemm", _gemm_desc(dt, dqkv, 3 * H, xin16, H, 3 * H, H, T, trans_a=1, trans_b=1,
+                                              out32=fl.g_fused(nm["qkv_w"]), ldc=H, accumulate=acc,
+                                              dbias=fl.g_fused(nm["qkv_b"])))
+            dx = self.garena[l, 1]
+            plan.add("univl_gemm", _gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["qkv_w"]), H, T, H, 3 * H, trans_b=1,
+                                              out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ks_h))
+            gin = dx
+            if layer_hook is not None:
+                layer_hook(plan, self.prefix, l)
+        return gin

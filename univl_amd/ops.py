@@ -1,0 +1,205 @@
+"""Tensor-level wrappers over the C ABI (one call = one enqueue on torch's current HIP stream).
+
+PyTorch is used here only for device memory and streams.  Every function fills the C descriptor from tensor
+pointers/strides and raises RuntimeError on a non-zero status.  The execution plans in `univl_amd.engine` build the
+same descriptors once and replay them; these wrappers are the eager form (unit tests, small host-side ops)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import DT_BF16, DT_F32
+
+_BYREF = C.byref
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def dtype_code(dtype):
+    if dtype == torch.float32:
+        return DT_F32
+    if dtype == torch.bfloat16:
+        return DT_BF16
+    raise RuntimeError("univl_amd: unsupported compute dtype %s (float32 or bfloat16)" % dtype)
+
+
+def _require_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("univl_amd kernels need HIP device tensors (got %s); there is no CPU fallback" % t.device)
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D view"
+    return t.stride(0)
+
+
+def probe_layouts():
+    out = torch.zeros(1792, device="cuda", dtype=torch.float32)
+    _lib.check(_lib.lib().univl_probe_layouts(_p(out), 1792, _stream()), "probe_layouts")
+    return out
+
+
+def gemm(A, B, M, N, K, *, trans_a=False, trans_b=False, out32=None, out16=None, bias=None, residual=None, aux=None,
+         gelu=None, accumulate=False, dbias=None, dbias_atomic=False, ksplit=1, tile=0, alpha=1.0):
+    """C[M,N] = epi(alpha * A_op . B_op^T); A/B are 2-D row-major views ([rows,K] or, if trans_x, [K,rows])."""
+    _require_gpu(A, B, out32, out16)
+    d = _lib.Gemm()
+    d.dtype = dtype_code(A.dtype)
+    assert B.dtype == A.dtype
+    d.trans_a, d.trans_b = int(trans_a), int(trans_b)
+    d.M, d.N, d.K = M, N, K
+    d.A, d.lda, d.B, d.ldb = _p(A), _ld(A), _p(B), _ld(B)
+    d.C32, d.C16 = _p(out32), _p(out16)
+    d.ldc = _ld(out32) if out32 is not None else _ld(out16)
+    if out32 is not None and out16 is not None:
+        assert _ld(out32) == _ld(out16)
+    d.bias = _p(bias)
+    d.R, d.ldr = _p(residual), (_ld(residual) if residual is not None else 0)
+    d.aux, d.ldaux = _p(aux), (_ld(aux) if aux is not None else 0)
+    d.dbias = _p(dbias)
+    d.alpha = alpha
+    flags = 0
+    if accumulate:
+        flags |= _lib.GEMM_ACCUM
+    if gelu == "fwd":
+        flags |= _lib.GEMM_GELU_FWD
+    elif gelu == "bwd":
+        flags |= _lib.GEMM_GELU_BWD
+    if dbias_atomic:
+        flags |= _lib.GEMM_DBIAS_ATOMIC
+    d.flags, d.ksplit, d.tile = flags, ksplit, tile
+    _lib.check(_lib.lib().univl_gemm(_BYREF(d), _stream()), "gemm")
+
+
+def layernorm_desc(dtype, rows, N, *, x=None, x_f64=False, residual=None, pos=None, pos_period=0, gamma=None,
+                   beta=None, eps=1e-12, y=None, stats=None, out32=None, out16=None, p_pre=0.0, p_post=0.0, seed=0,
+                   off_pre=0, off_post=0, seed_dev=None, dout=None, dx32=None, dxd32=None, dxd16=None, dgamma=None,
+                   dbeta=None, dbias=None, dpos=None):
+    d = _lib.LayerNorm()
+    d.dtype, d.rows, d.N, d.x_f64 = dtype, rows, N, int(x_f64)
+    d.x, d.residual, d.pos, d.pos_period = _p(x), _p(residual), _p(pos), pos_period
+    d.gamma, d.beta, d.eps = _p(gamma), _p(beta), eps
+    d.y, d.stats, d.out32, d.out16 = _p(y), _p(stats), _p(out32), _p(out16)
+    d.p_pre, d.p_post, d.seed, d.off_pre, d.off_post, d.seed_dev = p_pre, p_post, seed, off_pre, off_post, _p(seed_dev)
+    d.dout, d.dx32, d.dxd32, d.dxd16 = _p(dout), _p(dx32), _p(dxd32), _p(dxd16)
+    d.dgamma, d.dbeta, d.dbias, d.dpos = _p(dgamma), _p(dbeta), _p(dbias), _p(dpos)
+    return d
+
+
+def layernorm_fwd(**kw):
+    d = layernorm_desc(**kw)
+    _lib.check(_lib.lib().univl_layernorm_fwd(_BYREF(d), _stream()), "layernorm_fwd")
+
+
+def layernorm_bwd(**kw):
+    d = layernorm_desc(**kw)
+    _lib.check(_lib.lib().univl_layernorm_bwd(_BYREF(d), _stream()), "layernorm_bwd")
+
+
+def attention_desc(dtype, B, H, Sq, Sk, q, ldq, k, ldk, v, ldv, out, ldo, lse, *, key_mask=None, causal=False,
+                   p_drop=0.0, seed=0, offset=0, seed_dev=None, dout=None, lddo=0, dq=None, lddq=0, dk=None, lddk=0,
+                   dv=None, lddv=0):
+    """q/k/v/out/... are (tensor, element_offset) pairs or tensors; ld in elements."""
+    def ptr(t):
+        if t is None:
+            return None
+        if isinstance(t, tuple):
+            return C.c_void_p(t[0].data_ptr() + t[1] * t[0].element_size())
+        return C.c_void_p(t.data_ptr())
+    d = _lib.Attention()
+    d.dtype, d.B, d.H, d.Sq, d.Sk = dtype, B, H, Sq, Sk
+    d.q, d.ldq, d.k, d.ldk, d.v, d.ldv = ptr(q), ldq, ptr(k), ldk, ptr(v), ldv
+    d.key_mask, d.causal = _p(key_mask), int(causal)
+    d.out, d.ldo, d.lse = ptr(out), ldo, _p(lse)
+    d.p_drop, d.seed, d.offset, d.seed_dev = p_drop, seed, offset, _p(seed_dev)
+    d.dout, d.lddo, d.dq, d.lddq, d.dk, d.lddk, d.dv, d.lddv = ptr(dout), lddo, ptr(dq), lddq, ptr(dk), lddk, ptr(dv), lddv
+    return d
+
+
+def attention_fwd(*a, **kw):
+    d = attention_desc(*a, **kw)
+    _lib.check(_lib.lib().univl_attention_fwd(_BYREF(d), _stream()), "attention_fwd")
+
+
+def attention_bwd(*a, **kw):
+    d = attention_desc(*a, **kw)
+    _lib.check(_lib.lib().univl_attention_bwd(_BYREF(d), _stream()), "attention_bwd")
+
+
+def embed_text_desc(dtype, B, S, ids, word, pos, gamma, beta, *, type_ids=None, type_emb=None, eps=1e-12, y=None,
+                    stats=None, out32=None, out16=None, p_post=0.0, seed=0, off_post=0, seed_dev=None, dout=None,
+                    dword=None, dpos=None, dtype_emb=None, dgamma=None, dbeta=None):
+    d = _lib.EmbedText()
+    d.dtype, d.B, d.S, d.N = dtype, B, S, 768
+    d.ids, d.type_ids = _p(ids), _p(type_ids)
+    d.word, d.pos, d.type = _p(word), _p(pos), _p(type_emb)
+    d.gamma, d.beta, d.eps = _p(gamma), _p(beta), eps
+    d.y, d.stats, d.out32, d.out16 = _p(y), _p(stats), _p(out32), _p(out16)
+    d.p_post, d.seed, d.off_post, d.seed_dev = p_post, seed, off_post, _p(seed_dev)
+    d.dout, d.dword, d.dpos, d.dtype_emb, d.dgamma, d.dbeta = _p(dout), _p(dword), _p(dpos), _p(dtype_emb), _p(dgamma), _p(dbeta)
+    return d
+
+
+def embed_text_fwd(*a, **kw):
+    d = embed_text_desc(*a, **kw)
+    _lib.check(_lib.lib().univl_embed_text_fwd(_BYREF(d), _stream()), "embed_text_fwd")
+
+
+def embed_text_bwd(*a, **kw):
+    d = embed_text_desc(*a, **kw)
+    _lib.check(_lib.lib().univl_embed_text_bwd(_BYREF(d), _stream()), "embed_text_bwd")
+
+
+def pool_desc(B, S, x, mask, *, skip_first, normalize, mean=None, out=None, dout=None, dx=None, ldx_row=768):
+    d = _lib.Pool()
+    d.B, d.S, d.N = B, S, 768
+    d.x, d.ldx_row, d.mask = _p(x), ldx_row, _p(mask)
+    d.skip_first, d.normalize = int(skip_first), int(normalize)
+    d.mean, d.out, d.dout, d.dx = _p(mean), _p(out), _p(dout), _p(dx)
+    return d
+
+
+def pool_fwd(*a, **kw):
+    d = pool_desc(*a, **kw)
+    _lib.check(_lib.lib().univl_pool_fwd(_BYREF(d), _stream()), "pool_fwd")
+
+
+def pool_bwd(*a, **kw):
+    d = pool_desc(*a, **kw)
+    _lib.check(_lib.lib().univl_pool_bwd(_BYREF(d), _stream()), "pool_bwd")
+
+
+def maxmargin_loss(sim, margin, weight, loss, dsim):
+    """sim/dsim: [n, ld] row-major views (ld = stride(0) >= n)."""
+    n = sim.shape[0]
+    assert dsim.stride(0) == sim.stride(0)
+    _lib.check(_lib.lib().univl_maxmargin_loss(_p(sim), n, sim.stride(0), margin, _p(weight), _p(loss), _p(dsim), _stream()), "maxmargin")
+
+
+def crossen_loss(sim, loss, dsim):
+    assert dsim.stride(0) == sim.stride(0)
+    _lib.check(_lib.lib().univl_crossen_loss(_p(sim), sim.shape[0], sim.stride(0), _p(loss), _p(dsim), _stream()), "crossen")
+
+
+def milnce_loss(sim, batch_size, n_pair, loss, dsim):
+    assert dsim.stride(0) == sim.stride(0)
+    _lib.check(_lib.lib().univl_milnce_loss(_p(sim), batch_size, n_pair, sim.stride(0), _p(loss), _p(dsim), _stream()), "milnce")
+
+
+def scale_by_device_scalar(x, s):
+    _lib.check(_lib.lib().univl_scale_by_device_scalar(_p(x), x.numel(), _p(s), _stream()), "scale_by_device_scalar")
+
+
+def cast_bf16(src, dst):
+    _lib.check(_lib.lib().univl_cast_bf16(_p(src), _p(dst), src.numel(), _stream()), "cast_bf16")
+
+
+def bump_counter(ctr):
+    _lib.check(_lib.lib().univl_bump_counter(_p(ctr), _stream()), "bump_counter")

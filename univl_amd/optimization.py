@@ -1,0 +1,227 @@
+"""Drop-in for the reference's `modules/optimization.py::BertAdam` and for the `clip_grad_norm_` call of the
+training loop (main_task_retrieval.py:347), fused over the flat parameter / gradient buffers of
+`univl_amd.engine.FlatParams`: three kernel launches per step instead of ~12 per parameter tensor.
+
+Same constructor, param-group semantics, `state[p] = {step, next_m, next_v}` keys (so optimizer checkpoints of
+main_pretrain.py:266-273 interchange) and update rule (optimization.py:103-168): per-parameter clip, Adam moments
+without bias correction, decoupled weight decay, warmup-linear learning rate, parameters whose `.grad is None`
+are skipped.  Runs only on parameters owned by a univl_amd model on a HIP device (no CPU fallback).
+"""
+import ctypes as C
+
+import torch
+from torch.optim import Optimizer
+
+from . import _lib, ops
+from .engine import FLAT_REGISTRY
+
+CHUNK = 8192   # elements per workgroup
+
+
+def warmup_linear(x, warmup=0.002):
+    """optimization.py:38-43."""
+    if x < warmup:
+        return x / warmup
+    return max((x - 1.) / (warmup - 1.), 0)
+
+
+def _find_flat(p):
+    ptr = p.data_ptr()
+    for fl in list(FLAT_REGISTRY):
+        lo = fl.p32.data_ptr()
+        if lo <= ptr < lo + fl.total * 4:
+            return fl
+    raise RuntimeError("univl_amd.optimization: parameter is not owned by a univl_amd model on a HIP device "
+                       "(call the model once, or access model.flat, after model.to('cuda')); there is no CPU fallback")
+
+
+class _Tables:
+    """Device-side segment / chunk tables for one FlatParams and one (lr, wd, max_norm, active) assignment."""
+
+    def __init__(self, fl, seg_cfg):
+        dev = fl.device
+        nseg = len(fl.order)
+        segs = (_lib.Seg * nseg)()
+        c_seg, c_off, c_len = [], [], []
+        for s, n in enumerate(fl.order):
+            off, numel, _ = fl.index[n]
+            lr, wd, mgn, active = seg_cfg.get(n, (0.0, 0.0, 0.0, 0))
+            segs[s].offset, segs[s].numel = off, numel
+            segs[s].lr, segs[s].weight_decay, segs[s].max_grad_norm, segs[s].active = lr, wd, mgn, int(active)
+            for o in range(0, numel, CHUNK):
+                c_seg.append(s)
+                c_off.append(off + o)
+                c_len.append(min(CHUNK, numel - o))
+        raw = bytes(segs)
+        self.segs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.chunk_seg = torch.tensor(c_seg, dtype=torch.int32, device=dev)
+        self.chunk_off = torch.tensor(c_off, dtype=torch.int64, device=dev)
+        self.chunk_len = torch.tensor(c_len, dtype=torch.int32, device=dev)
+        self.nseg, self.nchunk = nseg, len(c_seg)
+        self.sumsq = torch.zeros(nseg, device=dev)
+        self.coef = torch.ones(2, device=dev)
+        self.scalars = torch.zeros(2 * nseg, device=dev)
+        self.key = tuple(sorted(seg_cfg.items()))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _sumsq(fl, tb):
+    tb.sumsq.zero_()
+    _lib.check(_lib.lib().univl_grad_sumsq(fl.g32.data_ptr(), tb.segs.data_ptr(), tb.nseg, tb.chunk_seg.data_ptr(),
+                                           tb.chunk_off.data_ptr(), tb.chunk_len.data_ptr(), tb.nchunk,
+                                           tb.sumsq.data_ptr(), _stream()), "grad_sumsq")
+
+
+def _active_cfg(fl, params_with_cfg):
+    cfg = {}
+    ptr2name = {fl.params[n].data_ptr(): n for n in fl.order}
+    for p, (lr, wd, mgn) in params_with_cfg:
+        n = ptr2name.get(p.data_ptr())
+        if n is None:
+            raise RuntimeError("univl_amd.optimization: parameter not found in the model's flat buffer")
+        if p.grad is None:
+            continue
+        if p.grad.data_ptr() != fl.g(n).data_ptr():
+            fl.g(n).copy_(p.grad)          # a foreign gradient tensor: bring it into the flat buffer
+            p.grad = fl.g(n)
+        cfg[n] = (float(lr), float(wd), float(mgn), 1)
+    return cfg
+
+
+def clip_grad_norm_(parameters, max_norm, norm_type=2.0, deferred=True):
+    """Fused torch.nn.utils.clip_grad_norm_ for univl_amd models (main_task_retrieval.py:347).
+
+    One streaming read of the flat gradient buffer gives every per-tensor sum of squares (re-used by BertAdam's
+    per-parameter clip).  deferred=True (default) folds the clip coefficient into the following BertAdam.step
+    instead of rewriting 4 B/param of gradients; deferred=False scales the gradients in place like torch does.
+    Returns the total norm (0-d device tensor)."""
+    assert float(norm_type) == 2.0, "only the L2 norm is used by the reference"
+    params = [p for p in (parameters if not isinstance(parameters, torch.Tensor) else [parameters]) if p.grad is not None]
+    if not params:
+        return torch.tensor(0.0)
+    fl = _find_flat(params[0])
+    cfg = _active_cfg(fl, [(p, (0.0, 0.0, 0.0)) for p in params])
+    key = tuple(sorted(cfg))
+    tb = fl._clip[1] if (fl._clip is not None and fl._clip[0] == key) else None
+    if tb is None:
+        tb = _Tables(fl, cfg)
+        fl._clip = (key, tb)
+    _sumsq(fl, tb)
+    L = _lib.lib()
+    _lib.check(L.univl_clip_coef(tb.sumsq.data_ptr(), tb.segs.data_ptr(), tb.nseg, float(max_norm), tb.coef.data_ptr(),
+                                 _stream()), "clip_coef")
+    if not deferred:
+        _lib.check(L.univl_scale_grads(fl.g32.data_ptr(), tb.segs.data_ptr(), tb.chunk_seg.data_ptr(),
+                                       tb.chunk_off.data_ptr(), tb.chunk_len.data_ptr(), tb.nchunk, tb.coef.data_ptr(),
+                                       _stream()), "scale_grads")
+        fl._pending = None
+    else:
+        fl._pending = dict(version=fl.grad_version, names=key, sumsq=tb.sumsq, coef=tb.coef)
+    return tb.coef[1]
+
+
+class BertAdam(Optimizer):
+    """Fused BERT-Adam (see module docstring).  Arguments as modules/optimization.py:66-84."""
+
+    def __init__(self, params, lr=None, warmup=-1, t_total=-1, schedule='warmup_linear', b1=0.9, b2=0.999, e=1e-6,
+                 weight_decay=0.01, max_grad_norm=1.0):
+        if lr is None or lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if schedule != 'warmup_linear':
+            raise ValueError("Invalid schedule parameter: {} (univl_amd implements warmup_linear, the one the "
+                             "reference's scripts use)".format(schedule))
+        if not 0.0 <= warmup < 1.0 and not warmup == -1:
+            raise ValueError("Invalid warmup: {} - should be in [0.0, 1.0[ or -1".format(warmup))
+        if not 0.0 <= b1 < 1.0:
+            raise ValueError("Invalid b1 parameter: {} - should be in [0.0, 1.0[".format(b1))
+        if not 0.0 <= b2 < 1.0:
+            raise ValueError("Invalid b2 parameter: {} - should be in [0.0, 1.0[".format(b2))
+        if not e >= 0.0:
+            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(e))
+        defaults = dict(lr=lr, schedule=schedule, warmup=warmup, t_total=t_total, b1=b1, b2=b2, e=e,
+                        weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        super(BertAdam, self).__init__(params, defaults)
+        g0 = self.param_groups[0]
+        for g in self.param_groups:
+            for k in ("warmup", "t_total", "b1", "b2", "e", "schedule"):
+                if g[k] != g0[k]:
+                    raise ValueError("univl_amd BertAdam: '%s' must be the same in every param group" % k)
+        self._fl = None
+        self._tb = None
+        self._m = self._v = self._step_dev = None
+
+    def get_lr(self):
+        """optimization.py:86-101."""
+        lr = []
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                state = self.state[p]
+                if len(state) == 0:
+                    return [0]
+                if group['t_total'] != -1:
+                    lr_scheduled = group['lr'] * warmup_linear(state['step'] / group['t_total'], group['warmup'])
+                else:
+                    lr_scheduled = group['lr']
+                lr.append(lr_scheduled)
+        return lr
+
+    def _bind(self):
+        p0 = self.param_groups[0]['params'][0]
+        fl = _find_flat(p0)
+        if self._fl is not fl:
+            self._fl = fl
+            self._m = torch.zeros(fl.total, device=fl.device)
+            self._v = torch.zeros(fl.total, device=fl.device)
+            self._step_dev = torch.zeros(len(fl.order), device=fl.device, dtype=torch.int32)
+            self._tb = None
+        return fl
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        fl = self._bind()
+        pw = []
+        for group in self.param_groups:
+            for p in group['params']:
+                pw.append((p, (group['lr'], group['weight_decay'], group['max_grad_norm'])))
+        cfg = _active_cfg(fl, pw)
+        key = tuple(sorted(cfg.items()))
+        if self._tb is None or self._tb.key != key:
+            self._tb = _Tables(fl, cfg)
+        tb = self._tb
+        pend = getattr(fl, "_pending", None)
+        coef_ptr = None
+        if pend is not None and pend["version"] == fl.grad_version and pend["names"] == tuple(sorted(cfg)):
+            sumsq, coef_ptr = pend["sumsq"], pend["coef"].data_ptr()      # clip already measured these gradients
+        else:
+            _sumsq(fl, tb)
+            sumsq = tb.sumsq
+        fl._pending = None
+        g0 = self.param_groups[0]
+        d = _lib.Adam()
+        d.p, d.g, d.m, d.v = fl.p32.data_ptr(), fl.g32.data_ptr(), self._m.data_ptr(), self._v.data_ptr()
+        d.p16 = fl.p16.data_ptr() if fl.p16 is not None else None
+        d.segs, d.nseg = tb.segs.data_ptr(), tb.nseg
+        d.chunk_seg, d.chunk_off, d.chunk_len, d.nchunk = (tb.chunk_seg.data_ptr(), tb.chunk_off.data_ptr(),
+                                                           tb.chunk_len.data_ptr(), tb.nchunk)
+        d.sumsq, d.coef, d.step = sumsq.data_ptr(), coef_ptr, self._step_dev.data_ptr()
+        d.b1, d.b2, d.eps = g0['b1'], g0['b2'], g0['e']
+        d.warmup, d.t_total = float(g0['warmup']), int(g0['t_total'])
+        d.seg_scalars = tb.scalars.data_ptr()
+        _lib.check(_lib.lib().univl_bert_adam(C.byref(d), _stream()), "bert_adam")
+        fl.shadow_valid = True      # the step rewrote the bf16 shadow
+        for n in cfg:
+            p = fl.params[n]
+            st = self.state[p]
+            if len(st) == 0:
+                o, k, shp = fl.index[n]
+                st['step'] = 0
+                st['next_m'] = self._m[o:o + k].view(shp)
+                st['next_v'] = self._v[o:o + k].view(shp)
+            st['step'] += 1
+        return loss

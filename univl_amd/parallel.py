@@ -1,0 +1,86 @@
+"""Data-parallel gradient exchange for the UniVL hot path.
+
+The reference wraps the model in torch DDP over NCCL (main_task_retrieval.py:197-198): bucketed all-reduce(SUM)/world
+of every gradient during backward, plus a per-iteration unused-parameter bitmap all-reduce
+(find_unused_parameters=True).  Here:
+  * gradients already live in ONE flat fp32 buffer laid out by layer, so a bucket is a contiguous slice -- no
+    flatten/unflatten copies, and the set of gradient-less parameters is static (the two dead poolers), so the
+    bitmap exchange disappears;
+  * one process per GPU, `torch.distributed` backend "nccl" (= RCCL over xGMI on ROCm).  Each layer's slice is
+    all-reduced (AVG) as soon as that layer's last wgrad kernel has been enqueued; RCCL runs it on its own HIP
+    stream behind an event, overlapping the rest of the backward; the step joins all buckets before the clip.
+  * works unchanged with backend "gloo" on CPU tensors (world_size-2 tests in tests/test_parallel_cpu.py).
+"""
+import torch
+import torch.distributed as dist
+
+
+class BucketReducer:
+    """All-reduce (mean) contiguous slices of a flat gradient buffer, asynchronously, in a fixed order."""
+
+    def __init__(self, flat_grad, process_group=None):
+        self.g = flat_grad
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.pending = []
+        self.bytes_reduced = 0
+        backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
+        self._avg = backend == "nccl"
+
+    def reduce_slice(self, start, end):
+        """Launch the all-reduce of g[start:end]; returns immediately (the collective is stream-/thread-async)."""
+        if self.world == 1 or end <= start:
+            return
+        t = self.g[start:end]
+        if self._avg:
+            w = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+        else:
+            w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self.pending.append((w, t))
+        self.bytes_reduced += t.numel() * t.element_size()
+
+    def join(self):
+        """Make the current stream (or thread, for gloo) wait for every outstanding bucket."""
+        for w, t in self.pending:
+            w.wait()
+            if not self._avg:
+                t.div_(self.world)
+        self.pending = []
+
+
+def layer_buckets(flat, used_names):
+    """Bucket plan over FlatParams: one bucket per encoder layer (its four weight matrices are contiguous,
+    ~28 MB fp32 -- the size of a default DDP bucket), one for the remaining matrices and one for the whole
+    atomic/vector region (embedding tables + all biases / LayerNorm parameters).  Returns
+    {"layers": {(prefix, l): (start, end)}, "tail": [(start, end), ...]}; slices never overlap and cover every
+    used parameter exactly once."""
+    layers, covered = {}, []
+    for n in used_names:
+        parts = n.split(".")
+        if len(parts) > 3 and parts[1] == "encoder" and parts[2] == "layer" and len(flat.index[n][2]) == 2:
+            key = (parts[0], int(parts[3]))
+            o, k, _ = flat.index[n]
+            end = o + (k + 63) // 64 * 64
+            if key in layers:
+                s, e = layers[key]
+                layers[key] = (min(s, o), max(e, end))
+            else:
+                layers[key] = (o, end)
+    for s, e in layers.values():
+        covered.append((s, e))
+    covered.sort()
+    tail = [(0, flat.v_end)]
+    cur = flat.v_end
+    for s, e in covered:
+        if s > cur:
+            tail.append((cur, s))
+        cur = max(cur, e)
+    if cur < flat.total:
+        tail.append((cur, flat.total))
+    return dict(layers=layers, tail=tail)
+
+
+def broadcast_parameters(flat_p32, src=0, process_group=None):
+    """DDP's constructor broadcast: one collective over the flat buffer."""
+    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        dist.broadcast(flat_p32, src=src, group=process_group)
