@@ -138,15 +138,17 @@ def test_gemm_gelu_epilogues_and_splitk(dtype):
 
 
 def test_gemm_argument_errors():
-    A = torch.zeros(8, 12, device=DEV)           # ld 12 not a multiple of 4? (12 % 4 == 0) -> use misaligned view
-    B = torch.zeros(8, 12, device=DEV)
+    A = torch.zeros(8, 256, device=DEV)
+    B = torch.zeros(8, 256, device=DEV)
     out = torch.zeros(8, 8, device=DEV)
     with pytest.raises(RuntimeError):
         ops.gemm(A[:, 1:], B[:, 1:], 8, 8, 8, out32=out)          # pointer not 16-byte aligned
     with pytest.raises(RuntimeError):
-        ops.gemm(A, B, 8, 8, 12, out16=out, ksplit=2)             # split-K needs fp32 output
+        ops.gemm(A, B, 8, 8, 256, out16=out, ksplit=2)            # split-K needs fp32 output
     with pytest.raises(RuntimeError):
-        ops.gemm(A.cpu(), B.cpu(), 8, 8, 12, out32=out)           # CPU tensors: no fallback
+        ops.gemm(A, B, 8, 8, 256, out32=out, gelu="fwd")          # GELU epilogue without aux
+    with pytest.raises(RuntimeError):
+        ops.gemm(A.cpu(), B.cpu(), 8, 8, 256, out32=out)          # CPU tensors: no fallback
 
 
 # --------------------------------------------------------------------------------------------- LayerNorm
