@@ -36,8 +36,8 @@ __device__ __forceinline__ void stage_rows(T* lds, const T* g, long ld, int rows
     constexpr int CPR = HD / EPC;   // 16-byte pieces per row
     for (int c = tid; c < rows_pad * CPR; c += 256) {
         const int r = c / CPR, e = (c % CPR) * EPC;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (r < rows) v = *reinterpret_cast<const uint4*>(g + (long)r * ld + e);
+        uint4 v = *reinterpret_cast<const uint4*>(g + (long)min(r, rows - 1) * ld + e);   // unconditional load
+        if (r >= rows) v = make_uint4(0u, 0u, 0u, 0u);
         *reinterpret_cast<uint4*>(lds + r * P + e) = v;
     }
 }
@@ -92,10 +92,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(UnivlAttention p, int Sk_
     if (q0 >= p.Sq) return;
     const int q = q0 + i;
     const bool qv = q < p.Sq;
-    const T* Qg = reinterpret_cast<const T*>(p.q) + ((long)b * p.Sq + q) * p.ldq + h * HD;
+    const int qc = min(q, p.Sq - 1);      // clamped row: lanes beyond Sq compute on a valid row and never store
+    const T* Qg = reinterpret_cast<const T*>(p.q) + ((long)b * p.Sq + qc) * p.ldq + h * HD;
     typename M::frag fq[C::NCD];
 #pragma unroll
-    for (int c = 0; c < C::NCD; ++c) fq[c] = M::gmem_kmajor(Qg + c * C::CH, g, qv);
+    for (int c = 0; c < C::NCD; ++c) fq[c] = M::gmem_kmajor(Qg + c * C::CH, g);
 
     const int nkt = Sk_pad / 16;
     f32x4_t s[MAXKT];
@@ -200,17 +201,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_
         const bool qv = q < p.Sq;
         typename M::frag fq[C::NCD], fdo[C::NCD];
         float dsum = 0.f;
+        const int qc = min(q, p.Sq - 1);
 #pragma unroll
         for (int c = 0; c < C::NCD; ++c) {
-            fq[c] = M::gmem_kmajor(Qb + (long)q * p.ldq + c * C::CH, g, qv);
-            fdo[c] = M::gmem_kmajor(dOb + (long)q * p.lddo + c * C::CH, g, qv);
-            const typename M::frag fo = M::gmem_kmajor(Ob + (long)q * p.ldo + c * C::CH, g, qv);
+            fq[c] = M::gmem_kmajor(Qb + (long)qc * p.ldq + c * C::CH, g);
+            fdo[c] = M::gmem_kmajor(dOb + (long)qc * p.lddo + c * C::CH, g);
+            const typename M::frag fo = M::gmem_kmajor(Ob + (long)qc * p.ldo + c * C::CH, g);
 #pragma unroll
             for (int e = 0; e < C::EPC; ++e) dsum += to_f32<T>(fdo[c][e]) * to_f32<T>(fo[e]);
         }
         dsum += __shfl_xor(dsum, 16, 64);
         dsum += __shfl_xor(dsum, 32, 64);
-        const float lse = qv ? p.lse[(long)bh * p.Sq + q] : 0.0f;
+        const float lse = p.lse[(long)bh * p.Sq + qc];
         const uint64_t drow = ((uint64_t)bh * p.Sq + q) * (uint64_t)p.Sk;
         f32x4_t dq[4];
 #pragma unroll
@@ -279,10 +281,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_
         const int key = k0 + i;
         const bool kv = key < p.Sk;
         typename M::frag fk[C::NCD], fv[C::NCD];
+        const int keyc = min(key, p.Sk - 1);
 #pragma unroll
         for (int c = 0; c < C::NCD; ++c) {
-            fk[c] = M::gmem_kmajor(Kb + (long)key * p.ldk + c * C::CH, g, kv);
-            fv[c] = M::gmem_kmajor(Vb + (long)key * p.ldv + c * C::CH, g, kv);
+            fk[c] = M::gmem_kmajor(Kb + (long)keyc * p.ldk + c * C::CH, g);
+            fv[c] = M::gmem_kmajor(Vb + (long)keyc * p.ldv + c * C::CH, g);
         }
         const float mkey = kv ? sM[key] : 0.0f;
         f32x4_t dk[4], dv[4];

@@ -110,18 +110,14 @@ template <> struct Mma<__bf16> {
         f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
         return f;
     }
-    // same, straight from global memory (used for loop-invariant operands held in registers)
-    __device__ static __forceinline__ frag gmem_kmajor(const __bf16* p, int g, bool valid) {
+    // same, straight from global memory (loop-invariant operands held in registers).  Unconditional: callers clamp
+    // the row so that the address is always valid (a branch around a load costs a full vmcnt(0) drain).
+    __device__ static __forceinline__ frag gmem_kmajor(const __bf16* p, int g) {
+        bf16x4_t lo = *reinterpret_cast<const bf16x4_t*>(p + 4 * g);
+        bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(p + 16 + 4 * g);
         frag f;
-        if (valid) {
-            bf16x4_t lo = *reinterpret_cast<const bf16x4_t*>(p + 4 * g);
-            bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(p + 16 + 4 * g);
-            f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-            f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.0f;
-        }
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
         return f;
     }
     // T-major: `base` points at element (contraction row k0, tile column 0 of the 16 columns) in LDS; `pitch`
@@ -162,10 +158,8 @@ template <> struct Mma<float> {
     __device__ static __forceinline__ frag lds_kmajor(const float* p, int g) {
         return *reinterpret_cast<const f32x4_t*>(p + 4 * g);
     }
-    __device__ static __forceinline__ frag gmem_kmajor(const float* p, int g, bool valid) {
-        frag f = {0.f, 0.f, 0.f, 0.f};
-        if (valid) f = *reinterpret_cast<const f32x4_t*>(p + 4 * g);
-        return f;
+    __device__ static __forceinline__ frag gmem_kmajor(const float* p, int g) {
+        return *reinterpret_cast<const f32x4_t*>(p + 4 * g);
     }
     __device__ static __forceinline__ frag lds_tmajor(const float* base, int pitch, int lane) {
         const int g = lane >> 4, i = lane & 15;

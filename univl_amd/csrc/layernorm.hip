@@ -18,10 +18,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(UnivlLayerNorm p) {
     const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
     const float inv_keep_pre = p.p_pre > 0.f ? 1.0f / (1.0f - p.p_pre) : 1.0f;
     const float inv_keep_post = p.p_post > 0.f ? 1.0f / (1.0f - p.p_post) : 1.0f;
+    // all loads of one kind are issued back to back inside ONE flag-uniform branch (a branch per load would drain
+    // vmcnt(0) behind each of them)
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const int col = 4 * lane + 256 * j;
-        const long o = (long)row * N + col;
+        const long o = (long)row * N + 4 * lane + 256 * j;
         if (F64) {
             const double* x = reinterpret_cast<const double*>(p.x) + o;
             const double2 a = *reinterpret_cast<const double2*>(x);
@@ -31,19 +32,34 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(UnivlLayerNorm p) {
             const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.x) + o);
             v[j][0] = a.x; v[j][1] = a.y; v[j][2] = a.z; v[j][3] = a.w;
         }
-        if (p.p_pre > 0.f) {
+    }
+    if (p.p_pre > 0.f) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const long o = (long)row * N + 4 * lane + 256 * j;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[j][e] *= dropout_scale(seed, p.off_pre, (uint64_t)(o + e), p.p_pre, inv_keep_pre);
         }
-        if (p.residual) {
-            const float4 r = *reinterpret_cast<const float4*>(p.residual + o);
-            v[j][0] += r.x; v[j][1] += r.y; v[j][2] += r.z; v[j][3] += r.w;
-        }
-        if (p.pos) {
-            const float4 r = *reinterpret_cast<const float4*>(p.pos + (long)(row % p.pos_period) * N + col);
-            v[j][0] += r.x; v[j][1] += r.y; v[j][2] += r.z; v[j][3] += r.w;
-        }
-        if (p.y) *reinterpret_cast<float4*>(p.y + o) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+    }
+    if (p.residual) {
+        float4 r[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) r[j] = *reinterpret_cast<const float4*>(p.residual + (long)row * N + 4 * lane + 256 * j);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { v[j][0] += r[j].x; v[j][1] += r[j].y; v[j][2] += r[j].z; v[j][3] += r[j].w; }
+    }
+    if (p.pos) {
+        float4 r[NV];
+        const float* pp = p.pos + (long)(row % p.pos_period) * N;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) r[j] = *reinterpret_cast<const float4*>(pp + 4 * lane + 256 * j);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { v[j][0] += r[j].x; v[j][1] += r[j].y; v[j][2] += r[j].z; v[j][3] += r[j].w; }
+    }
+    if (p.y) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            *reinterpret_cast<float4*>(p.y + (long)row * N + 4 * lane + 256 * j) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
     }
     float s = 0.f;
 #pragma unroll
@@ -106,7 +122,7 @@ __device__ __forceinline__ void block_colsum(float (*red)[N], const float (&part
 }
 
 template <int N, typename TO>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(UnivlLayerNorm p) {
+__global__ __launch_bounds__(256) void ln_bwd_kernel(UnivlLayerNorm p, int rpw) {
     constexpr int NV = N / 256;
     __shared__ float red[4][N];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -124,8 +140,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(UnivlLayerNorm p) {
         const float4 t = *reinterpret_cast<const float4*>(p.gamma + 4 * lane + 256 * j);
         ga[j][0] = t.x; ga[j][1] = t.y; ga[j][2] = t.z; ga[j][3] = t.w;
     }
-    for (int rr = 0; rr < LN_RPW; ++rr) {
-        const int row = (blockIdx.x * 4 + wave) * LN_RPW + rr;
+    for (int rr = 0; rr < rpw; ++rr) {
+        const int row = (blockIdx.x * 4 + wave) * rpw + rr;
         if (row >= p.rows) break;
         const float mean = p.stats[2 * (long)row], rstd = p.stats[2 * (long)row + 1];
         float dy[NV][4], xh[NV][4];
@@ -227,14 +243,18 @@ extern "C" int univl_layernorm_bwd(const UnivlLayerNorm* d, hipStream_t stream) 
     UNIVL_CHECK_ARG(aligned16(d->dout) && aligned16(d->y) && aligned16(d->dx32) && aligned16(d->dxd32) &&
                         aligned16(d->dxd16) && aligned16(d->gamma),
                     UNIVL_EALIGN, "univl_layernorm_bwd: pointers must be 16-byte aligned");
-    dim3 grid((d->rows + 4 * LN_RPW - 1) / (4 * LN_RPW)), block(256);
+    // rows per wave: 1 while the grid is small (parallelism first), up to LN_RPW once it fills the chip (fewer
+    // column-sum atomics per row)
+    int rpw = d->rows / 2048;
+    rpw = rpw < 1 ? 1 : (rpw > LN_RPW ? LN_RPW : rpw);
+    dim3 grid((d->rows + 4 * rpw - 1) / (4 * rpw)), block(256);
     const bool bf = d->dtype == UNIVL_DT_BF16;
     if (d->N == 768) {
-        if (bf) hipLaunchKernelGGL((ln_bwd_kernel<768, __bf16>), grid, block, 0, stream, *d);
-        else hipLaunchKernelGGL((ln_bwd_kernel<768, float>), grid, block, 0, stream, *d);
+        if (bf) hipLaunchKernelGGL((ln_bwd_kernel<768, __bf16>), grid, block, 0, stream, *d, rpw);
+        else hipLaunchKernelGGL((ln_bwd_kernel<768, float>), grid, block, 0, stream, *d, rpw);
     } else {
-        if (bf) hipLaunchKernelGGL((ln_bwd_kernel<1024, __bf16>), grid, block, 0, stream, *d);
-        else hipLaunchKernelGGL((ln_bwd_kernel<1024, float>), grid, block, 0, stream, *d);
+        if (bf) hipLaunchKernelGGL((ln_bwd_kernel<1024, __bf16>), grid, block, 0, stream, *d, rpw);
+        else hipLaunchKernelGGL((ln_bwd_kernel<1024, float>), grid, block, 0, stream, *d, rpw);
     }
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
