@@ -118,32 +118,71 @@ class FlatParams:
 
 
 class Plan:
-    """A static list of kernel enqueues."""
+    """A static list of kernel enqueues over a small set of HIP streams.
+
+    Stream 0 is whatever stream is current when run() is called (the capture stream under hipGraph capture); the
+    others are side streams created once per plan.  fork(a, b) makes b wait for everything enqueued on a so far,
+    join(a, b) is the same edge written from the consumer's side -- both are event record/wait pairs, which a
+    hipGraph capture turns into plain dependency edges, so independent chains (weight-gradient GEMMs, the text and
+    the video encoder) run concurrently on the 256 CUs instead of queueing behind the critical path."""
 
     def __init__(self):
-        self.calls = []
+        self.ops = []
         self.keep = []
+        self._side = {}
 
-    def add(self, fn_name, desc):
+    def add(self, fn_name, desc, stream=0):
         fn = getattr(_lib.lib(), fn_name)
         self.keep.append(desc)
-        self.calls.append((fn, C.byref(desc), fn_name))
+        self.ops.append(("call", fn, C.byref(desc), fn_name, stream))
 
-    def add_callable(self, f):
-        self.calls.append((f, None, getattr(f, "__name__", "callable")))
+    def add_callable(self, f, stream=0):
+        self.ops.append(("py", f, None, getattr(f, "__name__", "callable"), stream))
 
-    def run(self):
-        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for fn, ref, name in self.calls:
-            if ref is None:
-                fn()
-            else:
-                rc = fn(ref, s)
+    def fork(self, src, dst):
+        """dst waits for all work enqueued on src so far."""
+        if src != dst:
+            self.ops.append(("dep", src, dst, "dep", 0))
+
+    def join(self, src, dst):
+        self.fork(src, dst)
+
+    def _stream(self, idx, cur):
+        if idx == 0:
+            return cur
+        st = self._side.get(idx)
+        if st is None or st.device != cur.device:
+            st = torch.cuda.Stream(device=cur.device)
+            self._side[idx] = st
+        return st
+
+    def run(self, upto=None):
+        cur = torch.cuda.current_stream()
+        handles = {}
+        for op in (self.ops if upto is None else self.ops[:upto]):
+            kind, a, b, name, sidx = op
+            if kind == "call":
+                h = handles.get(sidx)
+                if h is None:
+                    h = handles[sidx] = C.c_void_p(self._stream(sidx, cur).cuda_stream)
+                rc = a(b, h)
                 if rc != 0:
                     _lib.check(rc, name)
+            elif kind == "py":
+                if sidx == 0:
+                    a()
+                else:
+                    with torch.cuda.stream(self._stream(sidx, cur)):
+                        a()
+            else:
+                self._stream(b, cur).wait_stream(self._stream(a, cur))
+
+    @property
+    def calls(self):
+        return self.ops
 
     def __len__(self):
-        return len(self.calls)
+        return len(self.ops)
 
 
 def _gemm_desc(dt, A, lda, B, ldb, M, N, K, *, trans_a=0, trans_b=0, out32=None, out16=None, ldc=0, bias=None,
@@ -187,8 +226,9 @@ class EncoderStack:
 
     H, NH, I = 768, 12, 3072
 
-    def __init__(self, flat, prefix, n_layers, B, S, key_mask, p_drop, seed_dev, sites, splitk=True):
+    def __init__(self, flat, prefix, n_layers, B, S, key_mask, p_drop, seed_dev, sites, splitk=True, s_main=0, s_side=1):
         self.flat, self.prefix, self.L, self.B, self.S = flat, prefix, n_layers, B, S
+        self.sm, self.ss = s_main, s_side
         self.T = B * S
         self.key_mask = key_mask            # int64 [B,S] device tensor (static buffer)
         self.p = float(p_drop)
@@ -212,7 +252,8 @@ class EncoderStack:
             self.layers.append(ws)
         # backward scratch shared by all layers
         self.gbuf = e(T, H)
-        self.dxd = e(T, H, dtype=ct)
+        self.dxd = e(T, H, dtype=ct)       # grad wrt FFN2 output (operand of its wgrad / dgrad)
+        self.dxd2 = e(T, H, dtype=ct)      # grad wrt attention-output projection (separate: wgrads run concurrently)
         self.du = e(T, I, dtype=ct)
         self.dctx = e(T, H, dtype=ct)
         self.dqkv = e(T, 3 * H, dtype=ct)
@@ -247,42 +288,48 @@ class EncoderStack:
     # ------------------------------------------------------------------------------------------ forward
     def build_forward(self, plan, x32, x16, training):
         fl, dt, T, H, I, S, B = self.flat, self.flat.dt, self.T, self.H, self.I, self.S, self.B
+        sm = self.sm
         p = self.p if training else 0.0
         if self.ks_h > 1:
-            plan.add_callable(self.yarena.zero_)
+            plan.add_callable(self.yarena.zero_, stream=sm)
         for l, ws in enumerate(self.layers):
             nm = self._names(l)
             wqkv, bqkv = fl.wop_fused(nm["qkv_w"]), fl.w32_fused(nm["qkv_b"])
-            plan.add("univl_gemm", _gemm_desc(dt, x16, H, wqkv, H, T, 3 * H, H, out16=ws["qkv"], ldc=3 * H, bias=bqkv))
+            plan.add("univl_gemm", _gemm_desc(dt, x16, H, wqkv, H, T, 3 * H, H, out16=ws["qkv"], ldc=3 * H, bias=bqkv), sm)
             qkv = ws["qkv"]
             plan.add("univl_attention_fwd", ops.attention_desc(
                 dt, B, self.NH, S, S, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx"], H, ws["lse"],
-                key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev))
+                key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev), sm)
             plan.add("univl_gemm", _gemm_desc(dt, ws["ctx"], H, fl.wop(nm["o_w"]), H, T, H, H, out32=ws["y1"], ldc=H,
-                                              bias=fl.w32(nm["o_b"]), ksplit=self.ks_h))
+                                              bias=fl.w32(nm["o_b"]), ksplit=self.ks_h), sm)
             plan.add("univl_layernorm_fwd", ops.layernorm_desc(
                 dt, T, H, x=ws["y1"], residual=x32, gamma=fl.w32(nm["ln1_g"]), beta=fl.w32(nm["ln1_b"]), y=ws["y1"],
                 stats=ws["st1"], out32=ws["a32"], out16=ws["a16"] if self.bf else None, p_pre=p, off_pre=ws["off"][1],
-                seed_dev=self.seed_dev))
+                seed_dev=self.seed_dev), sm)
             plan.add("univl_gemm", _gemm_desc(dt, ws["a16"], H, fl.wop(nm["w1"]), H, T, I, H, out16=ws["f"], ldc=I,
-                                              bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd"))
+                                              bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd"), sm)
             plan.add("univl_gemm", _gemm_desc(dt, ws["f"], I, fl.wop(nm["w2"]), I, T, H, I, out32=ws["y2"], ldc=H,
-                                              bias=fl.w32(nm["b2"]), ksplit=self.ks_h))
+                                              bias=fl.w32(nm["b2"]), ksplit=self.ks_h), sm)
             plan.add("univl_layernorm_fwd", ops.layernorm_desc(
                 dt, T, H, x=ws["y2"], residual=ws["a32"], gamma=fl.w32(nm["ln2_g"]), beta=fl.w32(nm["ln2_b"]), y=ws["y2"],
                 stats=ws["st2"], out32=ws["o32"], out16=ws["o16"] if self.bf else None, p_pre=p, off_pre=ws["off"][2],
-                seed_dev=self.seed_dev))
+                seed_dev=self.seed_dev), sm)
             x32, x16 = ws["o32"], ws["o16"]
 
     # ----------------------------------------------------------------------------------------- backward
     def build_backward(self, plan, gin, x0_32, x0_16, fresh, training, layer_hook=None):
         """gin: fp32 [T,H] gradient wrt the last layer's output.  Returns the buffer holding the gradient wrt the
-        stack input.  `fresh`: matrix gradients are written (beta = 0) instead of accumulated."""
+        stack input.  `fresh`: matrix gradients are written (beta = 0) instead of accumulated.
+
+        Stream `sm` carries the critical chain (LayerNorm backward -> dgrad -> ... -> dgrad); the four weight-gradient
+        GEMMs of a layer only CONSUME that chain's tensors, so they run on the side stream `ss` and rejoin at the
+        end of the layer (before scratch buffers are reused and before the layer's all-reduce bucket is launched)."""
         fl, dt, T, H, I, S, B = self.flat, self.flat.dt, self.T, self.H, self.I, self.S, self.B
+        sm, ss = self.sm, self.ss
         p = self.p if training else 0.0
         acc = not fresh
         if self.ks_h > 1:
-            plan.add_callable(self.garena.zero_)
+            plan.add_callable(self.garena.zero_, stream=sm)
         for l in range(self.L - 1, -1, -1):
             ws, nm = self.layers[l], self._names(l)
             xin32, xin16 = (x0_32, x0_16) if l == 0 else (self.layers[l - 1]["o32"], self.layers[l - 1]["o16"])
@@ -291,36 +338,41 @@ class EncoderStack:
             plan.add("univl_layernorm_bwd", ops.layernorm_desc(
                 dt, T, H, gamma=fl.w32(nm["ln2_g"]), y=ws["y2"], stats=ws["st2"], dout=gin, dx32=dz, dxd16=self.dxd,
                 dgamma=fl.g(nm["ln2_g"]), dbeta=fl.g(nm["ln2_b"]), dbias=fl.g(nm["b2"]), p_pre=p, off_pre=ws["off"][2],
-                seed_dev=self.seed_dev))
+                seed_dev=self.seed_dev), sm)
+            plan.fork(sm, ss)
             plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, ws["f"], I, H, I, T, trans_a=1, trans_b=1,
-                                              out32=fl.g(nm["w2"]), ldc=I, accumulate=acc))
+                                              out32=fl.g(nm["w2"]), ldc=I, accumulate=acc), ss)
             plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, fl.wop(nm["w2"]), I, T, I, H, trans_b=1, out16=self.du,
-                                              ldc=I, aux=ws["u"], ldaux=I, gelu="bwd"))
+                                              ldc=I, aux=ws["u"], ldaux=I, gelu="bwd"), sm)
+            plan.fork(sm, ss)
             plan.add("univl_gemm", _gemm_desc(dt, self.du, I, ws["a16"], H, I, H, T, trans_a=1, trans_b=1,
-                                              out32=fl.g(nm["w1"]), ldc=H, accumulate=acc, dbias=fl.g(nm["b1"])))
+                                              out32=fl.g(nm["w1"]), ldc=H, accumulate=acc, dbias=fl.g(nm["b1"])), ss)
             plan.add("univl_gemm", _gemm_desc(dt, self.du, I, fl.wop(nm["w1"]), H, T, H, I, trans_b=1, out32=da, ldc=H,
-                                              residual=dz, ldr=H, ksplit=self.ks_h))
+                                              residual=dz, ldr=H, ksplit=self.ks_h), sm)
             # attention-output LayerNorm / dropout backward (BertSelfOutput, module_bert.py:207-211)
             dy = self.gbuf
             plan.add("univl_layernorm_bwd", ops.layernorm_desc(
-                dt, T, H, gamma=fl.w32(nm["ln1_g"]), y=ws["y1"], stats=ws["st1"], dout=da, dx32=dy, dxd16=self.dxd,
+                dt, T, H, gamma=fl.w32(nm["ln1_g"]), y=ws["y1"], stats=ws["st1"], dout=da, dx32=dy, dxd16=self.dxd2,
                 dgamma=fl.g(nm["ln1_g"]), dbeta=fl.g(nm["ln1_b"]), dbias=fl.g(nm["o_b"]), p_pre=p, off_pre=ws["off"][1],
-                seed_dev=self.seed_dev))
-            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
-                                              out32=fl.g(nm["o_w"]), ldc=H, accumulate=acc))
-            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, fl.wop(nm["o_w"]), H, T, H, H, trans_b=1, out16=self.dctx, ldc=H))
+                seed_dev=self.seed_dev), sm)
+            plan.fork(sm, ss)
+            plan.add("univl_gemm", _gemm_desc(dt, self.dxd2, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
+                                              out32=fl.g(nm["o_w"]), ldc=H, accumulate=acc), ss)
+            plan.add("univl_gemm", _gemm_desc(dt, self.dxd2, H, fl.wop(nm["o_w"]), H, T, H, H, trans_b=1, out16=self.dctx, ldc=H), sm)
             qkv, dqkv = ws["qkv"], self.dqkv
             plan.add("univl_attention_bwd", ops.attention_desc(
                 dt, B, self.NH, S, S, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx"], H, ws["lse"],
                 key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev, dout=self.dctx, lddo=H,
-                dq=(dqkv, 0), lddq=3 * H, dk=(dqkv, H), lddk=3 * H, dv=(dqkv, 2 * H), lddv=3 * H))
+                dq=(dqkv, 0), lddq=3 * H, dk=(dqkv, H), lddk=3 * H, dv=(dqkv, 2 * H), lddv=3 * H), sm)
+            plan.fork(sm, ss)
             plan.add("univl_gemm", _gemm_desc(dt, dqkv, 3 * H, xin16, H, 3 * H, H, T, trans_a=1, trans_b=1,
                                               out32=fl.g_fused(nm["qkv_w"]), ldc=H, accumulate=acc,
-                                              dbias=fl.g_fused(nm["qkv_b"])))
+                                              dbias=fl.g_fused(nm["qkv_b"])), ss)
             dx = self.garena[l, 1]
             plan.add("univl_gemm", _gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["qkv_w"]), H, T, H, 3 * H, trans_b=1,
-                                              out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ks_h))
+                                              out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ks_h), sm)
+            plan.join(ss, sm)      # scratch (dxd, dxd2, du, dqkv) is reused by the next layer; grads of layer l done
             gin = dx
             if layer_hook is not None:
-                layer_hook(plan, self.prefix, l)
+                layer_hook(plan, self.prefix, l, sm)
         return gin

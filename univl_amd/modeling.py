@@ -224,6 +224,22 @@ class _JointLossFn(torch.autograd.Function):
         return None, None, None
 
 
+class _LossTensor(torch.Tensor):
+    """The scalar returned by UniVL.forward.  It is an ordinary autograd tensor (grad_fn = _JointLossFn), but a plain
+    `loss.backward()` -- what main_task_retrieval.py:342 does -- runs the backward plan directly in the calling
+    thread instead of going through the autograd engine's device thread (less overhead, and a multi-stream plan can
+    then be captured into a hipGraph together with the forward).  Anything else (`(loss / k).backward()`,
+    `loss.mean()`, explicit gradients) takes the normal autograd route and ends in _JointLossFn.backward."""
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        ms = self.__dict__.get("_univl", None)
+        if ms is not None and gradient is None and inputs is None and not create_graph:
+            model, step = ms
+            model._run_backward(step, None)
+            return None
+        return super().backward(gradient=gradient, retain_graph=retain_graph, create_graph=create_graph, inputs=inputs)
+
+
 class UniVL(UniVLPreTrainedModel):
     def __init__(self, bert_config, visual_config, cross_config, decoder_config, task_config):
         super().__init__()
@@ -369,8 +385,17 @@ class UniVL(UniVLPreTrainedModel):
         st.dseq, st.dvis = e(Tt, H), e(Tv, H)
         st.de_op = e(Tv, H, dtype=ct)
         st.dvnorm = e(Tv, D)
-        st.text = EncoderStack(fl, "bert", self.bert_config.num_hidden_layers, B, W, st.amask, p, self._seed_dev, sites)
-        st.vis = EncoderStack(fl, "visual", self.visual_config.num_hidden_layers, B, F, st.vmask, p, self._seed_dev, sites)
+        # streams: 0 = text chain (+ everything serial), 1 = text weight gradients, 2 = video chain, 3 = video wgrads
+        dual = os.environ.get("UNIVL_DUAL_ENCODER", "1") != "0"       # text || video encoder
+        # weight gradients on a side stream: measured SLOWER on MI355X/ROCm 7.2 (4.83 vs 4.16 ms/step at bs 4: every
+        # cross-stream edge of the captured hipGraph costs more than the overlap buys) and, combined with the dual
+        # encoder streams, crashes hipStreamEndCapture -- kept as an opt-in experiment only.
+        sidew = os.environ.get("UNIVL_SIDE_WGRAD", "0") == "1"
+        ST, SV = 0, (2 if dual else 0)
+        st.text = EncoderStack(fl, "bert", self.bert_config.num_hidden_layers, B, W, st.amask, p, self._seed_dev, sites,
+                               s_main=ST, s_side=(1 if sidew else ST))
+        st.vis = EncoderStack(fl, "visual", self.visual_config.num_hidden_layers, B, F, st.vmask, p, self._seed_dev, sites,
+                              s_main=SV, s_side=(((1 if os.environ.get('UNIVL_SIDE_SHARED', '0') == '1' else 3) if dual else 1) if sidew else SV))
         off_t, off_v = sites.next(), sites.next()
         use_mil = bool(tc.use_mil)
         W32, G = fl.w32, fl.g
@@ -386,20 +411,22 @@ class UniVL(UniVLPreTrainedModel):
         fwd = Plan()
         if p > 0:
             fwd.add_callable(lambda: ops.bump_counter(self._seed_dev))
+        fwd.fork(ST, SV)           # the video encoder runs concurrently with the text encoder
         fwd.add("univl_layernorm_fwd", ops.layernorm_desc(
             dt, Tv, D, x=st.video, x_f64=True, gamma=W32(nv_g), beta=W32(nv_b), y=st.vy, stats=st.vst,
-            out32=st.vn32, out16=st.vn_op if bf else None))
-        fwd.add("univl_gemm", _gemm_desc(dt, st.vn_op, D, fl.wop(vw), D, Tv, H, D, out32=st.ve, ldc=H, bias=W32(vb)))
+            out32=st.vn32, out16=st.vn_op if bf else None), SV)
+        fwd.add("univl_gemm", _gemm_desc(dt, st.vn_op, D, fl.wop(vw), D, Tv, H, D, out32=st.ve, ldc=H, bias=W32(vb)), SV)
         fwd.add("univl_layernorm_fwd", ops.layernorm_desc(
             dt, Tv, H, x=st.ve, pos=W32(vpos), pos_period=F, gamma=W32(vlg), beta=W32(vlb), y=st.ve, stats=st.vest,
             out32=st.v0_32, out16=st.v0_16 if bf else None, p_post=p, seed=self._seed, off_post=off_v,
-            seed_dev=self._seed_dev))
+            seed_dev=self._seed_dev), SV)
         fwd.add("univl_embed_text_fwd", ops.embed_text_desc(
             dt, B, W, st.ids, W32(bw), W32(bp), W32(blg), W32(blb), type_ids=st.type_ids, type_emb=W32(bt), y=st.te,
             stats=st.test, out32=st.t0_32, out16=st.t0_16 if bf else None, p_post=p, seed=self._seed, off_post=off_t,
-            seed_dev=self._seed_dev))
-        st.text.build_forward(fwd, st.t0_32, st.t0_16, training)
+            seed_dev=self._seed_dev), ST)
         st.vis.build_forward(fwd, st.v0_32, st.v0_16, training)
+        st.text.build_forward(fwd, st.t0_32, st.t0_16, training)
+        fwd.join(SV, ST)
         st.seq_out, st.vis_out = st.text.output()[0], st.vis.output()[0]
         st.fwd_encoders_len = len(fwd)
         fwd.add("univl_pool_fwd", ops.pool_desc(B, W, st.seq_out, st.amask, skip_first=True, normalize=not use_mil,
@@ -433,9 +460,9 @@ class UniVL(UniVLPreTrainedModel):
             if red is not None:
                 buckets = layer_buckets(fl, self.used_parameter_names())
 
-                def hook(plan, prefix, l):
+                def hook(plan, prefix, l, stream):
                     s0, e0 = buckets["layers"][(prefix, l)]
-                    plan.add_callable(lambda: red.reduce_slice(s0, e0))
+                    plan.add_callable(lambda: red.reduce_slice(s0, e0), stream=stream)
             if fresh:
                 bwd.add_callable(fl.g32[:fl.v_end].zero_)
             bwd.add_callable(lambda: ops.scale_by_device_scalar(st.dsim, st.gout))
@@ -446,20 +473,22 @@ class UniVL(UniVLPreTrainedModel):
                                                     mean=st.tmean, out=st.tn, dout=st.dtn, dx=st.dseq))
             bwd.add("univl_pool_bwd", ops.pool_desc(B, F, st.vis_out, st.vmask, skip_first=False, normalize=not use_mil,
                                                     mean=st.vmean, out=st.vn, dout=st.dvn, dx=st.dvis))
+            bwd.fork(ST, SV)       # video-encoder backward runs concurrently with the text-encoder backward
+            dxv = st.vis.build_backward(bwd, st.dvis, st.v0_32, st.v0_16, fresh, training, layer_hook=hook)
+            bwd.add("univl_layernorm_bwd", ops.layernorm_desc(
+                dt, Tv, H, gamma=W32(vlg), y=st.ve, stats=st.vest, dout=dxv, dxd16=st.de_op, dgamma=G(vlg), dbeta=G(vlb),
+                dbias=G(vb), dpos=G(vpos), pos_period=F, p_post=p, seed=self._seed, off_post=off_v, seed_dev=self._seed_dev), SV)
+            bwd.add("univl_gemm", _gemm_desc(dt, st.de_op, H, st.vn_op, D, H, D, Tv, trans_a=1, trans_b=1, out32=G(vw),
+                                             ldc=D, accumulate=not fresh), SV)
+            bwd.add("univl_gemm", _gemm_desc(dt, st.de_op, H, fl.wop(vw), D, Tv, D, H, trans_b=1, out32=st.dvnorm, ldc=D), SV)
+            bwd.add("univl_layernorm_bwd", ops.layernorm_desc(
+                dt, Tv, D, gamma=W32(nv_g), y=st.vy, stats=st.vst, dout=st.dvnorm, dgamma=G(nv_g), dbeta=G(nv_b)), SV)
             dxt = st.text.build_backward(bwd, st.dseq, st.t0_32, st.t0_16, fresh, training, layer_hook=hook)
             bwd.add("univl_embed_text_bwd", ops.embed_text_desc(
                 dt, B, W, st.ids, W32(bw), W32(bp), W32(blg), W32(blb), type_ids=st.type_ids, type_emb=W32(bt), y=st.te,
                 stats=st.test, p_post=p, seed=self._seed, off_post=off_t, seed_dev=self._seed_dev, dout=dxt,
-                dword=G(bw), dpos=G(bp), dtype_emb=G(bt), dgamma=G(blg), dbeta=G(blb)))
-            dxv = st.vis.build_backward(bwd, st.dvis, st.v0_32, st.v0_16, fresh, training, layer_hook=hook)
-            bwd.add("univl_layernorm_bwd", ops.layernorm_desc(
-                dt, Tv, H, gamma=W32(vlg), y=st.ve, stats=st.vest, dout=dxv, dxd16=st.de_op, dgamma=G(vlg), dbeta=G(vlb),
-                dbias=G(vb), dpos=G(vpos), pos_period=F, p_post=p, seed=self._seed, off_post=off_v, seed_dev=self._seed_dev))
-            bwd.add("univl_gemm", _gemm_desc(dt, st.de_op, H, st.vn_op, D, H, D, Tv, trans_a=1, trans_b=1, out32=G(vw),
-                                             ldc=D, accumulate=not fresh))
-            bwd.add("univl_gemm", _gemm_desc(dt, st.de_op, H, fl.wop(vw), D, Tv, D, H, trans_b=1, out32=st.dvnorm, ldc=D))
-            bwd.add("univl_layernorm_bwd", ops.layernorm_desc(
-                dt, Tv, D, gamma=W32(nv_g), y=st.vy, stats=st.vst, dout=st.dvnorm, dgamma=G(nv_g), dbeta=G(nv_b)))
+                dword=G(bw), dpos=G(bp), dtype_emb=G(bt), dgamma=G(blg), dbeta=G(blb)), ST)
+            bwd.join(SV, ST)
             if red is not None:
                 for (s0, e0) in buckets["tail"]:
                     bwd.add_callable(lambda s0=s0, e0=e0: red.reduce_slice(s0, e0))
@@ -483,7 +512,10 @@ class UniVL(UniVLPreTrainedModel):
         fl = self.flat
         used = self.used_parameter_names()
         fresh = all(fl.params[n].grad is None for n in (used[0], used[-1]))
-        st.gout.copy_(gout.reshape(1).to(torch.float32))
+        if gout is None:
+            st.gout.fill_(1.0)
+        else:
+            st.gout.copy_(gout.reshape(1).to(torch.float32))
         fl.grad_version += 1
         if fresh:
             st.bwd_fresh.run()
@@ -507,7 +539,9 @@ class UniVL(UniVLPreTrainedModel):
             return None
         anchor = fl.params["normalize_video.visual_norm2d.bias"]
         if torch.is_grad_enabled() and anchor.requires_grad:
-            return _JointLossFn.apply(anchor, self, st)
+            out = _JointLossFn.apply(anchor, self, st).as_subclass(_LossTensor)
+            out._univl = (self, st)
+            return out
         st.fwd.run()
         return st.loss[0].clone()
 
@@ -522,12 +556,7 @@ class UniVL(UniVLPreTrainedModel):
         fl.refresh_shadow()
         st = self._get_step(B, W, F)
         self._load_inputs(st, input_ids, token_type_ids, attention_mask, video, video_mask)
-        s = torch.cuda.current_stream().cuda_stream
-        for fn, ref, name in st.fwd.calls[:st.fwd_encoders_len]:
-            if ref is None:
-                fn()
-            else:
-                _lib.check(fn(ref, s), name)
+        st.fwd.run(upto=st.fwd_encoders_len)
         return st.seq_out.view(B, W, -1).clone(), st.vis_out.view(B, F, -1).clone()
 
     def get_similarity_logits(self, sequence_output, visual_output, attention_mask, video_mask, shaped=False,
