@@ -162,7 +162,8 @@ typedef struct UnivlPool {
     float* mean;        /* [B,N] saved pre-normalisation mean */
     float* out;         /* [B,N] */
     const float* dout;  /* bwd: [B,N] */
-    float* dx;          /* bwd: [B,S,N] (written, not accumulated) */
+    float* dx;          /* bwd: [B,S,N] */
+    int32_t accumulate; /* bwd: dx += instead of dx = */
 } UnivlPool;
 int univl_pool_fwd(const UnivlPool* d, hipStream_t stream);
 int univl_pool_bwd(const UnivlPool* d, hipStream_t stream);
@@ -179,6 +180,42 @@ int univl_milnce_loss(const float* sim, int32_t batch_size, int32_t n_pair, int3
                       hipStream_t stream);
 /* x[0..n) *= s[0] with s on the device (applies loss.backward()'s upstream gradient without a host sync) */
 int univl_scale_by_device_scalar(float* x, int64_t n, const float* s, hipStream_t stream);
+
+/* --------------------------------------------------------------------- cross encoder / classifier helpers
+ * pair_concat: out[p, :, :] = cat(seq[tidx[p]], vis[vidx[p]]) and out_mask likewise -- torch.cat of
+ * UniVL._get_cross_output (modeling.py:315-325) for an explicit list of (text row, video row) pairs (the repeat/view
+ * expansion of _cross_similarity modeling.py:352-366, or tidx = vidx = arange for the caption / pretrain path).
+ * Backward scatter-adds d out into dseq / dvis (fp32 atomics; callers zero or pre-fill them). */
+int univl_pair_concat_fwd(const float* seq, const float* vis, const int64_t* amask, const int64_t* vmask,
+                          const int32_t* tidx, const int32_t* vidx, int32_t P, int32_t W, int32_t F, float* out,
+                          int64_t* out_mask, hipStream_t stream);
+int univl_pair_concat_bwd(const float* dout, const int32_t* tidx, const int32_t* vidx, int32_t P, int32_t W, int32_t F,
+                          float* dseq, float* dvis, hipStream_t stream);
+/* CrossEmbeddings (module_cross.py:123-138): table[s] = position[s] + token_type[s >= W] for s < S = W + F; the
+ * LayerNorm kernel then adds it with period S.  Backward accumulates into dpos / dtype with atomics. */
+int univl_postype_fwd(const float* pos, const float* type, int32_t W, int32_t S, float* out, hipStream_t stream);
+int univl_postype_bwd(const float* dtable, int32_t W, int32_t S, float* dpos, float* dtype, hipStream_t stream);
+/* nn.Tanh of CrossPooler (module_cross.py:281-287) */
+int univl_tanh_fwd(const float* x, float* y, int64_t n, hipStream_t stream);
+int univl_tanh_bwd(int32_t dtype, const float* dy, const float* y, void* dx, int64_t n, hipStream_t stream);   /* dx in compute type */
+/* du (compute type) = dg (fp32) * gelu'(u): BertPredictionHeadTransform backward (module_bert.py:299-311) */
+int univl_gelu_bwd(int32_t dtype, const float* dg, const void* u, void* du, int64_t n, hipStream_t stream);
+/* similarity_dense = nn.Linear(768, 1) on the pooled cross output (modeling.py:167,371) and its backward
+ * (dx written, dw/db accumulated with atomics) */
+/* out[c] += sum_r x[r, c] over a [rows, ld] matrix in the compute type (atomics) */
+int univl_colsum(int32_t dtype, const void* x, int64_t ld, int32_t rows, int32_t n, float* out, hipStream_t stream);
+/* x (compute type) *= s[0], s on the device */
+int univl_scale_ct_by_device_scalar(int32_t dtype, void* x, int64_t n, const float* s, hipStream_t stream);
+int univl_simdense_fwd(const float* x, const float* w, const float* b, int32_t rows, float* out, hipStream_t stream);
+int univl_simdense_bwd(const float* ds, const float* x, const float* w, int32_t rows, float* dx, float* dw, float* db,
+                       hipStream_t stream);
+/* CrossEntropyLoss(ignore_index) over [rows, V] fp32 logits (modeling.py:168,252-254,275): loss = mean over rows with
+ * label != ignore_index; dlogits (compute type, [rows, lddl]) = (softmax - onehot) / n_valid.  scratch2: 2 floats. */
+int univl_ce_loss(int32_t dtype, const float* logits, int64_t ld, const int64_t* labels, int32_t rows, int32_t V,
+                  int32_t ignore_index, float* scratch2, float* loss, void* dlogits, int64_t lddl, hipStream_t stream);
+/* masked-frame NCE of UniVL._calculate_mfm_loss (modeling.py:285-297) on the [n,n] logits matrix */
+int univl_mfm_nce_loss(const float* logits, int64_t ld, const int64_t* vmask, const int64_t* labels, int32_t n,
+                       float* scratch2, float* loss, float* dlogits, int64_t lddl, hipStream_t stream);
 
 /* -------------------------------------------------------------------------------------------- optimizer
  * Fused multi-tensor BertAdam (modules/optimization.py:103-168) + clip_grad_norm_ (main_task_retrieval.py:347)

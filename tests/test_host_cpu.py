@@ -57,8 +57,9 @@ def test_flat_layout_and_plans_build_on_cpu():
     w = fl.w32_fused([a + "query.weight", a + "key.weight", a + "value.weight"])
     assert w.shape == (2304, 768) and torch.equal(w[768:1536], P[a + "key.weight"])
     m.train()
-    st = m._build_joint_step(2, 16, 16, True)
-    assert len(st.fwd) >= 3 * 7 + 4 + 4 and len(st.bwd_fresh) > len(st.fwd)
+    from univl_amd.steps import build_step
+    st = build_step(m, "joint", 2, 16, 16, True)
+    assert len(st.fwd) >= 3 * 7 + 4 + 4 and len(st.backward_plan(True)) > len(st.fwd)
     # data-parallel buckets: disjoint, cover every parameter that gets a gradient
     b = layer_buckets(fl, m.used_parameter_names())
     sl = sorted(list(b["layers"].values()) + b["tail"])
@@ -86,11 +87,21 @@ def test_product_path_fails_loudly_without_gpu():
         opt.step()
 
 
-def test_unbuilt_stages_are_explicit():
-    with pytest.raises(NotImplementedError):
-        _model(train_sim_after_cross=True)
-    with pytest.raises(NotImplementedError):
-        _model(stage_two=True, task_type="caption")
+@pytest.mark.parametrize("kw,kind", [(dict(), "joint"), (dict(train_sim_after_cross=True), "align"),
+                                     (dict(stage_two=True, task_type="caption", decoder_num_hidden_layers=1), "caption"),
+                                     (dict(stage_two=True, do_pretrain=True, use_mil=True, decoder_num_hidden_layers=1), "pretrain")])
+def test_every_forward_branch_builds_its_plans(kw, kind):
+    """The four branches of UniVL.forward (modeling.py:204-267): inventory equals the reference's, plans build."""
+    from univl_amd.steps import build_step
+    m, cfg = _model("fp32", **kw)
+    assert list(dict(m.named_parameters())) == list(O.param_shapes(cfg))
+    assert set(m.state_dict()) == set(O.param_shapes(cfg)) | set(O.tied_aliases(cfg))
+    m._flat, m._seed_dev = FlatParams(list(m.named_parameters()), "cpu", torch.float32), torch.zeros(1, dtype=torch.int64)
+    m.train()
+    assert m.step_kind(True) == kind
+    st = build_step(m, kind, 2, 16, 16, True)
+    assert len(st.fwd) > 20 and len(st.backward_plan(True)) > len(st.fwd)
+    assert len(st.backward_plan(False)) > 0
 
 
 def test_bert_adam_argument_validation():

@@ -22,6 +22,7 @@ if torch.cuda.is_available():
 
 DEV = "cuda"
 JOINT_CASES = ["joint_small", "joint_ones", "joint_full"]
+ALL_CASES = JOINT_CASES + ["align_small", "caption_small", "pretrain_small"]
 
 
 def task_ns(cfg, dtype):
@@ -46,9 +47,21 @@ def build(cfg, dtype):
 
 def call(model, batch):
     b = {k: v.to(DEV) for k, v in batch.items()}
+    kw = {}
+    if model.decoder is not None:
+        kw = dict(input_caption_ids=b["input_caption_ids"], decoder_mask=b["decoder_mask"],
+                  output_caption_ids=b["output_caption_ids"])
     return model(b["input_ids"], b["token_type_ids"], b["attention_mask"], b["video"], b["video_mask"],
                  pairs_masked_text=b["pairs_masked_text"], pairs_token_labels=b["pairs_token_labels"],
-                 masked_video=b["masked_video"], video_labels_index=b["video_labels_index"])
+                 masked_video=b["masked_video"], video_labels_index=b["video_labels_index"], **kw)
+
+
+def _sample(t, n=4096):
+    f = t.detach().reshape(-1)
+    if f.numel() <= n:
+        return f.float().cpu().numpy()
+    idx = torch.linspace(0, f.numel() - 1, n).long().to(f.device)
+    return f[idx].float().cpu().numpy()
 
 
 def max_abs(a, b):
@@ -56,8 +69,8 @@ def max_abs(a, b):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("name", JOINT_CASES)
-def test_joint_forward_backward_vs_reference_golden(golden_dir, name, dtype):
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_forward_backward_vs_reference_golden(golden_dir, name, dtype):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     cfg, rows, dseed = case_config(name)
     model, P = build(cfg, dtype)
@@ -71,15 +84,20 @@ def test_joint_forward_backward_vs_reference_golden(golden_dir, name, dtype):
                                                     b["video"], b["video_mask"])
         sim = model.get_similarity_logits(seq, vis, b["attention_mask"], b["video_mask"])
         assert model(b["input_ids"], b["token_type_ids"], b["attention_mask"], b["video"], b["video_mask"]) is None
+        if model.decoder is not None:
+            logits = model.decoder_caption(seq, vis, b["input_ids"], b["attention_mask"], b["video_mask"],
+                                           b["input_caption_ids"], b["decoder_mask"], shaped=False, get_logits=True)
+            assert tuple(logits.shape[-1:]) == (cfg.vocab_size,)
+            assert float(np.abs(_sample(logits) - g["decoder_logits_sample"]).max()) < (1e-3 if f32 else 3e-2)
     hid_tol = 1e-3 if f32 else 5e-2
     assert max_abs(seq, g["sequence_output"]) < hid_tol
     assert max_abs(vis, g["visual_output"]) < hid_tol
-    assert max_abs(sim, g["sim_matrix"]) < (1e-3 if f32 else 1e-2)
+    assert max_abs(sim, g["sim_matrix"]) < (1e-3 if f32 else 2e-2)
     # ---- training step: loss + every parameter gradient (main_task_retrieval.py:333-342)
     model.train()
     loss = call(model, batch)
     loss.backward()
-    assert abs(float(loss) - float(g["loss"])) < (1e-3 if f32 else 1e-2)
+    assert abs(float(loss) - float(g["loss"])) < (1e-3 if f32 else 1e-2) * max(1.0, abs(float(g["loss"])))
     names = [str(s) for s in g["grad_names"]]
     nograd = [str(s) for s in g["nograd_names"]]
     params = dict(model.named_parameters())

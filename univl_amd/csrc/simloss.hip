@@ -87,7 +87,10 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(UnivlPool p) {
         const float w = pool_weight(p, b, s) / cnt;
         float* dx = p.dx + ((long)b * p.S + s) * PN;
 #pragma unroll
-        for (int j = 0; j < PC; ++j) dx[t + 256 * j] = d[j] * w;
+        for (int j = 0; j < PC; ++j) {
+            if (p.accumulate) dx[t + 256 * j] += d[j] * w;
+            else dx[t + 256 * j] = d[j] * w;
+        }
     }
 }
 

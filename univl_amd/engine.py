@@ -69,6 +69,9 @@ class FlatParams:
         self._pending = None
         FLAT_REGISTRY.add(self)
 
+    def is_atomic(self, name):
+        return self.index[name][0] < self.v_end
+
     # ---- views
     def w32(self, name):
         o, k, shp = self.index[name]
@@ -115,6 +118,23 @@ class FlatParams:
             p = self.params[n]
             if p.grad is None or p.grad.data_ptr() != self.g(n).data_ptr():
                 p.grad = self.g(n)
+
+
+class GradState:
+    """Book-keeping while a backward plan is built: the first weight-gradient GEMM that writes a matrix in a FRESH
+    backward uses beta = 0 (no 600 MB memset, no read-modify-write); later writers of the same tensor (tied weights,
+    a module that runs twice in one step) and every backward under gradient accumulation use beta = 1.  Tensors of the
+    atomic region are zeroed by one memset when fresh and always accumulated into."""
+
+    def __init__(self, flat, fresh):
+        self.flat, self.fresh, self.written = flat, fresh, set()
+
+    def acc(self, name):
+        if self.flat.is_atomic(name):
+            return True
+        a = (not self.fresh) or (name in self.written)
+        self.written.add(name)
+        return a
 
 
 class Plan:
@@ -317,9 +337,9 @@ class EncoderStack:
             x32, x16 = ws["o32"], ws["o16"]
 
     # ----------------------------------------------------------------------------------------- backward
-    def build_backward(self, plan, gin, x0_32, x0_16, fresh, training, layer_hook=None):
+    def build_backward(self, plan, gin, x0_32, x0_16, gs, training, layer_hook=None):
         """gin: fp32 [T,H] gradient wrt the last layer's output.  Returns the buffer holding the gradient wrt the
-        stack input.  `fresh`: matrix gradients are written (beta = 0) instead of accumulated.
+        stack input.  `gs` (GradState) decides beta = 0 / 1 per weight-gradient GEMM.
 
         Stream `sm` carries the critical chain (LayerNorm backward -> dgrad -> ... -> dgrad); the four weight-gradient
         GEMMs of a layer only CONSUME that chain's tensors, so they run on the side stream `ss` and rejoin at the
@@ -327,7 +347,6 @@ class EncoderStack:
         fl, dt, T, H, I, S, B = self.flat, self.flat.dt, self.T, self.H, self.I, self.S, self.B
         sm, ss = self.sm, self.ss
         p = self.p if training else 0.0
-        acc = not fresh
         if self.ks_h > 1:
             plan.add_callable(self.garena.zero_, stream=sm)
         for l in range(self.L - 1, -1, -1):
@@ -341,12 +360,12 @@ class EncoderStack:
                 seed_dev=self.seed_dev), sm)
             plan.fork(sm, ss)
             plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, ws["f"], I, H, I, T, trans_a=1, trans_b=1,
-                                              out32=fl.g(nm["w2"]), ldc=I, accumulate=acc), ss)
+                                              out32=fl.g(nm["w2"]), ldc=I, accumulate=gs.acc(nm["w2"])), ss)
             plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, fl.wop(nm["w2"]), I, T, I, H, trans_b=1, out16=self.du,
                                               ldc=I, aux=ws["u"], ldaux=I, gelu="bwd"), sm)
             plan.fork(sm, ss)
             plan.add("univl_gemm", _gemm_desc(dt, self.du, I, ws["a16"], H, I, H, T, trans_a=1, trans_b=1,
-                                              out32=fl.g(nm["w1"]), ldc=H, accumulate=acc, dbias=fl.g(nm["b1"])), ss)
+                                              out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=fl.g(nm["b1"])), ss)
             plan.add("univl_gemm", _gemm_desc(dt, self.du, I, fl.wop(nm["w1"]), H, T, H, I, trans_b=1, out32=da, ldc=H,
                                               residual=dz, ldr=H, ksplit=self.ks_h), sm)
             # attention-output LayerNorm / dropout backward (BertSelfOutput, module_bert.py:207-211)
@@ -357,7 +376,7 @@ class EncoderStack:
                 seed_dev=self.seed_dev), sm)
             plan.fork(sm, ss)
             plan.add("univl_gemm", _gemm_desc(dt, self.dxd2, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
-                                              out32=fl.g(nm["o_w"]), ldc=H, accumulate=acc), ss)
+                                              out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"])), ss)
             plan.add("univl_gemm", _gemm_desc(dt, self.dxd2, H, fl.wop(nm["o_w"]), H, T, H, H, trans_b=1, out16=self.dctx, ldc=H), sm)
             qkv, dqkv = ws["qkv"], self.dqkv
             plan.add("univl_attention_bwd", ops.attention_desc(
@@ -366,7 +385,7 @@ class EncoderStack:
                 dq=(dqkv, 0), lddq=3 * H, dk=(dqkv, H), lddk=3 * H, dv=(dqkv, 2 * H), lddv=3 * H), sm)
             plan.fork(sm, ss)
             plan.add("univl_gemm", _gemm_desc(dt, dqkv, 3 * H, xin16, H, 3 * H, H, T, trans_a=1, trans_b=1,
-                                              out32=fl.g_fused(nm["qkv_w"]), ldc=H, accumulate=acc,
+                                              out32=fl.g_fused(nm["qkv_w"]), ldc=H, accumulate=gs.acc(nm["qkv_w"][0]),
                                               dbias=fl.g_fused(nm["qkv_b"])), ss)
             dx = self.garena[l, 1]
             plan.add("univl_gemm", _gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["qkv_w"]), H, T, H, 3 * H, trans_b=1,
@@ -375,4 +394,168 @@ class EncoderStack:
             gin = dx
             if layer_hook is not None:
                 layer_hook(plan, self.prefix, l, sm)
+        return gin
+
+
+class DecoderStack:
+    """Decoder of module_decoder.py:322-340: L layers of {causal self-attention, encoder attention over the cross
+    encoder output, FFN}, each followed by the BertSelfOutput / BertOutput residual + LayerNorm blocks
+    (module_decoder.py:268-292).  Tq = B*Wd decoder tokens, Tkv = B*Sk encoder tokens."""
+
+    H, NH, I = 768, 12, 3072
+
+    def __init__(self, flat, n_layers, B, Wd, Sk, dec_mask, enc_mask, p_drop, seed_dev, sites, stream=0):
+        self.flat, self.L, self.B, self.Wd, self.Sk = flat, n_layers, B, Wd, Sk
+        self.Tq, self.Tkv = B * Wd, B * Sk
+        self.dec_mask, self.enc_mask = dec_mask, enc_mask
+        self.p, self.seed_dev, self.sm = float(p_drop), seed_dev, stream
+        dev, H, I, Tq, Tkv = flat.device, self.H, self.I, self.Tq, self.Tkv
+        ct = flat.compute_dtype
+        self.bf = ct == torch.bfloat16
+        e = lambda *s, dtype=torch.float32: torch.empty(*s, device=dev, dtype=dtype)
+        self.layers = []
+        for l in range(n_layers):
+            ws = dict(qkv=e(Tq, 3 * H, dtype=ct), lse1=e(B, self.NH, Wd), ctx1=e(Tq, H, dtype=ct), y1=e(Tq, H), st1=e(Tq, 2),
+                      a32=e(Tq, H), q2=e(Tq, H, dtype=ct), kv2=e(Tkv, 2 * H, dtype=ct), lse2=e(B, self.NH, Wd),
+                      ctx2=e(Tq, H, dtype=ct), y2=e(Tq, H), st2=e(Tq, 2), d32=e(Tq, H), u=e(Tq, I, dtype=ct),
+                      f=e(Tq, I, dtype=ct), y3=e(Tq, H), st3=e(Tq, 2), o32=e(Tq, H))
+            for k in ("a", "d", "o"):
+                ws[k + "16"] = e(Tq, H, dtype=ct) if self.bf else ws[k + "32"]
+            ws["off"] = [sites.next() for _ in range(5)]
+            self.layers.append(ws)
+        self.g1, self.g2 = e(Tq, H), e(Tq, H)
+        self.dxd = e(Tq, H, dtype=ct)
+        self.du = e(Tq, I, dtype=ct)
+        self.dctx = e(Tq, H, dtype=ct)
+        self.dqkv = e(Tq, 3 * H, dtype=ct)
+        self.dq2 = e(Tq, H, dtype=ct)
+        self.dkv2 = e(Tkv, 2 * H, dtype=ct)
+
+    def _names(self, l):
+        p = "decoder.decoder.layer.%d" % l
+        s, c = p + ".slf_attn", p + ".enc_attn"
+        qkv = lambda a, names, suf: [a + ".att." + n + suf for n in names]
+        return dict(s_qkv_w=qkv(s, ("query", "key", "value"), ".weight"), s_qkv_b=qkv(s, ("query", "key", "value"), ".bias"),
+                    s_o_w=s + ".output.dense.weight", s_o_b=s + ".output.dense.bias",
+                    s_ln_g=s + ".output.LayerNorm.weight", s_ln_b=s + ".output.LayerNorm.bias",
+                    c_q_w=c + ".att.query.weight", c_q_b=c + ".att.query.bias",
+                    c_kv_w=qkv(c, ("key", "value"), ".weight"), c_kv_b=qkv(c, ("key", "value"), ".bias"),
+                    c_o_w=c + ".output.dense.weight", c_o_b=c + ".output.dense.bias",
+                    c_ln_g=c + ".output.LayerNorm.weight", c_ln_b=c + ".output.LayerNorm.bias",
+                    w1=p + ".intermediate.dense.weight", b1=p + ".intermediate.dense.bias",
+                    w2=p + ".output.dense.weight", b2=p + ".output.dense.bias",
+                    ln_g=p + ".output.LayerNorm.weight", ln_b=p + ".output.LayerNorm.bias")
+
+    def output(self):
+        return self.layers[-1]["o32"], self.layers[-1]["o16"]
+
+    def build_forward(self, plan, x32, x16, enc16, training):
+        fl, dt, H, I, B, Wd, Sk, Tq, Tkv, sm = self.flat, self.flat.dt, self.H, self.I, self.B, self.Wd, self.Sk, self.Tq, self.Tkv, self.sm
+        p = self.p if training else 0.0
+        for l, ws in enumerate(self.layers):
+            nm = self._names(l)
+            off = ws["off"]
+            plan.add("univl_gemm", _gemm_desc(dt, x16, H, fl.wop_fused(nm["s_qkv_w"]), H, Tq, 3 * H, H, out16=ws["qkv"], ldc=3 * H,
+                                              bias=fl.w32_fused(nm["s_qkv_b"])), sm)
+            qkv = ws["qkv"]
+            plan.add("univl_attention_fwd", ops.attention_desc(
+                dt, B, self.NH, Wd, Wd, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx1"], H, ws["lse1"],
+                key_mask=self.dec_mask, causal=True, p_drop=p, offset=off[0], seed_dev=self.seed_dev), sm)
+            plan.add("univl_gemm", _gemm_desc(dt, ws["ctx1"], H, fl.wop(nm["s_o_w"]), H, Tq, H, H, out32=ws["y1"], ldc=H,
+                                              bias=fl.w32(nm["s_o_b"])), sm)
+            plan.add("univl_layernorm_fwd", ops.layernorm_desc(
+                dt, Tq, H, x=ws["y1"], residual=x32, gamma=fl.w32(nm["s_ln_g"]), beta=fl.w32(nm["s_ln_b"]), y=ws["y1"],
+                stats=ws["st1"], out32=ws["a32"], out16=ws["a16"] if self.bf else None, p_pre=p, off_pre=off[1],
+                seed_dev=self.seed_dev), sm)
+            plan.add("univl_gemm", _gemm_desc(dt, ws["a16"], H, fl.wop(nm["c_q_w"]), H, Tq, H, H, out16=ws["q2"], ldc=H,
+                                              bias=fl.w32(nm["c_q_b"])), sm)
+            plan.add("univl_gemm", _gemm_desc(dt, enc16, H, fl.wop_fused(nm["c_kv_w"]), H, Tkv, 2 * H, H, out16=ws["kv2"],
+                                              ldc=2 * H, bias=fl.w32_fused(nm["c_kv_b"])), sm)
+            kv = ws["kv2"]
+            plan.add("univl_attention_fwd", ops.attention_desc(
+                dt, B, self.NH, Wd, Sk, ws["q2"], H, (kv, 0), 2 * H, (kv, H), 2 * H, ws["ctx2"], H, ws["lse2"],
+                key_mask=self.enc_mask, p_drop=p, offset=off[2], seed_dev=self.seed_dev), sm)
+            plan.add("univl_gemm", _gemm_desc(dt, ws["ctx2"], H, fl.wop(nm["c_o_w"]), H, Tq, H, H, out32=ws["y2"], ldc=H,
+                                              bias=fl.w32(nm["c_o_b"])), sm)
+            plan.add("univl_layernorm_fwd", ops.layernorm_desc(
+                dt, Tq, H, x=ws["y2"], residual=ws["a32"], gamma=fl.w32(nm["c_ln_g"]), beta=fl.w32(nm["c_ln_b"]), y=ws["y2"],
+                stats=ws["st2"], out32=ws["d32"], out16=ws["d16"] if self.bf else None, p_pre=p, off_pre=off[3],
+                seed_dev=self.seed_dev), sm)
+            plan.add("univl_gemm", _gemm_desc(dt, ws["d16"], H, fl.wop(nm["w1"]), H, Tq, I, H, out16=ws["f"], ldc=I,
+                                              bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd"), sm)
+            plan.add("univl_gemm", _gemm_desc(dt, ws["f"], I, fl.wop(nm["w2"]), I, Tq, H, I, out32=ws["y3"], ldc=H,
+                                              bias=fl.w32(nm["b2"])), sm)
+            plan.add("univl_layernorm_fwd", ops.layernorm_desc(
+                dt, Tq, H, x=ws["y3"], residual=ws["d32"], gamma=fl.w32(nm["ln_g"]), beta=fl.w32(nm["ln_b"]), y=ws["y3"],
+                stats=ws["st3"], out32=ws["o32"], out16=ws["o16"] if self.bf else None, p_pre=p, off_pre=off[4],
+                seed_dev=self.seed_dev), sm)
+            x32, x16 = ws["o32"], ws["o16"]
+
+    def build_backward(self, plan, gin, x0_32, x0_16, enc16, denc32, gs, training):
+        """gin: grad wrt the last layer output [Tq,H] fp32.  denc32 [Tkv,H] fp32 is ACCUMULATED into (every layer's
+        encoder-attention K/V projections read the same cross-encoder output).  Returns the grad wrt the stack input."""
+        fl, dt, H, I, B, Wd, Sk, Tq, Tkv, sm = self.flat, self.flat.dt, self.H, self.I, self.B, self.Wd, self.Sk, self.Tq, self.Tkv, self.sm
+        p = self.p if training else 0.0
+        G = fl.g
+        for l in range(self.L - 1, -1, -1):
+            ws, nm = self.layers[l], self._names(l)
+            off = ws["off"]
+            xin32, xin16 = (x0_32, x0_16) if l == 0 else (self.layers[l - 1]["o32"], self.layers[l - 1]["o16"])
+            # FFN block
+            dz = self.g1
+            plan.add("univl_layernorm_bwd", ops.layernorm_desc(
+                dt, Tq, H, gamma=fl.w32(nm["ln_g"]), y=ws["y3"], stats=ws["st3"], dout=gin, dx32=dz, dxd16=self.dxd,
+                dgamma=G(nm["ln_g"]), dbeta=G(nm["ln_b"]), dbias=G(nm["b2"]), p_pre=p, off_pre=off[4], seed_dev=self.seed_dev), sm)
+            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, ws["f"], I, H, I, Tq, trans_a=1, trans_b=1, out32=G(nm["w2"]), ldc=I,
+                                              accumulate=gs.acc(nm["w2"])), sm)
+            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, fl.wop(nm["w2"]), I, Tq, I, H, trans_b=1, out16=self.du, ldc=I,
+                                              aux=ws["u"], ldaux=I, gelu="bwd"), sm)
+            plan.add("univl_gemm", _gemm_desc(dt, self.du, I, ws["d16"], H, I, H, Tq, trans_a=1, trans_b=1, out32=G(nm["w1"]), ldc=H,
+                                              accumulate=gs.acc(nm["w1"]), dbias=G(nm["b1"])), sm)
+            dd = self.g2
+            plan.add("univl_gemm", _gemm_desc(dt, self.du, I, fl.wop(nm["w1"]), H, Tq, H, I, trans_b=1, out32=dd, ldc=H,
+                                              residual=dz, ldr=H), sm)
+            # encoder-attention block
+            dy2 = self.g1
+            plan.add("univl_layernorm_bwd", ops.layernorm_desc(
+                dt, Tq, H, gamma=fl.w32(nm["c_ln_g"]), y=ws["y2"], stats=ws["st2"], dout=dd, dx32=dy2, dxd16=self.dxd,
+                dgamma=G(nm["c_ln_g"]), dbeta=G(nm["c_ln_b"]), dbias=G(nm["c_o_b"]), p_pre=p, off_pre=off[3], seed_dev=self.seed_dev), sm)
+            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, ws["ctx2"], H, H, H, Tq, trans_a=1, trans_b=1, out32=G(nm["c_o_w"]),
+                                              ldc=H, accumulate=gs.acc(nm["c_o_w"])), sm)
+            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, fl.wop(nm["c_o_w"]), H, Tq, H, H, trans_b=1, out16=self.dctx, ldc=H), sm)
+            kv, dkv = ws["kv2"], self.dkv2
+            plan.add("univl_attention_bwd", ops.attention_desc(
+                dt, B, self.NH, Wd, Sk, ws["q2"], H, (kv, 0), 2 * H, (kv, H), 2 * H, ws["ctx2"], H, ws["lse2"],
+                key_mask=self.enc_mask, p_drop=p, offset=off[2], seed_dev=self.seed_dev, dout=self.dctx, lddo=H,
+                dq=self.dq2, lddq=H, dk=(dkv, 0), lddk=2 * H, dv=(dkv, H), lddv=2 * H), sm)
+            plan.add("univl_gemm", _gemm_desc(dt, dkv, 2 * H, enc16, H, 2 * H, H, Tkv, trans_a=1, trans_b=1,
+                                              out32=fl.g_fused(nm["c_kv_w"]), ldc=H, accumulate=gs.acc(nm["c_kv_w"][0]),
+                                              dbias=fl.g_fused(nm["c_kv_b"])), sm)
+            plan.add("univl_gemm", _gemm_desc(dt, dkv, 2 * H, fl.wop_fused(nm["c_kv_w"]), H, Tkv, H, 2 * H, trans_b=1,
+                                              out32=denc32, ldc=H, accumulate=True), sm)
+            plan.add("univl_gemm", _gemm_desc(dt, self.dq2, H, ws["a16"], H, H, H, Tq, trans_a=1, trans_b=1, out32=G(nm["c_q_w"]),
+                                              ldc=H, accumulate=gs.acc(nm["c_q_w"]), dbias=G(nm["c_q_b"])), sm)
+            da = self.g2
+            plan.add("univl_gemm", _gemm_desc(dt, self.dq2, H, fl.wop(nm["c_q_w"]), H, Tq, H, H, trans_b=1, out32=da, ldc=H,
+                                              residual=dy2, ldr=H), sm)
+            # causal self-attention block
+            dy1 = self.g1
+            plan.add("univl_layernorm_bwd", ops.layernorm_desc(
+                dt, Tq, H, gamma=fl.w32(nm["s_ln_g"]), y=ws["y1"], stats=ws["st1"], dout=da, dx32=dy1, dxd16=self.dxd,
+                dgamma=G(nm["s_ln_g"]), dbeta=G(nm["s_ln_b"]), dbias=G(nm["s_o_b"]), p_pre=p, off_pre=off[1], seed_dev=self.seed_dev), sm)
+            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, ws["ctx1"], H, H, H, Tq, trans_a=1, trans_b=1, out32=G(nm["s_o_w"]),
+                                              ldc=H, accumulate=gs.acc(nm["s_o_w"])), sm)
+            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, fl.wop(nm["s_o_w"]), H, Tq, H, H, trans_b=1, out16=self.dctx, ldc=H), sm)
+            qkv, dqkv = ws["qkv"], self.dqkv
+            plan.add("univl_attention_bwd", ops.attention_desc(
+                dt, B, self.NH, Wd, Wd, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx1"], H, ws["lse1"],
+                key_mask=self.dec_mask, causal=True, p_drop=p, offset=off[0], seed_dev=self.seed_dev, dout=self.dctx, lddo=H,
+                dq=(dqkv, 0), lddq=3 * H, dk=(dqkv, H), lddk=3 * H, dv=(dqkv, 2 * H), lddv=3 * H), sm)
+            plan.add("univl_gemm", _gemm_desc(dt, dqkv, 3 * H, xin16, H, 3 * H, H, Tq, trans_a=1, trans_b=1,
+                                              out32=fl.g_fused(nm["s_qkv_w"]), ldc=H, accumulate=gs.acc(nm["s_qkv_w"][0]),
+                                              dbias=fl.g_fused(nm["s_qkv_b"])), sm)
+            dx = self.g2
+            plan.add("univl_gemm", _gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["s_qkv_w"]), H, Tq, H, 3 * H, trans_b=1, out32=dx,
+                                              ldc=H, residual=dy1, ldr=H), sm)
+            gin = dx
         return gin

@@ -203,14 +203,127 @@ class UniVLPreTrainedModel(nn.Module):
         return model
 
 
-class _JointStep:
-    """Static plans + workspace of the stage-one (FT-Joint) training step for fixed (rows, max_words, max_frames)."""
-    pass
+class _CrossEmbeddingsParams(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.position_embeddings = nn.Embedding(cfg.max_position_embeddings, cfg.hidden_size)
+        self.token_type_embeddings = nn.Embedding(cfg.type_vocab_size, cfg.hidden_size)
+        self.LayerNorm = LayerNorm(cfg.hidden_size)
 
 
-class _JointLossFn(torch.autograd.Function):
-    """loss = UniVL.forward(...) for the stage-one FT-Joint path: the whole forward is one plan, the whole backward
-    another; parameter gradients are written straight into the flat gradient buffer (p.grad are views of it)."""
+class CrossModel(nn.Module):
+    """Parameters of module_cross.py:356-362."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.config = cfg
+        self.embeddings = _CrossEmbeddingsParams(cfg)
+        self.encoder = _EncoderParams(cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers)
+        self.pooler = _PoolerParams(cfg.hidden_size)
+
+
+class _MHAParams(nn.Module):
+    def __init__(self, Hd):
+        super().__init__()
+        self.query, self.key, self.value = nn.Linear(Hd, Hd), nn.Linear(Hd, Hd), nn.Linear(Hd, Hd)
+
+
+class _DecoderAttentionParams(nn.Module):
+    def __init__(self, Hd):
+        super().__init__()
+        self.att = _MHAParams(Hd)
+        self.output = _SelfOutputParams(Hd, Hd)
+
+
+class _DecoderLayerParams(nn.Module):
+    """module_decoder.py:279-285."""
+
+    def __init__(self, Hd, I):
+        super().__init__()
+        self.slf_attn = _DecoderAttentionParams(Hd)
+        self.enc_attn = _DecoderAttentionParams(Hd)
+        self.intermediate = _IntermediateParams(Hd, I)
+        self.output = _SelfOutputParams(I, Hd)
+
+
+class _DecoderEmbeddingsParams(nn.Module):
+    """module_decoder.py:294-307: word / position tables are BERT's (tied)."""
+
+    def __init__(self, cfg, word_w, pos_w):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(word_w.shape[0], word_w.shape[1])
+        self.position_embeddings = nn.Embedding(pos_w.shape[0], pos_w.shape[1])
+        self.word_embeddings.weight = word_w
+        self.position_embeddings.weight = pos_w
+        self.LayerNorm = LayerNorm(cfg.hidden_size)
+
+
+class _HeadTransformParams(nn.Module):
+    def __init__(self, Hd):
+        super().__init__()
+        self.dense = nn.Linear(Hd, Hd)
+        self.LayerNorm = LayerNorm(Hd)
+
+
+class _LMPredictionHeadParams(nn.Module):
+    """module_bert.py:314-325 / module_decoder.py:170-178: tied decoder.weight + own bias."""
+
+    def __init__(self, Hd, emb_w):
+        super().__init__()
+        self.transform = _HeadTransformParams(Hd)
+        self.decoder = nn.Linear(emb_w.size(1), emb_w.size(0), bias=False)
+        self.decoder.weight = emb_w
+        self.bias = nn.Parameter(torch.zeros(emb_w.size(0)))
+
+
+class _OnlyMLMHeadParams(nn.Module):
+    def __init__(self, Hd, emb_w):
+        super().__init__()
+        self.predictions = _LMPredictionHeadParams(Hd, emb_w)
+
+
+class _VisualLMPredictionHeadParams(nn.Module):
+    """module_visual.py:298-306: weight tied to the visual input projection (768,1024), bias (1024)."""
+
+    def __init__(self, Hd, vis_w):
+        super().__init__()
+        self.transform = _HeadTransformParams(Hd)
+        self.weight = vis_w
+        self.bias = nn.Parameter(torch.zeros(vis_w.size(1)))
+
+
+class _VisualOnlyMLMHeadParams(nn.Module):
+    def __init__(self, Hd, vis_w):
+        super().__init__()
+        self.predictions = _VisualLMPredictionHeadParams(Hd, vis_w)
+
+
+class _DecoderClassifierParams(nn.Module):
+    def __init__(self, Hd, emb_w):
+        super().__init__()
+        self.cls = _OnlyMLMHeadParams(Hd, emb_w)
+
+
+class _DecoderParams(nn.Module):
+    def __init__(self, Hd, I, L):
+        super().__init__()
+        self.layer = nn.ModuleList([_DecoderLayerParams(Hd, I) for _ in range(L)])
+
+
+class DecoderModel(nn.Module):
+    """Parameters of module_decoder.py:351-370."""
+
+    def __init__(self, cfg, word_w, pos_w):
+        super().__init__()
+        self.config = cfg
+        self.embeddings = _DecoderEmbeddingsParams(cfg, word_w, pos_w)
+        self.decoder = _DecoderParams(cfg.hidden_size, cfg.intermediate_size, cfg.num_decoder_layers)
+        self.classifier = _DecoderClassifierParams(cfg.hidden_size, word_w)
+
+
+class _StepLossFn(torch.autograd.Function):
+    """loss = UniVL.forward(...): the whole forward is one static plan, the whole backward another; parameter gradients
+    are written straight into the flat gradient buffer (p.grad are views of it)."""
 
     @staticmethod
     def forward(ctx, anchor, model, step):
@@ -225,11 +338,11 @@ class _JointLossFn(torch.autograd.Function):
 
 
 class _LossTensor(torch.Tensor):
-    """The scalar returned by UniVL.forward.  It is an ordinary autograd tensor (grad_fn = _JointLossFn), but a plain
+    """The scalar returned by UniVL.forward.  It is an ordinary autograd tensor (grad_fn = _StepLossFn), but a plain
     `loss.backward()` -- what main_task_retrieval.py:342 does -- runs the backward plan directly in the calling
     thread instead of going through the autograd engine's device thread (less overhead, and a multi-stream plan can
     then be captured into a hipGraph together with the forward).  Anything else (`(loss / k).backward()`,
-    `loss.mean()`, explicit gradients) takes the normal autograd route and ends in _JointLossFn.backward."""
+    `loss.mean()`, explicit gradients) takes the normal autograd route and ends in _StepLossFn.backward."""
 
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
         ms = self.__dict__.get("_univl", None)
@@ -260,17 +373,29 @@ class UniVL(UniVLPreTrainedModel):
             self._stage_one, self._stage_two = False, tc.stage_two
         self.train_sim_after_cross = bool(self._stage_one and _check_attr("train_sim_after_cross", tc))
 
+        # modeling.py:133-169 -- same construction order, same conditions
         if hasattr(tc, "text_num_hidden_layers"):
             bert_config.num_hidden_layers = tc.text_num_hidden_layers
         self.bert = BertModel(bert_config)
+        word_w = self.bert.embeddings.word_embeddings.weight
+        pos_w = self.bert.embeddings.position_embeddings.weight
         if hasattr(tc, "visual_num_hidden_layers"):
             visual_config.num_hidden_layers = tc.visual_num_hidden_layers
         self.visual = VisualModel(visual_config)
+        vis_w = self.visual.embeddings.word_embeddings.weight
         self.cross, self.decoder = None, None
         if self._stage_one is False or self.train_sim_after_cross:
-            raise NotImplementedError(
-                "univl_amd round 1 implements the stage-one FT-Joint retrieval path (SURVEY.md section 8); the cross "
-                "encoder / decoder paths (--train_sim_after_cross, --stage_two) are the next rows of section 8(a)")
+            if hasattr(tc, "cross_num_hidden_layers"):
+                cross_config.num_hidden_layers = tc.cross_num_hidden_layers
+            self.cross = CrossModel(cross_config)
+            if self.train_sim_after_cross is False:
+                if hasattr(tc, "decoder_num_hidden_layers"):
+                    decoder_config.num_decoder_layers = tc.decoder_num_hidden_layers
+                self.decoder = DecoderModel(decoder_config, word_w, pos_w)
+            if tc.do_pretrain:
+                self.cls = _OnlyMLMHeadParams(bert_config.hidden_size, word_w)
+                self.cls_visual = _VisualOnlyMLMHeadParams(visual_config.hidden_size, vis_w)
+            self.similarity_dense = nn.Linear(bert_config.hidden_size, 1)
         self.normalize_video = NormalizeVideo(tc)
         self.apply(self.init_weights)
 
@@ -337,209 +462,77 @@ class UniVL(UniVLPreTrainedModel):
         self._steps = {}
         return self
 
-    def used_parameter_names(self):
-        """Parameters that receive a gradient on the stage-one path: everything except the two dead poolers
-        (modeling.py:307,310 discard the pooled outputs)."""
-        return [n for n, _ in self.named_parameters() if ".pooler." not in n]
+    def step_kind(self, has_caption):
+        """Which of the reference's forward() branches applies (modeling.py:204-267)."""
+        tc = self.task_config
+        if self._stage_one:
+            return "align" if self.train_sim_after_cross else "joint"
+        if tc.do_pretrain:
+            return "pretrain"
+        if tc.task_type == "caption":
+            return "caption"
+        return "align"                       # stage two, task_type "retrieval": cross-encoder similarity + CrossEn
 
-    # ------------------------------------------------------------------------------------------ plans
-    def _get_step(self, B, W, F):
-        key = (B, W, F, self.training)
+    def used_parameter_names(self, kind=None):
+        """Parameters that receive a gradient in this configuration (the reference leaves `.grad = None` on the rest:
+        dead poolers modeling.py:307,310; the cross pooler / similarity_dense on the caption path)."""
+        kind = kind or self.step_kind(True)
+        out = []
+        for n, _ in self.named_parameters():
+            if n.startswith("bert.pooler") or n.startswith("visual.pooler"):
+                continue
+            if kind == "caption" and (n.startswith("cross.pooler") or n.startswith("similarity_dense")):
+                continue
+            if kind == "align" and (n.startswith("decoder.") or n.startswith("cls")):
+                continue
+            out.append(n)
+        return out
+
+    # ---------------------------------------------------------------------------------------- execution
+    def _get_step(self, kind, B, W, F):
+        key = (kind, B, W, F, self.training)
         st = self._steps.get(key)
         if st is None:
-            st = self._build_joint_step(B, W, F, self.training)
+            from .steps import build_step
+            st = build_step(self, kind, B, W, F, self.training)
             self._steps[key] = st
         return st
 
-    def _build_joint_step(self, B, W, F, training):
-        fl = self.flat
-        dev, ct, dt = fl.device, fl.compute_dtype, fl.dt
-        bf = ct == torch.bfloat16
-        tc = self.task_config
-        D, H = tc.video_dim, 768
-        f32, i64 = torch.float32, torch.int64
-        e = lambda *s, dtype=f32: torch.zeros(*s, device=dev, dtype=dtype)
-        st = _JointStep()
-        st.B, st.W, st.F = B, W, F
-        p = self.dropout_prob if training else 0.0
-        sites = _SiteCounter()
-        # static inputs
-        st.ids, st.type_ids, st.amask = e(B, W, dtype=i64), e(B, W, dtype=i64), e(B, W, dtype=i64)
-        st.video, st.vmask = e(B * F, D, dtype=torch.float64), e(B, F, dtype=i64)
-        Tt, Tv = B * W, B * F
-        # workspaces outside the encoder stacks
-        st.vy, st.vst = e(Tv, D), e(Tv, 2)
-        st.vn32 = e(Tv, D)
-        st.vn_op = e(Tv, D, dtype=ct) if bf else st.vn32
-        st.ve, st.vest = e(Tv, H), e(Tv, 2)
-        st.v0_32 = e(Tv, H)
-        st.v0_16 = e(Tv, H, dtype=ct) if bf else st.v0_32
-        st.te, st.test = e(Tt, H), e(Tt, 2)
-        st.t0_32 = e(Tt, H)
-        st.t0_16 = e(Tt, H, dtype=ct) if bf else st.t0_32
-        ldp = (B + 3) // 4 * 4
-        st.tmean, st.tn, st.vmean, st.vn = e(B, H), e(ldp, H), e(B, H), e(ldp, H)
-        st.sim, st.dsim = e(ldp, ldp), e(ldp, ldp)
-        st.loss, st.gout = e(1), e(1)
-        st.dtn, st.dvn = e(B, H), e(B, H)
-        st.dseq, st.dvis = e(Tt, H), e(Tv, H)
-        st.de_op = e(Tv, H, dtype=ct)
-        st.dvnorm = e(Tv, D)
-        # streams: 0 = text chain (+ everything serial), 1 = text weight gradients, 2 = video chain, 3 = video wgrads
-        dual = os.environ.get("UNIVL_DUAL_ENCODER", "1") != "0"       # text || video encoder
-        # weight gradients on a side stream: measured SLOWER on MI355X/ROCm 7.2 (4.83 vs 4.16 ms/step at bs 4: every
-        # cross-stream edge of the captured hipGraph costs more than the overlap buys) and, combined with the dual
-        # encoder streams, crashes hipStreamEndCapture -- kept as an opt-in experiment only.
-        sidew = os.environ.get("UNIVL_SIDE_WGRAD", "0") == "1"
-        ST, SV = 0, (2 if dual else 0)
-        st.text = EncoderStack(fl, "bert", self.bert_config.num_hidden_layers, B, W, st.amask, p, self._seed_dev, sites,
-                               s_main=ST, s_side=(1 if sidew else ST))
-        st.vis = EncoderStack(fl, "visual", self.visual_config.num_hidden_layers, B, F, st.vmask, p, self._seed_dev, sites,
-                              s_main=SV, s_side=(((1 if os.environ.get('UNIVL_SIDE_SHARED', '0') == '1' else 3) if dual else 1) if sidew else SV))
-        off_t, off_v = sites.next(), sites.next()
-        use_mil = bool(tc.use_mil)
-        W32, G = fl.w32, fl.g
-        nv_g, nv_b = "normalize_video.visual_norm2d.weight", "normalize_video.visual_norm2d.bias"
-        vw, vb = "visual.embeddings.word_embeddings.weight", "visual.embeddings.word_embeddings.bias"
-        vpos = "visual.embeddings.position_embeddings.weight"
-        vlg, vlb = "visual.embeddings.LayerNorm.weight", "visual.embeddings.LayerNorm.bias"
-        bw, bp, bt = ("bert.embeddings.word_embeddings.weight", "bert.embeddings.position_embeddings.weight",
-                      "bert.embeddings.token_type_embeddings.weight")
-        blg, blb = "bert.embeddings.LayerNorm.weight", "bert.embeddings.LayerNorm.bias"
-
-        # ------------------------------------------------------------------------------------ forward plan
-        fwd = Plan()
-        if p > 0:
-            fwd.add_callable(lambda: ops.bump_counter(self._seed_dev))
-        fwd.fork(ST, SV)           # the video encoder runs concurrently with the text encoder
-        fwd.add("univl_layernorm_fwd", ops.layernorm_desc(
-            dt, Tv, D, x=st.video, x_f64=True, gamma=W32(nv_g), beta=W32(nv_b), y=st.vy, stats=st.vst,
-            out32=st.vn32, out16=st.vn_op if bf else None), SV)
-        fwd.add("univl_gemm", _gemm_desc(dt, st.vn_op, D, fl.wop(vw), D, Tv, H, D, out32=st.ve, ldc=H, bias=W32(vb)), SV)
-        fwd.add("univl_layernorm_fwd", ops.layernorm_desc(
-            dt, Tv, H, x=st.ve, pos=W32(vpos), pos_period=F, gamma=W32(vlg), beta=W32(vlb), y=st.ve, stats=st.vest,
-            out32=st.v0_32, out16=st.v0_16 if bf else None, p_post=p, seed=self._seed, off_post=off_v,
-            seed_dev=self._seed_dev), SV)
-        fwd.add("univl_embed_text_fwd", ops.embed_text_desc(
-            dt, B, W, st.ids, W32(bw), W32(bp), W32(blg), W32(blb), type_ids=st.type_ids, type_emb=W32(bt), y=st.te,
-            stats=st.test, out32=st.t0_32, out16=st.t0_16 if bf else None, p_post=p, seed=self._seed, off_post=off_t,
-            seed_dev=self._seed_dev), ST)
-        st.vis.build_forward(fwd, st.v0_32, st.v0_16, training)
-        st.text.build_forward(fwd, st.t0_32, st.t0_16, training)
-        fwd.join(SV, ST)
-        st.seq_out, st.vis_out = st.text.output()[0], st.vis.output()[0]
-        st.fwd_encoders_len = len(fwd)
-        fwd.add("univl_pool_fwd", ops.pool_desc(B, W, st.seq_out, st.amask, skip_first=True, normalize=not use_mil,
-                                                mean=st.tmean, out=st.tn))
-        fwd.add("univl_pool_fwd", ops.pool_desc(B, F, st.vis_out, st.vmask, skip_first=False, normalize=not use_mil,
-                                                mean=st.vmean, out=st.vn))
-        fwd.add("univl_gemm", _gemm_desc(_lib.DT_F32, st.tn, H, st.vn, H, B, B, H, out32=st.sim, ldc=ldp))
-        L = _lib.lib()
-        sim_v, dsim_v = st.sim, st.dsim
-        if use_mil:
-            bs, npair = B // tc.n_pair, tc.n_pair
-            fwd.add_callable(lambda: ops.milnce_loss(sim_v[:B], bs, npair, st.loss, dsim_v[:B]))
-        else:
-            wts = None
-            bsz = tc.batch_size // tc.n_gpu
-            if tc.negative_weighting and tc.n_pair > 1 and bsz > 1:   # until_module.py:238-243
-                easy = 1 - tc.hard_negative_rate
-                alpha = easy / ((bsz - 1) * (1 - easy))
-                mm = np.kron((1 - alpha) * np.eye(bsz) + alpha, np.ones((tc.n_pair, tc.n_pair))) * (bsz * (1 - easy))
-                wts = torch.tensor(mm, dtype=f32, device=dev).contiguous()
-            st.loss_weight = wts
-            margin = float(tc.margin)
-            fwd.add_callable(lambda: ops.maxmargin_loss(sim_v[:B], margin, wts, st.loss, dsim_v[:B]))
-        st.fwd = fwd
-
-        # ----------------------------------------------------------------------------------- backward plans
-        def build_bwd(fresh):
-            bwd = Plan()
-            hook = None
-            red = self._reducer
-            if red is not None:
-                buckets = layer_buckets(fl, self.used_parameter_names())
-
-                def hook(plan, prefix, l, stream):
-                    s0, e0 = buckets["layers"][(prefix, l)]
-                    plan.add_callable(lambda: red.reduce_slice(s0, e0), stream=stream)
-            if fresh:
-                bwd.add_callable(fl.g32[:fl.v_end].zero_)
-            bwd.add_callable(lambda: ops.scale_by_device_scalar(st.dsim, st.gout))
-            # d tn = dsim . vn ;  d vn = dsim^T . tn      (modeling.py:389)
-            bwd.add("univl_gemm", _gemm_desc(_lib.DT_F32, st.dsim, ldp, st.vn, H, B, H, B, trans_b=1, out32=st.dtn, ldc=H))
-            bwd.add("univl_gemm", _gemm_desc(_lib.DT_F32, st.dsim, ldp, st.tn, H, B, H, B, trans_a=1, trans_b=1, out32=st.dvn, ldc=H))
-            bwd.add("univl_pool_bwd", ops.pool_desc(B, W, st.seq_out, st.amask, skip_first=True, normalize=not use_mil,
-                                                    mean=st.tmean, out=st.tn, dout=st.dtn, dx=st.dseq))
-            bwd.add("univl_pool_bwd", ops.pool_desc(B, F, st.vis_out, st.vmask, skip_first=False, normalize=not use_mil,
-                                                    mean=st.vmean, out=st.vn, dout=st.dvn, dx=st.dvis))
-            bwd.fork(ST, SV)       # video-encoder backward runs concurrently with the text-encoder backward
-            dxv = st.vis.build_backward(bwd, st.dvis, st.v0_32, st.v0_16, fresh, training, layer_hook=hook)
-            bwd.add("univl_layernorm_bwd", ops.layernorm_desc(
-                dt, Tv, H, gamma=W32(vlg), y=st.ve, stats=st.vest, dout=dxv, dxd16=st.de_op, dgamma=G(vlg), dbeta=G(vlb),
-                dbias=G(vb), dpos=G(vpos), pos_period=F, p_post=p, seed=self._seed, off_post=off_v, seed_dev=self._seed_dev), SV)
-            bwd.add("univl_gemm", _gemm_desc(dt, st.de_op, H, st.vn_op, D, H, D, Tv, trans_a=1, trans_b=1, out32=G(vw),
-                                             ldc=D, accumulate=not fresh), SV)
-            bwd.add("univl_gemm", _gemm_desc(dt, st.de_op, H, fl.wop(vw), D, Tv, D, H, trans_b=1, out32=st.dvnorm, ldc=D), SV)
-            bwd.add("univl_layernorm_bwd", ops.layernorm_desc(
-                dt, Tv, D, gamma=W32(nv_g), y=st.vy, stats=st.vst, dout=st.dvnorm, dgamma=G(nv_g), dbeta=G(nv_b)), SV)
-            dxt = st.text.build_backward(bwd, st.dseq, st.t0_32, st.t0_16, fresh, training, layer_hook=hook)
-            bwd.add("univl_embed_text_bwd", ops.embed_text_desc(
-                dt, B, W, st.ids, W32(bw), W32(bp), W32(blg), W32(blb), type_ids=st.type_ids, type_emb=W32(bt), y=st.te,
-                stats=st.test, p_post=p, seed=self._seed, off_post=off_t, seed_dev=self._seed_dev, dout=dxt,
-                dword=G(bw), dpos=G(bp), dtype_emb=G(bt), dgamma=G(blg), dbeta=G(blb)), ST)
-            bwd.join(SV, ST)
-            if red is not None:
-                for (s0, e0) in buckets["tail"]:
-                    bwd.add_callable(lambda s0=s0, e0=e0: red.reduce_slice(s0, e0))
-                bwd.add_callable(red.join)
-            return bwd
-
-        st.bwd_fresh = build_bwd(True)
-        st.bwd_acc = None
-        st._build_bwd = build_bwd
-        return st
-
-    # ---------------------------------------------------------------------------------------- execution
-    def _load_inputs(self, st, input_ids, token_type_ids, attention_mask, video, video_mask):
-        st.ids.copy_(input_ids.reshape(st.B, st.W), non_blocking=True)
-        st.type_ids.copy_(token_type_ids.reshape(st.B, st.W), non_blocking=True)
-        st.amask.copy_(attention_mask.reshape(st.B, st.W), non_blocking=True)
-        st.video.copy_(torch.as_tensor(video).reshape(st.B * st.F, -1), non_blocking=True)
-        st.vmask.copy_(video_mask.reshape(st.B, st.F), non_blocking=True)
-
     def _run_backward(self, st, gout):
         fl = self.flat
-        used = self.used_parameter_names()
+        used = self.used_parameter_names(st.kind)
         fresh = all(fl.params[n].grad is None for n in (used[0], used[-1]))
         if gout is None:
             st.gout.fill_(1.0)
         else:
             st.gout.copy_(gout.reshape(1).to(torch.float32))
         fl.grad_version += 1
-        if fresh:
-            st.bwd_fresh.run()
-        else:
-            if st.bwd_acc is None:
-                st.bwd_acc = st._build_bwd(False)
-            st.bwd_acc.run()
+        st.backward_plan(fresh).run()
         fl.attach_grads(used)
 
     def forward(self, input_ids, token_type_ids, attention_mask, video, video_mask=None,
                 pairs_masked_text=None, pairs_token_labels=None, masked_video=None, video_labels_index=None,
                 input_caption_ids=None, decoder_mask=None, output_caption_ids=None):
-        """modeling.py:188-271 (stage-one branch).  Returns the scalar loss in training mode, None otherwise."""
-        W, F = input_ids.shape[-1], video_mask.shape[-1]
-        B = input_ids.numel() // W
-        fl = self.flat
-        fl.refresh_shadow()
-        st = self._get_step(B, W, F)
-        self._load_inputs(st, input_ids, token_type_ids, attention_mask, video, video_mask)
+        """modeling.py:188-271.  Returns the scalar loss in training mode, None otherwise."""
         if not self.training:
             return None
+        W, F = input_ids.shape[-1], video_mask.shape[-1]
+        B = input_ids.numel() // W
+        kind = self.step_kind(input_caption_ids is not None)
+        if kind in ("caption", "pretrain") and input_caption_ids is None:
+            raise RuntimeError("UniVL.forward: the %s path needs input_caption_ids / decoder_mask / output_caption_ids" % kind)
+        fl = self.flat
+        fl.refresh_shadow()
+        st = self._get_step(kind, B, W, F)
+        st.enc.load(input_ids, token_type_ids, attention_mask, video, video_mask)
+        if kind == "pretrain":
+            st.enc_m.load(pairs_masked_text, token_type_ids, attention_mask, masked_video, video_mask)
+            st.heads.load(pairs_token_labels, video_labels_index)
+        if st.decoder is not None:
+            st.decoder.load(input_caption_ids, decoder_mask, output_caption_ids)
         anchor = fl.params["normalize_video.visual_norm2d.bias"]
         if torch.is_grad_enabled() and anchor.requires_grad:
-            out = _JointLossFn.apply(anchor, self, st).as_subclass(_LossTensor)
+            out = _StepLossFn.apply(anchor, self, st).as_subclass(_LossTensor)
             out._univl = (self, st)
             return out
         st.fwd.run()
@@ -554,35 +547,107 @@ class UniVL(UniVLPreTrainedModel):
         B = input_ids.numel() // W
         fl = self.flat
         fl.refresh_shadow()
-        st = self._get_step(B, W, F)
-        self._load_inputs(st, input_ids, token_type_ids, attention_mask, video, video_mask)
+        was = self.training
+        self.training = False                      # feature extraction never applies dropout plans' training variant
+        try:
+            st = self._get_step("joint" if self.cross is None else "features", B, W, F)
+        finally:
+            self.training = was
+        st.enc.load(input_ids, token_type_ids, attention_mask, video, video_mask)
         st.fwd.run(upto=st.fwd_encoders_len)
-        return st.seq_out.view(B, W, -1).clone(), st.vis_out.view(B, F, -1).clone()
+        return st.enc.seq_out.view(B, W, -1).clone(), st.enc.vis_out.view(B, F, -1).clone()
 
     def get_similarity_logits(self, sequence_output, visual_output, attention_mask, video_mask, shaped=False,
                               _pretrain_joint=False):
-        """modeling.py:377-391 (mean-pooling branch): masked means, L2 normalisation unless use_mil, text . video^T."""
+        """modeling.py:377-391: cross-encoder similarity when stage two / train_sim_after_cross, else masked means,
+        L2 normalisation unless use_mil, text . video^T."""
         attention_mask = attention_mask.reshape(-1, attention_mask.shape[-1])
         video_mask = video_mask.reshape(-1, video_mask.shape[-1])
         _lib.lib()
         dev = sequence_output.device
         if dev.type != "cuda":
             raise RuntimeError("univl_amd.UniVL.get_similarity_logits needs HIP device tensors; no CPU fallback")
-        Bt, W, H = sequence_output.shape
+        Bt, W, Hd = sequence_output.shape
         Bv, F, _ = visual_output.shape
-        norm = not bool(self.task_config.use_mil)
         seq = sequence_output.to(torch.float32).contiguous()
         vis = visual_output.to(torch.float32).contiguous()
         am = attention_mask.to(dev, torch.int64).contiguous()
         vm = video_mask.to(dev, torch.int64).contiguous()
+        if (self._stage_two and _pretrain_joint is False) or self.train_sim_after_cross:
+            return self._cross_similarity_eval(seq, vis, am, vm)
+        norm = not bool(self.task_config.use_mil)
         ldt, ldv = (Bt + 3) // 4 * 4, (Bv + 3) // 4 * 4
-        tn = torch.zeros(ldt, H, device=dev)
-        vn = torch.zeros(ldv, H, device=dev)
+        tn = torch.zeros(ldt, Hd, device=dev)
+        vn = torch.zeros(ldv, Hd, device=dev)
         ops.pool_fwd(Bt, W, seq, am, skip_first=True, normalize=norm, out=tn)
         ops.pool_fwd(Bv, F, vis, vm, skip_first=False, normalize=norm, out=vn)
         sim = torch.empty(Bt, Bv, device=dev)
-        ops.gemm(tn, vn, Bt, Bv, H, out32=sim)
+        ops.gemm(tn, vn, Bt, Bv, Hd, out32=sim)
         return sim
 
-    def decoder_caption(self, *a, **kw):
-        raise NotImplementedError("decoder path (SURVEY.md section 8a, caption rows) is not built yet in univl_amd")
+    def _cross_similarity_eval(self, seq, vis, am, vm, chunk_rows=5):
+        """_cross_similarity (modeling.py:341-375) for cached features: every (text, video) pair through the cross
+        encoder, `chunk_rows` text rows at a time (the reference's step_size = 5)."""
+        from .steps import Ctx, CrossRun, PoolerSim, RowFeatures
+        from .engine import Plan
+        Bt, W, _ = seq.shape
+        Bv, F, _ = vis.shape
+        self.flat.refresh_shadow()
+        out = torch.empty(Bt, Bv, device=seq.device)
+        for lo in range(0, Bt, chunk_rows):
+            n = min(chunk_rows, Bt - lo)
+            key = ("xsim", n, Bv, W, F)
+            ev = self._steps.get(key)
+            if ev is None:
+                cx = Ctx(self, False)
+                feats = RowFeatures(cx, n, Bv, W, F)
+                pairs = [(i, j) for i in range(n) for j in range(Bv)]
+                run = CrossRun(cx, feats, [a for a, _ in pairs], [b for _, b in pairs])
+                plan = Plan()
+                run.build_forward(plan)
+                pooler = PoolerSim(cx, run, n, Bv, None)
+                pooler.build_forward(plan)
+                ev = self._steps[key] = (feats, run, pooler, plan)
+            feats, run, pooler, plan = ev
+            feats.load(seq[lo:lo + n], vis, am[lo:lo + n], vm)
+            plan.run()
+            out[lo:lo + n].copy_(pooler.sim.view(n, Bv))
+        return out
+
+    def decoder_caption(self, sequence_output, visual_output, input_ids, attention_mask, video_mask, input_caption_ids,
+                        decoder_mask, shaped=False, get_logits=False):
+        """modeling.py:409-428: cross encoder on cat(text, video) then the decoder; returns the (n, len, vocab) logits or
+        their argmax."""
+        if self.decoder is None:
+            raise RuntimeError("decoder_caption: this model was built without a decoder (stage one)")
+        from .steps import Ctx, CrossRun, DecoderRun, RowFeatures
+        from .engine import Plan
+        attention_mask = attention_mask.reshape(-1, attention_mask.shape[-1])
+        video_mask = video_mask.reshape(-1, video_mask.shape[-1])
+        input_caption_ids = input_caption_ids.reshape(-1, input_caption_ids.shape[-1])
+        decoder_mask = decoder_mask.reshape(-1, decoder_mask.shape[-1])
+        B, W, _ = sequence_output.shape
+        F, Wd = visual_output.shape[1], input_caption_ids.shape[-1]
+        if sequence_output.device.type != "cuda":
+            raise RuntimeError("univl_amd.UniVL.decoder_caption needs HIP device tensors; no CPU fallback")
+        self.flat.refresh_shadow()
+        key = ("caption_eval", B, W, F, Wd)
+        ev = self._steps.get(key)
+        if ev is None:
+            cx = Ctx(self, False)
+            feats = RowFeatures(cx, B, B, W, F)
+            run = CrossRun(cx, feats, list(range(B)), list(range(B)))
+            plan = Plan()
+            run.build_forward(plan)
+            dec = DecoderRun(cx, run, Wd, with_loss=False)
+            dec.build_forward(plan)
+            ev = self._steps[key] = (feats, run, dec, plan)
+        feats, run, dec, plan = ev
+        feats.load(sequence_output.to(torch.float32), visual_output.to(torch.float32), attention_mask, video_mask)
+        dec.load(input_caption_ids, decoder_mask)
+        plan.run()
+        V = self.bert_config.vocab_size
+        scores = dec.head.logits.view(B, Wd, -1)[:, :, :V]
+        if get_logits:
+            return scores.clone()
+        return torch.max(scores, -1)[1]

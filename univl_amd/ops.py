@@ -157,12 +157,13 @@ def embed_text_bwd(*a, **kw):
     _lib.check(_lib.lib().univl_embed_text_bwd(_BYREF(d), _stream()), "embed_text_bwd")
 
 
-def pool_desc(B, S, x, mask, *, skip_first, normalize, mean=None, out=None, dout=None, dx=None, ldx_row=768):
+def pool_desc(B, S, x, mask, *, skip_first, normalize, mean=None, out=None, dout=None, dx=None, ldx_row=768, accumulate=False):
     d = _lib.Pool()
     d.B, d.S, d.N = B, S, 768
     d.x, d.ldx_row, d.mask = _p(x), ldx_row, _p(mask)
     d.skip_first, d.normalize = int(skip_first), int(normalize)
     d.mean, d.out, d.dout, d.dx = _p(mean), _p(out), _p(dout), _p(dx)
+    d.accumulate = int(accumulate)
     return d
 
 
@@ -203,3 +204,61 @@ def cast_bf16(src, dst):
 
 def bump_counter(ctr):
     _lib.check(_lib.lib().univl_bump_counter(_p(ctr), _stream()), "bump_counter")
+
+
+def pair_concat_fwd(seq, vis, amask, vmask, tidx, vidx, P, W, F, out, out_mask):
+    _lib.check(_lib.lib().univl_pair_concat_fwd(_p(seq), _p(vis), _p(amask), _p(vmask), _p(tidx), _p(vidx), P, W, F, _p(out),
+                                                _p(out_mask), _stream()), "pair_concat_fwd")
+
+
+def pair_concat_bwd(dout, tidx, vidx, P, W, F, dseq, dvis):
+    _lib.check(_lib.lib().univl_pair_concat_bwd(_p(dout), _p(tidx), _p(vidx), P, W, F, _p(dseq), _p(dvis), _stream()), "pair_concat_bwd")
+
+
+def postype_fwd(pos, type_emb, W, S, out):
+    _lib.check(_lib.lib().univl_postype_fwd(_p(pos), _p(type_emb), W, S, _p(out), _stream()), "postype_fwd")
+
+
+def postype_bwd(dtable, W, S, dpos, dtype_emb):
+    _lib.check(_lib.lib().univl_postype_bwd(_p(dtable), W, S, _p(dpos), _p(dtype_emb), _stream()), "postype_bwd")
+
+
+def tanh_fwd(x, y):
+    _lib.check(_lib.lib().univl_tanh_fwd(_p(x), _p(y), x.numel(), _stream()), "tanh_fwd")
+
+
+def tanh_bwd(dy, y, dx):
+    _lib.check(_lib.lib().univl_tanh_bwd(dtype_code(dx.dtype), _p(dy), _p(y), _p(dx), y.numel(), _stream()), "tanh_bwd")
+
+
+def gelu_bwd(dg, u, du):
+    _lib.check(_lib.lib().univl_gelu_bwd(dtype_code(du.dtype), _p(dg), _p(u), _p(du), u.numel(), _stream()), "gelu_bwd")
+
+
+def simdense_fwd(x, w, b, out):
+    _lib.check(_lib.lib().univl_simdense_fwd(_p(x), _p(w), _p(b), x.shape[0], _p(out), _stream()), "simdense_fwd")
+
+
+def simdense_bwd(ds, x, w, dx, dw, db):
+    _lib.check(_lib.lib().univl_simdense_bwd(_p(ds), _p(x), _p(w), x.shape[0], _p(dx), _p(dw), _p(db), _stream()), "simdense_bwd")
+
+
+def ce_loss(logits, labels, V, scratch2, loss, dlogits, ignore_index=-1):
+    """logits: [rows, ld] fp32 view; dlogits: [rows, lddl] compute-type view."""
+    _lib.check(_lib.lib().univl_ce_loss(dtype_code(dlogits.dtype), _p(logits), logits.stride(0), _p(labels), logits.shape[0], V,
+                                        ignore_index, _p(scratch2), _p(loss), _p(dlogits), dlogits.stride(0), _stream()), "ce_loss")
+
+
+def mfm_nce_loss(logits, vmask, labels, scratch2, loss, dlogits):
+    n = logits.shape[0]
+    _lib.check(_lib.lib().univl_mfm_nce_loss(_p(logits), logits.stride(0), _p(vmask), _p(labels), n, _p(scratch2), _p(loss),
+                                             _p(dlogits), dlogits.stride(0), _stream()), "mfm_nce_loss")
+
+
+def colsum(x, out):
+    """out[c] += sum_r x[r, c]; x: [rows, ld] view in the compute type."""
+    _lib.check(_lib.lib().univl_colsum(dtype_code(x.dtype), _p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), _stream()), "colsum")
+
+
+def scale_ct(x, s):
+    _lib.check(_lib.lib().univl_scale_ct_by_device_scalar(dtype_code(x.dtype), _p(x), x.numel(), _p(s), _stream()), "scale_ct")

@@ -1,0 +1,650 @@
+"""Static execution plans for the four ways the reference drives `UniVL.forward` (modules/modeling.py:188-271):
+
+    joint     stage one, FT-Joint:  encoders -> mean-pool similarity -> ranking / MIL-NCE loss          (:206-211)
+    align     stage one, FT-Align (--train_sim_after_cross): encoders -> every (text, video) pair through the cross
+              encoder -> pooler -> similarity_dense -> loss                                              (:341-375)
+    caption   stage two, task_type "caption": encoders -> cross encoder -> decoder -> vocabulary CE      (:238-254)
+    pretrain  stage two, do_pretrain: clean + masked encoder passes, cross encoder, MLM + MFM heads, joint
+              similarity, decoder, cross-encoder alignment -- the five losses of :212-267
+
+Each component below owns its persistent workspace and can append its forward and backward kernels to a Plan.
+Gradient flow between components goes through fp32 accumulation buffers (dseq/dvis of an encoder pass, dcross of a
+cross-encoder run) that the backward plan zeroes once and every consumer adds into.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .engine import DecoderStack, EncoderStack, GradState, Plan, _SiteCounter, _gemm_desc
+
+H = 768
+
+
+def _e(dev):
+    return lambda *s, dtype=torch.float32: torch.zeros(*s, device=dev, dtype=dtype)
+
+
+class Ctx:
+    """Everything the components share for one compiled step."""
+
+    def __init__(self, model, training):
+        self.model, self.fl, self.training = model, model.flat, training
+        self.tc = model.task_config
+        self.dev, self.ct, self.dt = self.fl.device, self.fl.compute_dtype, self.fl.dt
+        self.bf = self.ct == torch.bfloat16
+        self.p = model.dropout_prob if training else 0.0
+        self.seed, self.seed_dev = model._seed, model._seed_dev
+        self.sites = _SiteCounter()
+        self.e = _e(self.dev)
+        self.red = model._reducer
+
+
+class EncoderPass:
+    """NormalizeVideo + BertModel + VisualModel for one set of inputs (modeling.py:196-202, 299-313)."""
+
+    def __init__(self, cx, B, W, F, s_text=0, s_vis=2):
+        self.cx, self.B, self.W, self.F = cx, B, W, F
+        e, ct, bf, fl = cx.e, cx.ct, cx.bf, cx.fl
+        D = cx.tc.video_dim
+        self.D, self.Tt, self.Tv = D, B * W, B * F
+        self.ST, self.SV = s_text, s_vis
+        i64 = torch.int64
+        self.ids, self.type_ids, self.amask = e(B, W, dtype=i64), e(B, W, dtype=i64), e(B, W, dtype=i64)
+        self.video, self.vmask = e(B * F, D, dtype=torch.float64), e(B, F, dtype=i64)
+        self.vy, self.vst, self.vn32 = e(self.Tv, D), e(self.Tv, 2), e(self.Tv, D)
+        self.vn_op = e(self.Tv, D, dtype=ct) if bf else self.vn32
+        self.ve, self.vest, self.v0_32 = e(self.Tv, H), e(self.Tv, 2), e(self.Tv, H)
+        self.v0_16 = e(self.Tv, H, dtype=ct) if bf else self.v0_32
+        self.te, self.test, self.t0_32 = e(self.Tt, H), e(self.Tt, 2), e(self.Tt, H)
+        self.t0_16 = e(self.Tt, H, dtype=ct) if bf else self.t0_32
+        self.dseq, self.dvis = e(self.Tt, H), e(self.Tv, H)
+        self.de_op = e(self.Tv, H, dtype=ct)
+        self.dvnorm = e(self.Tv, D)            # grad wrt the normalised video (accumulated: encoder + MFM loss)
+        m = cx.model
+        self.text = EncoderStack(fl, "bert", m.bert_config.num_hidden_layers, B, W, self.amask, cx.p, cx.seed_dev, cx.sites,
+                                 s_main=s_text, s_side=s_text)
+        self.vis = EncoderStack(fl, "visual", m.visual_config.num_hidden_layers, B, F, self.vmask, cx.p, cx.seed_dev, cx.sites,
+                                s_main=s_vis, s_side=s_vis)
+        self.off_t, self.off_v = cx.sites.next(), cx.sites.next()
+        self.seq_out, self.seq_out16 = self.text.output()
+        self.vis_out, self.vis_out16 = self.vis.output()
+
+    N = dict(nv_g="normalize_video.visual_norm2d.weight", nv_b="normalize_video.visual_norm2d.bias",
+             vw="visual.embeddings.word_embeddings.weight", vb="visual.embeddings.word_embeddings.bias",
+             vpos="visual.embeddings.position_embeddings.weight", vlg="visual.embeddings.LayerNorm.weight",
+             vlb="visual.embeddings.LayerNorm.bias", bw="bert.embeddings.word_embeddings.weight",
+             bp="bert.embeddings.position_embeddings.weight", bt="bert.embeddings.token_type_embeddings.weight",
+             blg="bert.embeddings.LayerNorm.weight", blb="bert.embeddings.LayerNorm.bias")
+
+    def load(self, input_ids, token_type_ids, attention_mask, video, video_mask):
+        B, W, F = self.B, self.W, self.F
+        self.ids.copy_(input_ids.reshape(B, W), non_blocking=True)
+        self.type_ids.copy_(token_type_ids.reshape(B, W), non_blocking=True)
+        self.amask.copy_(attention_mask.reshape(B, W), non_blocking=True)
+        self.video.copy_(torch.as_tensor(video).reshape(B * F, -1), non_blocking=True)
+        self.vmask.copy_(video_mask.reshape(B, F), non_blocking=True)
+
+    def build_forward(self, fwd):
+        cx, n, fl, dt, bf = self.cx, self.N, self.cx.fl, self.cx.dt, self.cx.bf
+        W32, p, B, W, F, D, Tv = fl.w32, cx.p, self.B, self.W, self.F, self.D, self.Tv
+        ST, SV = self.ST, self.SV
+        fwd.fork(ST, SV)           # the video encoder runs concurrently with the text encoder
+        fwd.add("univl_layernorm_fwd", ops.layernorm_desc(
+            dt, Tv, D, x=self.video, x_f64=True, gamma=W32(n["nv_g"]), beta=W32(n["nv_b"]), y=self.vy, stats=self.vst,
+            out32=self.vn32, out16=self.vn_op if bf else None), SV)
+        fwd.add("univl_gemm", _gemm_desc(dt, self.vn_op, D, fl.wop(n["vw"]), D, Tv, H, D, out32=self.ve, ldc=H, bias=W32(n["vb"])), SV)
+        fwd.add("univl_layernorm_fwd", ops.layernorm_desc(
+            dt, Tv, H, x=self.ve, pos=W32(n["vpos"]), pos_period=F, gamma=W32(n["vlg"]), beta=W32(n["vlb"]), y=self.ve,
+            stats=self.vest, out32=self.v0_32, out16=self.v0_16 if bf else None, p_post=p, seed=cx.seed, off_post=self.off_v,
+            seed_dev=cx.seed_dev), SV)
+        fwd.add("univl_embed_text_fwd", ops.embed_text_desc(
+            dt, B, W, self.ids, W32(n["bw"]), W32(n["bp"]), W32(n["blg"]), W32(n["blb"]), type_ids=self.type_ids,
+            type_emb=W32(n["bt"]), y=self.te, stats=self.test, out32=self.t0_32, out16=self.t0_16 if bf else None, p_post=p,
+            seed=cx.seed, off_post=self.off_t, seed_dev=cx.seed_dev), ST)
+        self.vis.build_forward(fwd, self.v0_32, self.v0_16, cx.training)
+        self.text.build_forward(fwd, self.t0_32, self.t0_16, cx.training)
+        fwd.join(SV, ST)
+
+    def zero_grads(self, bwd):
+        bwd.add_callable(self.dseq.zero_)
+        bwd.add_callable(self.dvis.zero_)
+        bwd.add_callable(self.dvnorm.zero_)
+
+    def build_backward(self, bwd, gs, hook=None):
+        """Consumes self.dseq / self.dvis (+ whatever was accumulated into self.dvnorm)."""
+        cx, n, fl, dt = self.cx, self.N, self.cx.fl, self.cx.dt
+        W32, G, p, B, W, F, D, Tv = fl.w32, fl.g, cx.p, self.B, self.W, self.F, self.D, self.Tv
+        ST, SV = self.ST, self.SV
+        bwd.fork(ST, SV)
+        dxv = self.vis.build_backward(bwd, self.dvis, self.v0_32, self.v0_16, gs, cx.training, layer_hook=hook)
+        bwd.add("univl_layernorm_bwd", ops.layernorm_desc(
+            dt, Tv, H, gamma=W32(n["vlg"]), y=self.ve, stats=self.vest, dout=dxv, dxd16=self.de_op, dgamma=G(n["vlg"]),
+            dbeta=G(n["vlb"]), dbias=G(n["vb"]), dpos=G(n["vpos"]), pos_period=F, p_post=p, seed=cx.seed, off_post=self.off_v,
+            seed_dev=cx.seed_dev), SV)
+        bwd.add("univl_gemm", _gemm_desc(dt, self.de_op, H, self.vn_op, D, H, D, Tv, trans_a=1, trans_b=1, out32=G(n["vw"]),
+                                         ldc=D, accumulate=gs.acc(n["vw"])), SV)
+        bwd.add("univl_gemm", _gemm_desc(dt, self.de_op, H, fl.wop(n["vw"]), D, Tv, D, H, trans_b=1, out32=self.dvnorm, ldc=D,
+                                         accumulate=True), SV)
+        bwd.add("univl_layernorm_bwd", ops.layernorm_desc(
+            dt, Tv, D, gamma=W32(n["nv_g"]), y=self.vy, stats=self.vst, dout=self.dvnorm, dgamma=G(n["nv_g"]), dbeta=G(n["nv_b"])), SV)
+        dxt = self.text.build_backward(bwd, self.dseq, self.t0_32, self.t0_16, gs, cx.training, layer_hook=hook)
+        bwd.add("univl_embed_text_bwd", ops.embed_text_desc(
+            dt, B, W, self.ids, W32(n["bw"]), W32(n["bp"]), W32(n["blg"]), W32(n["blb"]), type_ids=self.type_ids,
+            type_emb=W32(n["bt"]), y=self.te, stats=self.test, p_post=p, seed=cx.seed, off_post=self.off_t,
+            seed_dev=cx.seed_dev, dout=dxt, dword=G(n["bw"]), dpos=G(n["bp"]), dtype_emb=G(n["bt"]), dgamma=G(n["blg"]),
+            dbeta=G(n["blb"])), ST)
+        bwd.join(SV, ST)
+
+
+class SimLoss:
+    """loss_fct on a [n, ld] similarity matrix (modeling.py:172-184): MaxMarginRankingLoss / MILNCELoss / CrossEn."""
+
+    def __init__(self, cx, kind, n):
+        self.cx, self.kind, self.n = cx, kind, n
+        self.loss = cx.e(1)
+        tc = cx.tc
+        self.wts = None
+        if kind == "maxmargin":
+            bsz = tc.batch_size // tc.n_gpu
+            if tc.negative_weighting and tc.n_pair > 1 and bsz > 1:     # until_module.py:238-243
+                easy = 1 - tc.hard_negative_rate
+                alpha = easy / ((bsz - 1) * (1 - easy))
+                mm = np.kron((1 - alpha) * np.eye(bsz) + alpha, np.ones((tc.n_pair, tc.n_pair))) * (bsz * (1 - easy))
+                self.wts = torch.tensor(mm, dtype=torch.float32, device=cx.dev).contiguous()
+
+    def build(self, fwd, sim, dsim):
+        """sim / dsim: [n, ld] views."""
+        tc, n = self.cx.tc, self.n
+        if self.kind == "milnce":
+            bs, npair = n // tc.n_pair, tc.n_pair
+            fwd.add_callable(lambda: ops.milnce_loss(sim, bs, npair, self.loss, dsim))
+        elif self.kind == "crossen":
+            fwd.add_callable(lambda: ops.crossen_loss(sim, self.loss, dsim))
+        else:
+            margin, wts = float(tc.margin), self.wts
+            fwd.add_callable(lambda: ops.maxmargin_loss(sim, margin, wts, self.loss, dsim))
+
+
+class JointSim:
+    """get_similarity_logits, mean-pooling branch (modeling.py:327-339, 383-389)."""
+
+    def __init__(self, cx, enc, loss_kind):
+        self.cx, self.enc = cx, enc
+        B = enc.B
+        e = cx.e
+        self.ldp = (B + 3) // 4 * 4
+        self.tmean, self.tn, self.vmean, self.vn = e(B, H), e(self.ldp, H), e(B, H), e(self.ldp, H)
+        self.sim, self.dsim = e(self.ldp, self.ldp), e(self.ldp, self.ldp)
+        self.dtn, self.dvn = e(B, H), e(B, H)
+        self.norm = not bool(cx.tc.use_mil)
+        self.lossfn = SimLoss(cx, loss_kind, B)
+        self.loss = self.lossfn.loss
+
+    def build_forward(self, fwd):
+        enc, B = self.enc, self.enc.B
+        fwd.add("univl_pool_fwd", ops.pool_desc(B, enc.W, enc.seq_out, enc.amask, skip_first=True, normalize=self.norm,
+                                                mean=self.tmean, out=self.tn))
+        fwd.add("univl_pool_fwd", ops.pool_desc(B, enc.F, enc.vis_out, enc.vmask, skip_first=False, normalize=self.norm,
+                                                mean=self.vmean, out=self.vn))
+        fwd.add("univl_gemm", _gemm_desc(_lib.DT_F32, self.tn, H, self.vn, H, B, B, H, out32=self.sim, ldc=self.ldp))
+        self.lossfn.build(fwd, self.sim[:B], self.dsim[:B])
+
+    def build_backward(self, bwd, gout):
+        enc, B, ldp = self.enc, self.enc.B, self.ldp
+        bwd.add_callable(lambda: ops.scale_by_device_scalar(self.dsim, gout))
+        bwd.add("univl_gemm", _gemm_desc(_lib.DT_F32, self.dsim, ldp, self.vn, H, B, H, B, trans_b=1, out32=self.dtn, ldc=H))
+        bwd.add("univl_gemm", _gemm_desc(_lib.DT_F32, self.dsim, ldp, self.tn, H, B, H, B, trans_a=1, trans_b=1, out32=self.dvn, ldc=H))
+        bwd.add("univl_pool_bwd", ops.pool_desc(B, enc.W, enc.seq_out, enc.amask, skip_first=True, normalize=self.norm,
+                                                mean=self.tmean, out=self.tn, dout=self.dtn, dx=enc.dseq, accumulate=True))
+        bwd.add("univl_pool_bwd", ops.pool_desc(B, enc.F, enc.vis_out, enc.vmask, skip_first=False, normalize=self.norm,
+                                                mean=self.vmean, out=self.vn, dout=self.dvn, dx=enc.dvis, accumulate=True))
+
+
+class CrossRun:
+    """CrossModel over P sequences cat(text row tidx[p], video row vidx[p]) (modeling.py:315-325, module_cross.py:364-394)."""
+
+    def __init__(self, cx, enc, tidx, vidx, stream=0):
+        self.cx, self.enc = cx, enc
+        self.P = len(tidx)
+        self.W, self.F = enc.W, enc.F
+        self.S = S = enc.W + enc.F
+        self.T = T = self.P * S
+        e, ct, bf, fl = cx.e, cx.ct, cx.bf, cx.fl
+        self.sm = stream
+        self.tidx = torch.tensor(list(tidx), dtype=torch.int32, device=cx.dev)
+        self.vidx = torch.tensor(list(vidx), dtype=torch.int32, device=cx.dev)
+        self.cmask = e(self.P, S, dtype=torch.int64)
+        self.concat, self.cst = e(T, H), e(T, 2)
+        self.c0_32 = e(T, H)
+        self.c0_16 = e(T, H, dtype=ct) if bf else self.c0_32
+        self.postype, self.dpostype = e(S, H), e(S, H)
+        self.dcross = e(T, H)
+        self.dconcat = e(T, H)
+        L = cx.model.cross_config.num_hidden_layers
+        self.stack = EncoderStack(fl, "cross", L, self.P, S, self.cmask, cx.p, cx.seed_dev, cx.sites, s_main=stream, s_side=stream)
+        self.off = cx.sites.next()
+        self.out32, self.out16 = self.stack.output()
+
+    N = dict(pos="cross.embeddings.position_embeddings.weight", typ="cross.embeddings.token_type_embeddings.weight",
+             lg="cross.embeddings.LayerNorm.weight", lb="cross.embeddings.LayerNorm.bias")
+
+    def build_forward(self, fwd):
+        cx, enc, n, fl, dt, sm = self.cx, self.enc, self.N, self.cx.fl, self.cx.dt, self.sm
+        W32 = fl.w32
+        P, W, F, S, T = self.P, self.W, self.F, self.S, self.T
+        fwd.add_callable(lambda: ops.postype_fwd(W32(n["pos"]), W32(n["typ"]), W, S, self.postype), sm)
+        fwd.add_callable(lambda: ops.pair_concat_fwd(enc.seq_out, enc.vis_out, enc.amask, enc.vmask, self.tidx, self.vidx, P, W, F,
+                                                     self.concat, self.cmask), sm)
+        fwd.add("univl_layernorm_fwd", ops.layernorm_desc(
+            dt, T, H, x=self.concat, pos=self.postype, pos_period=S, gamma=W32(n["lg"]), beta=W32(n["lb"]), y=self.concat,
+            stats=self.cst, out32=self.c0_32, out16=self.c0_16 if cx.bf else None, p_post=cx.p, seed=cx.seed, off_post=self.off,
+            seed_dev=cx.seed_dev), sm)
+        self.stack.build_forward(fwd, self.c0_32, self.c0_16, cx.training)
+
+    def zero_grads(self, bwd):
+        bwd.add_callable(self.dcross.zero_, self.sm)
+        bwd.add_callable(self.dpostype.zero_, self.sm)
+
+    def build_backward(self, bwd, gs, hook=None):
+        """Consumes self.dcross (accumulated by the consumers); adds into enc.dseq / enc.dvis."""
+        cx, enc, n, fl, dt, sm = self.cx, self.enc, self.N, self.cx.fl, self.cx.dt, self.sm
+        W32, G = fl.w32, fl.g
+        P, W, F, S, T = self.P, self.W, self.F, self.S, self.T
+        dx0 = self.stack.build_backward(bwd, self.dcross, self.c0_32, self.c0_16, gs, cx.training, layer_hook=hook)
+        bwd.add("univl_layernorm_bwd", ops.layernorm_desc(
+            dt, T, H, gamma=W32(n["lg"]), y=self.concat, stats=self.cst, dout=dx0, dx32=self.dconcat, dgamma=G(n["lg"]),
+            dbeta=G(n["lb"]), dpos=self.dpostype, pos_period=S, p_post=cx.p, seed=cx.seed, off_post=self.off,
+            seed_dev=cx.seed_dev), sm)
+        bwd.add_callable(lambda: ops.pair_concat_bwd(self.dconcat, self.tidx, self.vidx, P, W, F, enc.dseq, enc.dvis), sm)
+        bwd.add_callable(lambda: ops.postype_bwd(self.dpostype, W, S, G(n["pos"]), G(n["typ"])), sm)
+
+
+class PoolerSim:
+    """CrossPooler + similarity_dense on a CrossRun over all (text, video) pairs (modeling.py:369-373)."""
+
+    def __init__(self, cx, run, Bt, Bv, loss_kind):
+        self.cx, self.run, self.Bt, self.Bv = cx, run, Bt, Bv
+        e, ct = cx.e, cx.ct
+        P = run.P
+        self.pre, self.pooled, self.sim, self.dsim = e(P, H), e(P, H), e(P), e(P)
+        self.dpooled, self.dpre = e(P, H), e(P, H, dtype=ct)
+        self.lossfn = SimLoss(cx, loss_kind, Bt) if loss_kind else None
+        self.loss = self.lossfn.loss if self.lossfn else None
+
+    N = dict(pw="cross.pooler.dense.weight", pb="cross.pooler.dense.bias", sw="similarity_dense.weight", sb="similarity_dense.bias")
+
+    def build_forward(self, fwd):
+        cx, run, n, fl, dt = self.cx, self.run, self.N, self.cx.fl, self.cx.dt
+        P, S = run.P, run.S
+        x0 = run.out16            # first token of every sequence: row stride S*H
+        fwd.add("univl_gemm", _gemm_desc(dt, x0, S * H, fl.wop(n["pw"]), H, P, H, H, out32=self.pre, ldc=H, bias=fl.w32(n["pb"])), run.sm)
+        fwd.add_callable(lambda: ops.tanh_fwd(self.pre, self.pooled), run.sm)
+        fwd.add_callable(lambda: ops.simdense_fwd(self.pooled, fl.w32(n["sw"]), fl.w32(n["sb"]), self.sim), run.sm)
+        if self.lossfn:
+            self.lossfn.build(fwd, self.sim.view(self.Bt, self.Bv), self.dsim.view(self.Bt, self.Bv))
+
+    def build_backward(self, bwd, gs, gout):
+        cx, run, n, fl, dt = self.cx, self.run, self.N, self.cx.fl, self.cx.dt
+        P, S, G = run.P, run.S, fl.g
+        bwd.add_callable(lambda: ops.scale_by_device_scalar(self.dsim, gout), run.sm)
+        bwd.add_callable(lambda: ops.simdense_bwd(self.dsim, self.pooled, fl.w32(n["sw"]), self.dpooled, G(n["sw"]), G(n["sb"])), run.sm)
+        bwd.add_callable(lambda: ops.tanh_bwd(self.dpooled, self.pooled, self.dpre), run.sm)
+        bwd.add("univl_gemm", _gemm_desc(dt, self.dpre, H, run.out16, S * H, H, H, P, trans_a=1, trans_b=1, out32=G(n["pw"]), ldc=H,
+                                         accumulate=gs.acc(n["pw"]), dbias=G(n["pb"])), run.sm)
+        bwd.add("univl_gemm", _gemm_desc(dt, self.dpre, H, fl.wop(n["pw"]), H, P, H, H, trans_b=1, out32=run.dcross, ldc=S * H,
+                                         accumulate=True), run.sm)
+
+
+class VocabHead:
+    """BertLMPredictionHead tied to BERT's word table + CrossEntropyLoss(ignore_index=-1)
+    (module_bert.py:299-330 / module_decoder.py:156-183; modeling.py:252-254, 273-276)."""
+
+    def __init__(self, cx, prefix, T, stream=0):
+        self.cx, self.prefix, self.T, self.sm = cx, prefix, T, stream
+        e, ct, bf = cx.e, cx.ct, cx.bf
+        V = cx.model.bert_config.vocab_size
+        self.V, self.ldv = V, (V + 7) // 8 * 8
+        self.u, self.hy, self.hst = e(T, H, dtype=ct), e(T, H), e(T, 2)
+        self.h32 = e(T, H)
+        self.h16 = e(T, H, dtype=ct) if bf else self.h32
+        self.logits = e(T, self.ldv)
+        self.dlogits = e(T, self.ldv, dtype=ct)
+        self.labels = e(T, dtype=torch.int64)
+        self.loss, self.scratch = e(1), e(2)
+        self.dh, self.dg, self.du = e(T, H), e(T, H), e(T, H, dtype=ct)
+
+    def names(self):
+        p = self.prefix
+        return dict(tw=p + ".transform.dense.weight", tb=p + ".transform.dense.bias", lg=p + ".transform.LayerNorm.weight",
+                    lb=p + ".transform.LayerNorm.bias", bias=p + ".bias", emb="bert.embeddings.word_embeddings.weight")
+
+    def build_forward(self, fwd, x16, with_loss=True):
+        cx, fl, dt, n, T, sm = self.cx, self.cx.fl, self.cx.dt, self.names(), self.T, self.sm
+        W32 = fl.w32
+        fwd.add("univl_gemm", _gemm_desc(dt, x16, H, fl.wop(n["tw"]), H, T, H, H, out32=self.hy, ldc=H, bias=W32(n["tb"]),
+                                         aux=self.u, ldaux=H, gelu="fwd"), sm)
+        fwd.add("univl_layernorm_fwd", ops.layernorm_desc(dt, T, H, x=self.hy, gamma=W32(n["lg"]), beta=W32(n["lb"]), y=self.hy,
+                                                          stats=self.hst, out32=self.h32, out16=self.h16 if cx.bf else None), sm)
+        fwd.add("univl_gemm", _gemm_desc(dt, self.h16, H, fl.wop(n["emb"]), H, T, self.V, H, out32=self.logits, ldc=self.ldv,
+                                         bias=W32(n["bias"])), sm)
+        if with_loss:
+            fwd.add_callable(lambda: ops.ce_loss(self.logits, self.labels, self.V, self.scratch, self.loss, self.dlogits), sm)
+
+    def build_backward(self, bwd, gs, gout, x16, dx32, accumulate_dx):
+        """dx32 receives the gradient wrt the head input (accumulated if accumulate_dx)."""
+        cx, fl, dt, n, T, sm = self.cx, self.cx.fl, self.cx.dt, self.names(), self.T, self.sm
+        W32, G = fl.w32, fl.g
+        bwd.add_callable(lambda: ops.scale_ct(self.dlogits, gout), sm)
+        bwd.add("univl_gemm", _gemm_desc(dt, self.dlogits, self.ldv, fl.wop(n["emb"]), H, T, H, self.V, trans_b=1, out32=self.dh, ldc=H), sm)
+        bwd.add("univl_gemm", _gemm_desc(dt, self.dlogits, self.ldv, self.h16, H, self.V, H, T, trans_a=1, trans_b=1, out32=G(n["emb"]),
+                                         ldc=H, accumulate=True, dbias=G(n["bias"])), sm)
+        bwd.add("univl_layernorm_bwd", ops.layernorm_desc(dt, T, H, gamma=W32(n["lg"]), y=self.hy, stats=self.hst, dout=self.dh,
+                                                          dx32=self.dg, dgamma=G(n["lg"]), dbeta=G(n["lb"])), sm)
+        bwd.add_callable(lambda: ops.gelu_bwd(self.dg, self.u, self.du), sm)
+        bwd.add("univl_gemm", _gemm_desc(dt, self.du, H, x16, H, H, H, T, trans_a=1, trans_b=1, out32=G(n["tw"]), ldc=H,
+                                         accumulate=gs.acc(n["tw"]), dbias=G(n["tb"])), sm)
+        bwd.add("univl_gemm", _gemm_desc(dt, self.du, H, fl.wop(n["tw"]), H, T, H, H, trans_b=1, out32=dx32, ldc=H,
+                                         accumulate=accumulate_dx), sm)
+
+
+class RowFeatures:
+    """Stand-in for an EncoderPass when the caller supplies sequence_output / visual_output tensors
+    (decoder_caption, get_similarity_logits on cached features: main_task_caption.py:450, main_task_retrieval.py:376)."""
+
+    def __init__(self, cx, Bt, Bv, W, F):
+        e = cx.e
+        self.B, self.W, self.F = Bt, W, F
+        self.seq_out, self.vis_out = e(Bt * W, H), e(Bv * F, H)
+        self.amask, self.vmask = e(Bt, W, dtype=torch.int64), e(Bv, F, dtype=torch.int64)
+        self.dseq, self.dvis = None, None
+
+    def load(self, seq, vis, amask, vmask):
+        self.seq_out.copy_(seq.reshape(self.seq_out.shape), non_blocking=True)
+        self.vis_out.copy_(vis.reshape(self.vis_out.shape), non_blocking=True)
+        self.amask.copy_(amask.reshape(self.amask.shape), non_blocking=True)
+        self.vmask.copy_(vmask.reshape(self.vmask.shape), non_blocking=True)
+
+
+class DecoderRun:
+    """DecoderModel.forward (module_decoder.py:372-406) on top of a row-wise CrossRun + the caption CE (modeling.py:246-254)."""
+
+    def __init__(self, cx, run, Wd, with_loss=True):
+        self.cx, self.run, self.Wd = cx, run, Wd
+        B = run.P
+        self.B, self.T = B, B * Wd
+        e, ct, bf, fl = cx.e, cx.ct, cx.bf, cx.fl
+        T = self.T
+        self.cap_ids, self.dmask = e(B, Wd, dtype=torch.int64), e(B, Wd, dtype=torch.int64)
+        self.ey, self.est, self.e0_32 = e(T, H), e(T, 2), e(T, H)
+        self.e0_16 = e(T, H, dtype=ct) if bf else self.e0_32
+        L = cx.model.decoder_config.num_decoder_layers
+        self.stack = DecoderStack(fl, L, B, Wd, run.S, self.dmask, run.cmask, cx.p, cx.seed_dev, cx.sites, stream=run.sm)
+        self.head = VocabHead(cx, "decoder.classifier.cls.predictions", T, stream=run.sm)
+        self.off = cx.sites.next()
+        self.dout = e(T, H)
+        self.with_loss = with_loss
+        self.loss = self.head.loss
+
+    N = dict(bw="bert.embeddings.word_embeddings.weight", bp="bert.embeddings.position_embeddings.weight",
+             lg="decoder.embeddings.LayerNorm.weight", lb="decoder.embeddings.LayerNorm.bias")
+
+    def load(self, input_caption_ids, decoder_mask, output_caption_ids=None):
+        self.cap_ids.copy_(input_caption_ids.reshape(self.B, self.Wd), non_blocking=True)
+        self.dmask.copy_(decoder_mask.reshape(self.B, self.Wd), non_blocking=True)
+        if output_caption_ids is not None:
+            self.head.labels.copy_(output_caption_ids.reshape(-1), non_blocking=True)
+
+    def build_forward(self, fwd):
+        cx, n, fl, dt, sm = self.cx, self.N, self.cx.fl, self.cx.dt, self.run.sm
+        W32 = fl.w32
+        fwd.add("univl_embed_text_fwd", ops.embed_text_desc(
+            dt, self.B, self.Wd, self.cap_ids, W32(n["bw"]), W32(n["bp"]), W32(n["lg"]), W32(n["lb"]), y=self.ey, stats=self.est,
+            out32=self.e0_32, out16=self.e0_16 if cx.bf else None, p_post=cx.p, seed=cx.seed, off_post=self.off,
+            seed_dev=cx.seed_dev), sm)
+        self.stack.build_forward(fwd, self.e0_32, self.e0_16, self.run.out16, cx.training)
+        self.head.build_forward(fwd, self.stack.output()[1], with_loss=self.with_loss)
+
+    def build_backward(self, bwd, gs, gout):
+        cx, n, fl, dt, sm = self.cx, self.N, self.cx.fl, self.cx.dt, self.run.sm
+        W32, G = fl.w32, fl.g
+        self.head.build_backward(bwd, gs, gout, self.stack.output()[1], self.dout, accumulate_dx=False)
+        dx0 = self.stack.build_backward(bwd, self.dout, self.e0_32, self.e0_16, self.run.out16, self.run.dcross, gs, cx.training)
+        bwd.add("univl_embed_text_bwd", ops.embed_text_desc(
+            dt, self.B, self.Wd, self.cap_ids, W32(n["bw"]), W32(n["bp"]), W32(n["lg"]), W32(n["lb"]), y=self.ey, stats=self.est,
+            p_post=cx.p, seed=cx.seed, off_post=self.off, seed_dev=cx.seed_dev, dout=dx0, dword=G(n["bw"]), dpos=G(n["bp"]),
+            dgamma=G(n["lg"]), dbeta=G(n["lb"])), sm)
+
+
+class PretrainHeads:
+    """MLM + MFM heads on a row-wise CrossRun over the MASKED inputs (modeling.py:224-231, 273-297)."""
+
+    def __init__(self, cx, run, enc_clean):
+        self.cx, self.run, self.clean = cx, run, enc_clean
+        e, ct, bf = cx.e, cx.ct, cx.bf
+        B, W, F = run.P, run.W, run.F
+        self.B, self.W, self.F = B, W, F
+        Tt, Tv, D = B * W, B * F, cx.tc.video_dim
+        self.Tt, self.Tv, self.D = Tt, Tv, D
+        self.arange = torch.arange(B, dtype=torch.int32, device=cx.dev)
+        self.tpart, self.vpart = e(Tt, H), e(Tv, H)
+        self.tpart16 = e(Tt, H, dtype=ct) if bf else self.tpart
+        self.vpart16 = e(Tv, H, dtype=ct) if bf else self.vpart
+        self.dtpart, self.dvpart = e(Tt, H), e(Tv, H)
+        self.mlm = VocabHead(cx, "cls.predictions", Tt, stream=run.sm)
+        # visual head
+        self.u, self.hy, self.hst, self.h32 = e(Tv, H, dtype=ct), e(Tv, H), e(Tv, 2), e(Tv, H)
+        self.h16 = e(Tv, H, dtype=ct) if bf else self.h32
+        self.scores = e(Tv, D, dtype=ct)
+        self.ldl = (Tv + 7) // 8 * 8
+        self.logits = e(Tv, self.ldl)
+        self.dlogits_ct = e(Tv, self.ldl, dtype=ct) if bf else self.logits
+        self.dscores = e(Tv, D, dtype=ct)
+        self.dh, self.dg, self.du = e(Tv, H), e(Tv, H), e(Tv, H, dtype=ct)
+        self.vlabels = e(Tv, dtype=torch.int64)
+        self.nce_loss, self.scratch = e(1), e(2)
+
+    VN = dict(tw="cls_visual.predictions.transform.dense.weight", tb="cls_visual.predictions.transform.dense.bias",
+              lg="cls_visual.predictions.transform.LayerNorm.weight", lb="cls_visual.predictions.transform.LayerNorm.bias",
+              bias="cls_visual.predictions.bias", vw="visual.embeddings.word_embeddings.weight")
+
+    def load(self, pairs_token_labels, video_labels_index):
+        self.mlm.labels.copy_(pairs_token_labels.reshape(-1), non_blocking=True)
+        self.vlabels.copy_(video_labels_index.reshape(-1), non_blocking=True)
+
+    def build_forward(self, fwd):
+        cx, run, fl, dt, n, sm = self.cx, self.run, self.cx.fl, self.cx.dt, self.VN, self.run.sm
+        W32 = fl.w32
+        B, W, F, Tv, D = self.B, self.W, self.F, self.Tv, self.D
+        # torch.split(cross_output, [W, F], dim=1)  (modeling.py:225)
+        fwd.add_callable(self.tpart.zero_, sm)
+        fwd.add_callable(self.vpart.zero_, sm)
+        fwd.add_callable(lambda: ops.pair_concat_bwd(run.out32, self.arange, self.arange, B, W, F, self.tpart, self.vpart), sm)
+        if cx.bf:
+            fwd.add_callable(lambda: ops.cast_bf16(self.tpart, self.tpart16), sm)
+            fwd.add_callable(lambda: ops.cast_bf16(self.vpart, self.vpart16), sm)
+        self.mlm.build_forward(fwd, self.tpart16)
+        # VisualLMPredictionHead (module_visual.py:298-311): LN(gelu(dense(x))) . W_vis[768,1024] + bias
+        fwd.add("univl_gemm", _gemm_desc(dt, self.vpart16, H, fl.wop(n["tw"]), H, Tv, H, H, out32=self.hy, ldc=H, bias=W32(n["tb"]),
+                                         aux=self.u, ldaux=H, gelu="fwd"), sm)
+        fwd.add("univl_layernorm_fwd", ops.layernorm_desc(dt, Tv, H, x=self.hy, gamma=W32(n["lg"]), beta=W32(n["lb"]), y=self.hy,
+                                                          stats=self.hst, out32=self.h32, out16=self.h16 if cx.bf else None), sm)
+        fwd.add("univl_gemm", _gemm_desc(dt, self.h16, H, fl.wop(n["vw"]), D, Tv, D, H, trans_b=1, out16=self.scores, ldc=D,
+                                         bias=W32(n["bias"])), sm)
+        # logits_matrix = afm_scores . video^T against all normalised CLEAN frames of the batch (modeling.py:282-285)
+        fwd.add("univl_gemm", _gemm_desc(dt, self.scores, D, self.clean.vn_op, D, Tv, Tv, D, out32=self.logits, ldc=self.ldl), sm)
+        fwd.add_callable(lambda: ops.mfm_nce_loss(self.logits[:, :Tv], self.clean.vmask, self.vlabels, self.scratch, self.nce_loss,
+                                                  self.logits[:, :Tv]), sm)
+        if cx.bf:
+            fwd.add_callable(lambda: ops.cast_bf16(self.logits, self.dlogits_ct), sm)
+
+    def build_backward(self, bwd, gs, gout):
+        cx, run, fl, dt, n, sm = self.cx, self.run, self.cx.fl, self.cx.dt, self.VN, self.run.sm
+        W32, G = fl.w32, fl.g
+        B, W, F, Tv, D, ldl = self.B, self.W, self.F, self.Tv, self.D, self.ldl
+        dl = self.dlogits_ct
+        bwd.add_callable(lambda: ops.scale_ct(dl, gout), sm)
+        # d scores = dlogits . video ;  d video += dlogits^T . scores
+        bwd.add("univl_gemm", _gemm_desc(dt, dl, ldl, self.clean.vn_op, D, Tv, D, Tv, trans_b=1, out16=self.dscores, ldc=D), sm)
+        bwd.add("univl_gemm", _gemm_desc(dt, dl, ldl, self.scores, D, Tv, D, Tv, trans_a=1, trans_b=1, out32=self.clean.dvnorm, ldc=D,
+                                         accumulate=True), sm)
+        bwd.add_callable(lambda: ops.colsum(self.dscores, G(n["bias"])), sm)
+        # scores = h . W_vis: dh = dscores . W_vis^T ; dW_vis += h^T . dscores
+        bwd.add("univl_gemm", _gemm_desc(dt, self.dscores, D, fl.wop(n["vw"]), D, Tv, H, D, out32=self.dh, ldc=H), sm)
+        bwd.add("univl_gemm", _gemm_desc(dt, self.h16, H, self.dscores, D, H, D, Tv, trans_a=1, trans_b=1, out32=G(n["vw"]), ldc=D,
+                                         accumulate=gs.acc(n["vw"])), sm)
+        bwd.add("univl_layernorm_bwd", ops.layernorm_desc(dt, Tv, H, gamma=W32(n["lg"]), y=self.hy, stats=self.hst, dout=self.dh,
+                                                          dx32=self.dg, dgamma=G(n["lg"]), dbeta=G(n["lb"])), sm)
+        bwd.add_callable(lambda: ops.gelu_bwd(self.dg, self.u, self.du), sm)
+        bwd.add("univl_gemm", _gemm_desc(dt, self.du, H, self.vpart16, H, H, H, Tv, trans_a=1, trans_b=1, out32=G(n["tw"]), ldc=H,
+                                         accumulate=gs.acc(n["tw"]), dbias=G(n["tb"])), sm)
+        bwd.add("univl_gemm", _gemm_desc(dt, self.du, H, fl.wop(n["tw"]), H, Tv, H, H, trans_b=1, out32=self.dvpart, ldc=H), sm)
+        self.mlm.build_backward(bwd, gs, gout, self.tpart16, self.dtpart, accumulate_dx=False)
+        # d cross_output = cat(d text part, d video part): written in full (this run has no other consumer)
+        bwd.add_callable(lambda: ops.pair_concat_fwd(self.dtpart, self.dvpart, run.enc.amask, run.enc.vmask, self.arange, self.arange,
+                                                     B, W, F, run.dcross, None), sm)
+
+
+# ------------------------------------------------------------------------------------------------ step assembly
+class Step:
+    """fwd / bwd plans + the buffers UniVL.forward fills for one (rows, max_words, max_frames, training) signature."""
+
+    def __init__(self, cx):
+        self.cx = cx
+        self.loss, self.gout = cx.e(1), cx.e(1)
+        self.fwd = Plan()
+        self.bwd = {}
+        self.loss_terms = []
+
+    def finish_forward(self):
+        terms = self.loss_terms
+        if len(terms) == 1:
+            self.fwd.add_callable(lambda: self.loss.copy_(terms[0]))
+        else:
+            def add():
+                torch.add(terms[0], terms[1], out=self.loss)
+                for t in terms[2:]:
+                    self.loss.add_(t)
+            self.fwd.add_callable(add)
+
+    def backward_plan(self, fresh):
+        if fresh not in self.bwd:
+            self.bwd[fresh] = self._build_bwd(fresh)
+        return self.bwd[fresh]
+
+
+def _ddp_hook(cx, fl, model):
+    red = cx.red
+    if red is None:
+        return None, None
+    from .parallel import layer_buckets
+    buckets = layer_buckets(fl, model.used_parameter_names())
+
+    def hook(plan, prefix, l, stream):
+        key = (prefix, l)
+        if key in buckets["layers"]:
+            s0, e0 = buckets["layers"][key]
+            plan.add_callable(lambda: red.reduce_slice(s0, e0), stream=stream)
+    return hook, buckets
+
+
+def build_step(model, kind, B, W, F, training):
+    cx = Ctx(model, training)
+    fl, tc = cx.fl, cx.tc
+    st = Step(cx)
+    st.kind, st.B, st.W, st.F = kind, B, W, F
+    fwd = st.fwd
+    if cx.p > 0:
+        fwd.add_callable(lambda: ops.bump_counter(cx.seed_dev))
+    st.enc = enc = EncoderPass(cx, B, W, F)
+    enc.build_forward(fwd)
+    st.fwd_encoders_len = len(fwd)
+    stage_two = bool(model._stage_two)
+    loss_kind = "crossen" if stage_two else ("milnce" if tc.use_mil else "maxmargin")
+    pre_kind = "milnce" if tc.use_mil else "maxmargin"          # _pretrain_sim_loss_fct (modeling.py:179-184)
+    st.enc_m = st.joint = st.run_pairs = st.pooler = st.run_rows = st.decoder = st.heads = st.run_heads = None
+    pairs = [(i, j) for i in range(B) for j in range(B)]
+    rows = list(range(B))
+    if kind == "joint":
+        st.joint = JointSim(cx, enc, loss_kind)
+        st.joint.build_forward(fwd)
+        st.loss_terms.append(st.joint.loss)
+    elif kind == "align":
+        st.run_pairs = CrossRun(cx, enc, [a for a, _ in pairs], [b for _, b in pairs])
+        st.run_pairs.build_forward(fwd)
+        st.pooler = PoolerSim(cx, st.run_pairs, B, B, loss_kind)
+        st.pooler.build_forward(fwd)
+        st.loss_terms.append(st.pooler.loss)
+    elif kind == "caption":
+        st.run_rows = CrossRun(cx, enc, rows, rows)
+        st.run_rows.build_forward(fwd)
+        st.decoder = DecoderRun(cx, st.run_rows, W)
+        st.decoder.build_forward(fwd)
+        st.loss_terms.append(st.decoder.loss)
+    elif kind == "pretrain":
+        st.enc_m = enc_m = EncoderPass(cx, B, W, F)            # masked text / masked video pass (modeling.py:221)
+        enc_m.build_forward(fwd)
+        st.run_heads = CrossRun(cx, enc_m, rows, rows)
+        st.run_heads.build_forward(fwd)
+        st.heads = PretrainHeads(cx, st.run_heads, enc)
+        st.heads.build_forward(fwd)
+        st.loss_terms += [st.heads.mlm.loss, st.heads.nce_loss]
+        st.joint = JointSim(cx, enc, pre_kind)                  # _pretrain_joint on the CLEAN outputs (:233-236)
+        st.joint.build_forward(fwd)
+        st.loss_terms.append(st.joint.loss)
+        st.run_rows = CrossRun(cx, enc_m, rows, rows)            # _get_decoder_score re-runs the cross encoder (:404)
+        st.run_rows.build_forward(fwd)
+        st.decoder = DecoderRun(cx, st.run_rows, W)
+        st.decoder.build_forward(fwd)
+        st.loss_terms.append(st.decoder.loss)
+        st.run_pairs = CrossRun(cx, enc_m, [a for a, _ in pairs], [b for _, b in pairs])   # alignment (:258-267)
+        st.run_pairs.build_forward(fwd)
+        st.pooler = PoolerSim(cx, st.run_pairs, B, B, loss_kind)
+        st.pooler.build_forward(fwd)
+        st.loss_terms.append(st.pooler.loss)
+    elif kind == "features":
+        pass                                   # encoders only (get_sequence_visual_output on a stage-two model)
+    else:
+        raise ValueError(kind)
+    if st.loss_terms:
+        st.finish_forward()
+
+    def build_bwd(fresh):
+        bwd = Plan()
+        gs = GradState(fl, fresh)
+        hook, buckets = _ddp_hook(cx, fl, model)
+        if fresh:
+            bwd.add_callable(fl.g32[:fl.v_end].zero_)
+        enc.zero_grads(bwd)
+        if st.enc_m is not None:
+            st.enc_m.zero_grads(bwd)
+        for r in (st.run_pairs, st.run_rows):
+            if r is not None:
+                r.zero_grads(bwd)
+        if st.run_heads is not None:
+            bwd.add_callable(st.run_heads.dpostype.zero_)
+        g = st.gout
+        if st.pooler is not None:
+            st.pooler.build_backward(bwd, gs, g)
+            st.run_pairs.build_backward(bwd, gs, hook)
+        if st.decoder is not None:
+            st.decoder.build_backward(bwd, gs, g)
+            st.run_rows.build_backward(bwd, gs, hook)
+        if st.heads is not None:
+            st.heads.build_backward(bwd, gs, g)
+            st.run_heads.build_backward(bwd, gs, hook)
+        if st.joint is not None:
+            st.joint.build_backward(bwd, g)
+        if st.enc_m is not None:
+            st.enc_m.build_backward(bwd, gs, hook)
+        enc.build_backward(bwd, gs, hook)
+        if cx.red is not None:
+            done = set(buckets["layers"].values())
+            for (s0, e0) in buckets["tail"]:
+                bwd.add_callable(lambda s0=s0, e0=e0: cx.red.reduce_slice(s0, e0))
+            bwd.add_callable(cx.red.join)
+        return bwd
+
+    st._build_bwd = build_bwd
+    return st
