@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 WHAT="${1:-all}"
 echo "== $(date) host: $(nproc) cpus; $(rocminfo 2>/dev/null | grep -m1 'Marketing Name.*MI' || true)" | tee gpurun_out/session.log
 if [[ "$WHAT" == all || "$WHAT" == tests ]]; then
-  timeout 1500 python -m pytest tests -m gpu -q --no-header -rfE -p no:cacheprovider ${PYTEST_ARGS:-} > gpurun_out/pytest_gpu.log 2>&1
+  timeout 1500 python -m pytest tests -m gpu -q --no-header -rfE -p no:cacheprovider ${PYTEST_K:+-k "$PYTEST_K"} > gpurun_out/pytest_gpu.log 2>&1
   echo "pytest exit $?" | tee -a gpurun_out/session.log
   tail -n 60 gpurun_out/pytest_gpu.log
 fi

@@ -372,3 +372,119 @@ def test_maxmargin_weighted():
     ops.maxmargin_loss(sim.to(DEV), 0.1, w.to(DEV), loss, ds)
     assert abs(float(loss) - float(ref)) < 1e-5
     assert rel_err(ds, s.grad) < 1e-5
+
+
+# ------------------------------------------------------------ cross encoder / classifier / pretraining helpers
+def test_pair_concat_and_postype():
+    """torch.cat((seq, vis), 1) over (text row, video row) pairs + concat_mask (modeling.py:315-325, 352-366) and the
+    position + token-type table of CrossEmbeddings (module_cross.py:123-138); backward scatter-adds."""
+    Bt, Bv, W, F = 3, 2, 5, 7
+    seq, vis = gen(Bt, W, 768, seed=1), gen(Bv, F, 768, seed=2)
+    am = (torch.arange(W)[None] < torch.tensor([[5], [2], [3]])).long()
+    vm = (torch.arange(F)[None] < torch.tensor([[7], [1]])).long()
+    pairs = [(i, j) for i in range(Bt) for j in range(Bv)]
+    tidx = torch.tensor([a for a, _ in pairs], dtype=torch.int32, device=DEV)
+    vidx = torch.tensor([b for _, b in pairs], dtype=torch.int32, device=DEV)
+    P, S = len(pairs), W + F
+    out = torch.zeros(P * S, 768, device=DEV); om = torch.zeros(P, S, dtype=torch.int64, device=DEV)
+    ops.pair_concat_fwd(seq.to(DEV), vis.to(DEV), am.to(DEV), vm.to(DEV), tidx, vidx, P, W, F, out, om)
+    ref = torch.stack([torch.cat((seq[a], vis[b]), 0) for a, b in pairs])
+    refm = torch.stack([torch.cat((am[a], vm[b]), 0) for a, b in pairs])
+    assert torch.equal(out.view(P, S, 768).cpu(), ref) and torch.equal(om.cpu(), refm)
+    d = gen(P, S, 768, seed=3)
+    dseq, dvis = torch.zeros(Bt * W, 768, device=DEV), torch.zeros(Bv * F, 768, device=DEV)
+    ops.pair_concat_bwd(d.to(DEV).view(P * S, 768), tidx, vidx, P, W, F, dseq, dvis)
+    rs = torch.zeros(Bt, W, 768, dtype=torch.float64); rv = torch.zeros(Bv, F, 768, dtype=torch.float64)
+    for k, (a, b) in enumerate(pairs):
+        rs[a] += d[k, :W].double(); rv[b] += d[k, W:].double()
+    assert rel_err(dseq.view(Bt, W, 768), rs) < 1e-6 and rel_err(dvis.view(Bv, F, 768), rv) < 1e-6
+    pos, typ = gen(32, 768, seed=4), gen(2, 768, seed=5)
+    tab = torch.zeros(S, 768, device=DEV)
+    ops.postype_fwd(pos.to(DEV), typ.to(DEV), W, S, tab)
+    reft = pos[:S] + typ[(torch.arange(S) >= W).long()]
+    assert torch.equal(tab.cpu(), reft)
+    dpos, dtyp = torch.zeros(32, 768, device=DEV), torch.zeros(2, 768, device=DEV)
+    dt_ = gen(S, 768, seed=6)
+    ops.postype_bwd(dt_.to(DEV), W, S, dpos, dtyp)
+    assert rel_err(dpos[:S], dt_) < 1e-6 and float(dpos[S:].abs().max()) == 0.0
+    assert rel_err(dtyp, torch.stack([dt_[:W].sum(0), dt_[W:].sum(0)])) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_tanh_gelu_simdense_colsum(dtype):
+    x = gen(37, 768, seed=1)
+    y = torch.empty(37, 768, device=DEV)
+    ops.tanh_fwd(x.to(DEV), y)
+    assert rel_err(y, torch.tanh(x.double())) < 1e-6
+    dy = gen(37, 768, seed=2)
+    dx = torch.empty(37, 768, device=DEV, dtype=dtype)
+    ops.tanh_bwd(dy.to(DEV), y, dx)
+    assert rel_err(dx.float(), dy.double() * (1 - torch.tanh(x.double()) ** 2)) < tol(dtype)
+    u = gen(37, 768, seed=3).to(DEV, dtype)
+    du = torch.empty(37, 768, device=DEV, dtype=dtype)
+    ops.gelu_bwd(dy.to(DEV), u, du)
+    uu = u.double().cpu().requires_grad_(True)
+    O.gelu(uu).backward(dy.double())
+    assert rel_err(du.float(), uu.grad) < tol(dtype)
+    w, b = gen(768, seed=4, scale=0.05), gen(1, seed=5)
+    s = torch.empty(37, device=DEV)
+    ops.simdense_fwd(x.to(DEV), w.to(DEV), b.to(DEV), s)
+    assert rel_err(s, x.double() @ w.double() + b.double()) < 1e-5
+    ds = gen(37, seed=6)
+    dxs = torch.empty(37, 768, device=DEV); dw = torch.zeros(768, device=DEV); db = torch.zeros(1, device=DEV)
+    ops.simdense_bwd(ds.to(DEV), x.to(DEV), w.to(DEV), dxs, dw, db)
+    assert rel_err(dxs, ds.double()[:, None] * w.double()[None]) < 1e-6
+    assert rel_err(dw, ds.double() @ x.double()) < 1e-5 and abs(float(db) - float(ds.sum())) < 1e-4
+    m = gen(100, 1024, seed=7).to(DEV, dtype)
+    cs = torch.ones(1024, device=DEV)
+    ops.colsum(m, cs)
+    assert rel_err(cs, m.double().cpu().sum(0) + 1) < 1e-5
+    z = gen(50, 64, seed=8).to(DEV, dtype)
+    ref = z.double().cpu() * 0.25
+    ops.scale_ct(z, torch.tensor([0.25], device=DEV))
+    assert rel_err(z.float(), ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ce_loss_with_ignore_index(dtype):
+    """CrossEntropyLoss(ignore_index=-1) (modeling.py:168): padding label 0 is NOT ignored, only -1 is."""
+    T, V = 50, 1000
+    ld = 1008
+    logits = torch.zeros(T, ld); logits[:, :V] = gen(T, V, seed=1, scale=3.0)
+    g = torch.Generator().manual_seed(2)
+    labels = torch.randint(0, V, (T,), generator=g)
+    labels[::5] = -1
+    labels[1] = 0
+    ld_ = torch.zeros(T, ld, device=DEV, dtype=dtype)
+    loss = torch.zeros(1, device=DEV); scr = torch.zeros(2, device=DEV)
+    ops.ce_loss(logits.to(DEV), labels.to(DEV), V, scr, loss, ld_)
+    lr = logits[:, :V].double().requires_grad_(True)
+    ref = O.cross_entropy_ignore(lr, labels)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * float(ref)
+    assert rel_err(ld_[:, :V].float(), lr.grad) < tol(dtype)
+    assert float(ld_[:, V:].abs().max()) == 0.0 and float(ld_[::5].abs().max()) == 0.0
+    labels[:] = -1                                        # nothing to average over: NaN, like torch
+    ops.ce_loss(logits.to(DEV), labels.to(DEV), V, scr, loss, ld_)
+    assert math.isnan(float(loss))
+
+
+def test_mfm_nce_loss():
+    """_calculate_mfm_loss tail (modeling.py:285-297): pair mask * -1e8, diagonal log-softmax, masked-position mean."""
+    B, F = 3, 8
+    n = B * F
+    logits = gen(n, n, seed=1, scale=2.0)
+    vmask = (torch.arange(F)[None] < torch.tensor([[8], [3], [5]])).long().reshape(-1)
+    lab = torch.full((n,), -1, dtype=torch.int64)
+    lab[[1, 4, 9, 17, 20]] = torch.tensor([1, 4, 1, 1, 4])
+    x = logits.double().requires_grad_(True)
+    vm = vmask.double()
+    masked = x + (1.0 - vm.view(-1, 1) @ vm.view(1, -1)) * -1e8
+    nce = -torch.diag(torch.log_softmax(masked, dim=-1))
+    ref = nce[lab != -1].mean()
+    ref.backward()
+    buf = torch.zeros(n, n, device=DEV); buf.copy_(logits)
+    loss = torch.zeros(1, device=DEV); scr = torch.zeros(2, device=DEV)
+    ops.mfm_nce_loss(buf, vmask.to(DEV), lab.to(DEV), scr, loss, buf)          # gradient written in place
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+    assert rel_err(buf, x.grad) < 1e-5
