@@ -14,6 +14,7 @@
 // Epilogue (all optional, in this order): *alpha, +bias[n], +residual[m,n] (fp32), erf-GELU forward (saving the
 // pre-activation), *gelu'(saved pre-activation), +C_old (accumulate), store fp32 and/or T.  A wgrad launch can
 // also emit the bias gradient (row sums of A_op over the contraction) from the tiles it already staged.
+#include <stdlib.h>
 #include "common.h"
 #include "univl_hip.h"
 
@@ -40,51 +41,74 @@ template <typename T, bool TR, int ROWS, int BK> struct Tile {
     static constexpr int PER_THREAD = CHUNKS / 256;
     static_assert(CHUNKS % 256 == 0, "tile must split evenly over 256 threads");
 
-    // global -> registers.  `row0` first tile row, `k0` first contraction index, `rows_total`/`k_end` bounds.
-    // The load is UNCONDITIONAL (out-of-range pieces read a clamped, valid address): a branch around a load makes
-    // hipcc wait vmcnt(0) right behind it and serialises every load of the kernel.  Masking happens in store().
-    __device__ static __forceinline__ void load(uint4 (&r)[PER_THREAD], const T* base, long ld, int row0, int k0,
-                                                int rows_total, int k_end, int tid) {
+    // Per-thread source pointers of its 16-byte pieces.  Everything that does not change along K (row clamp, piece
+    // coordinates) is folded into the pointer ONCE; a K step is then `load; pointer += step` -- the inner loop of
+    // a small-M GEMM runs one wave per SIMD and is bound by instruction issue, not by MFMA or HBM.
+
+    __device__ static __forceinline__ void coords(int c, int tid, int& row, int& kk) {
+        const int ch = tid + 256 * c;
+        if (TR) { kk = ch / (ROWS / EPC); row = (ch % (ROWS / EPC)) * EPC; }
+        else    { row = ch / (BK / EPC);  kk = (ch % (BK / EPC)) * EPC; }
+    }
+    // Rows beyond rows_total are CLAMPED, not masked: they only feed accumulator rows/columns the epilogue never
+    // stores.  (Only the contraction direction needs zero fill, and only in the last, partial K tile.)
+    __device__ static __forceinline__ void init(const T* (&P)[PER_THREAD], const T* base, long ld, int row0, int k0, int rows_total, int tid) {
         const int rmax = TR ? ((rows_total - 1) / EPC) * EPC : rows_total - 1;
-        const int kmax = TR ? k_end - 1 : ((k_end - 1) / EPC) * EPC;
 #pragma unroll
         for (int c = 0; c < PER_THREAD; ++c) {
-            const int ch = tid + 256 * c;
             int row, kk;
-            if (TR) { kk = ch / (ROWS / EPC); row = (ch % (ROWS / EPC)) * EPC; }
-            else    { row = ch / (BK / EPC);  kk = (ch % (BK / EPC)) * EPC; }
-            const int gr = min(row0 + row, rmax), gk = min(k0 + kk, kmax);
-            const T* p = TR ? (base + (long)gk * ld + gr) : (base + (long)gr * ld + gk);
-            r[c] = *reinterpret_cast<const uint4*>(p);
+            coords(c, tid, row, kk);
+            const int gr = min(row0 + row, rmax);
+            P[c] = TR ? (base + (long)(k0 + kk) * ld + gr) : (base + (long)gr * ld + (k0 + kk));
         }
     }
-    // registers -> LDS, zeroing whatever lies outside [rows_total) x [k_end) (same tile coordinates as load()).
-    __device__ static __forceinline__ void store(const uint4 (&r)[PER_THREAD], T* lds, int row0, int k0,
-                                                 int rows_total, int k_end, int tid) {
+    __device__ static __forceinline__ long kstep(long ld) { return TR ? (long)BK * ld : (long)BK; }
+    __device__ static __forceinline__ void load_fast(u32x4_t (&r)[PER_THREAD], const T* const (&P)[PER_THREAD]) {
+#pragma unroll
+        for (int c = 0; c < PER_THREAD; ++c) r[c] = *reinterpret_cast<const u32x4_t*>(P[c]);
+    }
+    __device__ static __forceinline__ void advance(const T* (&P)[PER_THREAD], long step) {
+#pragma unroll
+        for (int c = 0; c < PER_THREAD; ++c) P[c] += step;
+    }
+    __device__ static __forceinline__ void store_fast(const u32x4_t (&r)[PER_THREAD], T* lds, int tid) {
 #pragma unroll
         for (int c = 0; c < PER_THREAD; ++c) {
-            const int ch = tid + 256 * c;
             int row, kk;
-            if (TR) { kk = ch / (ROWS / EPC); row = (ch % (ROWS / EPC)) * EPC; }
-            else    { row = ch / (BK / EPC);  kk = (ch % (BK / EPC)) * EPC; }
-            const int off = TR ? kk * PITCH + row : row * PITCH + kk;
-            const int gr = row0 + row, gk = k0 + kk;
-            uint4 v = r[c];
-            const int lim = (gr < rows_total && gk < k_end) ? (TR ? (rows_total - gr) : (k_end - gk)) : 0;
+            coords(c, tid, row, kk);
+            *reinterpret_cast<u32x4_t*>(lds + (TR ? kk * PITCH + row : row * PITCH + kk)) = r[c];
+        }
+    }
+    // last, partial K tile (krem < BK contraction indices left; P + skip points at the tile start): clamped addresses,
+    // then zero fill of everything at or beyond krem when the registers go to LDS
+    __device__ static __forceinline__ void load_tail(u32x4_t (&r)[PER_THREAD], const T* const (&P)[PER_THREAD], long skip, long ld, int krem, int tid) {
+        const int klast = TR ? krem - 1 : ((krem - 1) / EPC) * EPC;
+#pragma unroll
+        for (int c = 0; c < PER_THREAD; ++c) {
+            int row, kk;
+            coords(c, tid, row, kk);
+            const long back = (long)(min(kk, klast) - kk) * (TR ? ld : 1);
+            r[c] = *reinterpret_cast<const u32x4_t*>(P[c] + skip + back);
+        }
+    }
+    __device__ static __forceinline__ void store_tail(const u32x4_t (&r)[PER_THREAD], T* lds, int krem, int tid) {
+#pragma unroll
+        for (int c = 0; c < PER_THREAD; ++c) {
+            int row, kk;
+            coords(c, tid, row, kk);
+            u32x4_t v = r[c];
+            const int lim = TR ? (kk < krem ? EPC : 0) : max(0, min(EPC, krem - kk));
             if (lim < EPC) {
-                // whole-dword AND masks (no per-element extraction of the loaded data: the compiler would hoist
-                // that above the loop and wait for every prologue load)
                 constexpr int EPD = 4 / (int)sizeof(T);      // elements per dword
-                unsigned* w = reinterpret_cast<unsigned*>(&v);
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     unsigned m = 0u;
                     if (EPD == 1) m = (d < lim) ? 0xFFFFFFFFu : 0u;
                     else m = ((2 * d < lim) ? 0x0000FFFFu : 0u) | ((2 * d + 1 < lim) ? 0xFFFF0000u : 0u);
-                    w[d] &= m;
+                    v[d] &= m;
                 }
             }
-            *reinterpret_cast<uint4*>(lds + off) = v;
+            *reinterpret_cast<u32x4_t*>(lds + (TR ? kk * PITCH + row : row * PITCH + kk)) = v;
         }
     }
     // fragment for the 16 tile rows starting at `r16`, chunk `c` (contraction offset c*CH)
@@ -94,15 +118,15 @@ template <typename T, bool TR, int ROWS, int BK> struct Tile {
     }
 };
 
-template <typename T, bool TA, bool TB, int BM, int BN, int D>
+template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     constexpr int CH = Mma<T>::CH;
-    constexpr int BK = 2 * CH;
+    constexpr int BK = NC * CH;          // contraction depth of one LDS stage (NC chunks of CH)
     using TileA = Tile<T, TA, BM, BK>;
     using TileB = Tile<T, TB, BN, BK>;
     constexpr int WM = BM / 2, WN = BN / 2;      // per-wave sub-tile
     constexpr int MI = WM / 16, NI = WN / 16;
-    static_assert(D % 2 == 0, "ring depth must be even (LDS double buffer index is then compile-time)");
+    static_assert(D == 2, "two register stages");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* sA = reinterpret_cast<T*>(smem_raw);
@@ -114,10 +138,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * p.ksplit_len;
     const int kend = min(p.K, kbeg + p.ksplit_len);
-    const int nk = (kend - kbeg + BK - 1) / BK;
-
-    const T* A = reinterpret_cast<const T*>(p.A);
-    const T* B = reinterpret_cast<const T*>(p.B);
+    const int nfull = (kend - kbeg) / BK;              // full K tiles: no masking at all
+    const int krem = (kend - kbeg) - nfull * BK;       // > 0: one partial tile at the end
 
     f32x4_t acc[MI][NI];
 #pragma unroll
@@ -125,36 +147,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int b = 0; b < NI; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // Register ring of D K-tiles in flight: at small M every workgroup streams its own slice of the weights and
-    // the kernel is bound by HBM LATENCY, not bandwidth -- the fix is bytes in flight (D x 16 KB per workgroup).
-    // The compiler's counted s_waitcnt vmcnt(N) (loads retire in order) keeps D-1 tiles in flight while the
-    // oldest is written to LDS; a plain __syncthreads() does not drain register-destination loads.
-    uint4 ra[D][TileA::PER_THREAD], rb[D][TileB::PER_THREAD];
     const bool want_dbias = TA && (p.dbias != nullptr) && (blockIdx.x == 0);
     float dbias_acc = 0.0f;
 
-    // prologue: D tiles in flight (tile index clamped: a short contraction re-reads its last tile from L2 rather
-    // than branching around the load -- any branch/PHI around these loads makes hipcc copy the ring registers
-    // and wait for the data right behind the load)
+    auto compute = [&](const T* cA, const T* cB) {
 #pragma unroll
-    for (int s = 0; s < D; ++s) {
-        const int t = min(s, nk - 1);
-        TileA::load(ra[s], A, p.lda, m0, kbeg + t * BK, p.M, kend, tid);
-        TileB::load(rb[s], B, p.ldb, n0, kbeg + t * BK, p.N, kend, tid);
-    }
-    auto step = [&](uint4 (&qa)[TileA::PER_THREAD], uint4 (&qb)[TileB::PER_THREAD], int kt, int cur, bool reload) {
-        T* cA = sA + cur * TileA::ELEMS;
-        T* cB = sB + cur * TileB::ELEMS;
-        TileA::store(qa, cA, m0, kbeg + kt * BK, p.M, kend, tid);
-        TileB::store(qb, cB, n0, kbeg + kt * BK, p.N, kend, tid);
-        if (reload) {
-            const int t = min(kt + D, nk - 1);
-            TileA::load(qa, A, p.lda, m0, kbeg + t * BK, p.M, kend, tid);
-            TileB::load(qb, B, p.ldb, n0, kbeg + t * BK, p.N, kend, tid);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NC; ++c) {
             typename Mma<T>::frag fa[MI], fb[NI];
 #pragma unroll
             for (int a = 0; a < MI; ++a) fa[a] = TileA::frag(cA, wm0 + 16 * a, c, lane);
@@ -173,17 +171,66 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
             }
         }
     };
-    // steady state: whole groups of D steps, every step refills its ring slot (no conditionals around loads)
-    const int ngroups = nk / D;
-    for (int grp = 0; grp < ngroups; ++grp) {
-#pragma unroll
-        for (int s = 0; s < D; ++s) step(ra[s], rb[s], grp * D + s, s & 1, true);
+
+    const T* pa[TileA::PER_THREAD];
+    const T* pb[TileB::PER_THREAD];
+    TileA::init(pa, reinterpret_cast<const T*>(p.A), p.lda, m0, kbeg, p.M, tid);
+    TileB::init(pb, reinterpret_cast<const T*>(p.B), p.ldb, n0, kbeg, p.N, tid);
+    const long stepA = TileA::kstep(p.lda), stepB = TileB::kstep(p.ldb);
+
+    // the partial tile (if any) is fetched first so that its latency hides behind the whole main loop
+    u32x4_t ta[TileA::PER_THREAD], tb[TileB::PER_THREAD];
+    if (krem > 0) {
+        TileA::load_tail(ta, pa, stepA * nfull, p.lda, krem, tid);
+        TileB::load_tail(tb, pb, stepB * nfull, p.ldb, krem, tid);
     }
-    // tail: fewer than D steps left, nothing more to fetch
-    const int rem = nk - ngroups * D;
-#pragma unroll
-    for (int s = 0; s < D - 1; ++s) {
-        if (s < rem) step(ra[s], rb[s], ngroups * D + s, s & 1, false);
+    if (nfull > 0) {
+        // Two named register stages (2 x BK contraction indices in flight).  No branch sits between a load and its
+        // use: past the last tile the pointers simply stop advancing (re-reading an L2-resident tile that is never
+        // consumed).  The compiler's counted s_waitcnt vmcnt(N) keeps the younger stage in flight while the older is
+        // written to LDS; __syncthreads() does not drain register-destination loads.  (Named stages, not an array
+        // of stages handed to a lambda: that form was demoted to scratch memory by hipcc.)
+        u32x4_t ra0[TileA::PER_THREAD], rb0[TileB::PER_THREAD], ra1[TileA::PER_THREAD], rb1[TileB::PER_THREAD];
+        int issued = 0;
+#define UNIVL_LOAD_STAGE(RA, RB)                                  \
+        do {                                                      \
+            TileA::load_fast(RA, pa);                             \
+            TileB::load_fast(RB, pb);                             \
+            ++issued;                                             \
+            const long adv__ = issued < nfull ? 1 : 0;            \
+            TileA::advance(pa, stepA * adv__);                    \
+            TileB::advance(pb, stepB * adv__);                    \
+        } while (0)
+#define UNIVL_STEP(RA, RB, CUR, RELOAD)                           \
+        do {                                                      \
+            T* cA__ = sA + (CUR) * TileA::ELEMS;                  \
+            T* cB__ = sB + (CUR) * TileB::ELEMS;                  \
+            TileA::store_fast(RA, cA__, tid);                     \
+            TileB::store_fast(RB, cB__, tid);                     \
+            if (RELOAD) UNIVL_LOAD_STAGE(RA, RB);                 \
+            __syncthreads();                                      \
+            compute(cA__, cB__);                                  \
+        } while (0)
+        UNIVL_LOAD_STAGE(ra0, rb0);
+        UNIVL_LOAD_STAGE(ra1, rb1);
+        const int ngroups = nfull / 2;
+        for (int grp = 0; grp < ngroups; ++grp) {
+            UNIVL_STEP(ra0, rb0, 0, true);
+            UNIVL_STEP(ra1, rb1, 1, true);
+        }
+        if (nfull & 1) UNIVL_STEP(ra0, rb0, 0, false);
+#undef UNIVL_STEP
+#undef UNIVL_LOAD_STAGE
+    }
+    if (krem > 0) {
+        const int cur = nfull & 1;
+        T* cA = sA + cur * TileA::ELEMS;
+        T* cB = sB + cur * TileB::ELEMS;
+        __syncthreads();          // every wave is done reading whichever buffer the tail overwrites
+        TileA::store_tail(ta, cA, krem, tid);
+        TileB::store_tail(tb, cB, krem, tid);
+        __syncthreads();
+        compute(cA, cB);
     }
 
     // ------------------------------------------------------------------------------------------ epilogue
@@ -310,30 +357,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     }
 }
 
-template <typename T, bool TA, bool TB, int BM, int BN, int D>
+template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC>
 int launch(const GemmArgs& a, int ksplit, hipStream_t stream) {
-    constexpr int BK = 2 * Mma<T>::CH;
+    constexpr int BK = NC * Mma<T>::CH;
     using TileA = Tile<T, TA, BM, BK>;
     using TileB = Tile<T, TB, BN, BK>;
     const size_t smem = 2 * (TileA::ELEMS + TileB::ELEMS) * sizeof(T);
     static bool attr_done = false;   // per instantiation
     if (!attr_done && smem > 48 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, TA, TB, BM, BN, D>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, TA, TB, BM, BN, D, NC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, ksplit);
-    hipLaunchKernelGGL((gemm_kernel<T, TA, TB, BM, BN, D>), grid, dim3(256), smem, stream, a);
+    hipLaunchKernelGGL((gemm_kernel<T, TA, TB, BM, BN, D, NC>), grid, dim3(256), smem, stream, a);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
 
-template <typename T, int BM, int BN, int D>
+template <typename T, int BM, int BN, int D, int NC>
 int dispatch_trans(const GemmArgs& a, int ta, int tb, int ksplit, hipStream_t s) {
-    if (!ta && !tb) return launch<T, false, false, BM, BN, D>(a, ksplit, s);
-    if (!ta && tb) return launch<T, false, true, BM, BN, D>(a, ksplit, s);
-    if (ta && tb) return launch<T, true, true, BM, BN, D>(a, ksplit, s);
-    return launch<T, true, false, BM, BN, D>(a, ksplit, s);
+    if (!ta && !tb) return launch<T, false, false, BM, BN, D, NC>(a, ksplit, s);
+    if (!ta && tb) return launch<T, false, true, BM, BN, D, NC>(a, ksplit, s);
+    if (ta && tb) return launch<T, true, true, BM, BN, D, NC>(a, ksplit, s);
+    return launch<T, true, false, BM, BN, D, NC>(a, ksplit, s);
 }
 
 }  // namespace
@@ -350,8 +397,15 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
     const int flags = d->flags;
     UNIVL_CHECK_ARG(!((flags & (UNIVL_GEMM_GELU_FWD | UNIVL_GEMM_GELU_BWD)) && !d->aux), UNIVL_EINVAL,
                     "univl_gemm: GELU epilogue needs aux");
+    // tile choice: 128x128 once the grid fills the chip, else 64x64 for parallelism.  The small tile stages
+    // 4 chunks (128 bf16 / 64 f32) per barrier: at M <= a few hundred the kernel is a latency chain of K steps
+    // (ds_write -> barrier -> ds_read -> MFMA), so fewer, deeper steps win; 2 stages of 32 KB stay in flight.
+    const long tiles128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
+    const bool big = d->tile == 128 || (d->tile == 0 && tiles128 >= 384);
+    static const int small_nc = [] { const char* e = getenv("UNIVL_GEMM_SMALL_NC"); return (e && e[0] == '2') ? 2 : 4; }();
+    const int nc = big ? 2 : small_nc;
     int ksplit = d->ksplit < 1 ? 1 : d->ksplit;
-    const int BK = d->dtype == UNIVL_BF16 ? 64 : 32;
+    const int BK = (d->dtype == UNIVL_BF16 ? 32 : 16) * nc;
     int klen = ((d->K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
     ksplit = (d->K + klen - 1) / klen;
     if (ksplit > 1) {
@@ -366,13 +420,12 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
     a.aux = d->aux; a.ldaux = d->ldaux; a.dbias = d->dbias; a.alpha = d->alpha;
     a.flags = flags | (ksplit > 1 ? UNIVL_GEMM_ATOMIC : 0);
     a.ksplit_len = klen;
-    // tile choice: 128x128 once the grid fills the chip twice over, else 64x64 for parallelism
-    const long tiles128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
-    const bool big = d->tile == 128 || (d->tile == 0 && tiles128 >= 384);
     if (d->dtype == UNIVL_BF16) {
-        return big ? dispatch_trans<__bf16, 128, 128, 2>(a, d->trans_a, d->trans_b, ksplit, stream)
-                   : dispatch_trans<__bf16, 64, 64, 4>(a, d->trans_a, d->trans_b, ksplit, stream);
+        if (big) return dispatch_trans<__bf16, 128, 128, 2, 2>(a, d->trans_a, d->trans_b, ksplit, stream);
+        return nc == 4 ? dispatch_trans<__bf16, 64, 64, 2, 4>(a, d->trans_a, d->trans_b, ksplit, stream)
+                       : dispatch_trans<__bf16, 64, 64, 2, 2>(a, d->trans_a, d->trans_b, ksplit, stream);
     }
-    return big ? dispatch_trans<float, 128, 128, 2>(a, d->trans_a, d->trans_b, ksplit, stream)
-               : dispatch_trans<float, 64, 64, 4>(a, d->trans_a, d->trans_b, ksplit, stream);
+    if (big) return dispatch_trans<float, 128, 128, 2, 2>(a, d->trans_a, d->trans_b, ksplit, stream);
+    return nc == 4 ? dispatch_trans<float, 64, 64, 2, 4>(a, d->trans_a, d->trans_b, ksplit, stream)
+                   : dispatch_trans<float, 64, 64, 2, 2>(a, d->trans_a, d->trans_b, ksplit, stream);
 }

@@ -10,6 +10,7 @@ Design (MI355X-first):
     enqueues kernels on the current HIP stream; it is what gets captured into a hipGraph.
 """
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -277,11 +278,19 @@ class EncoderStack:
         self.du = e(T, I, dtype=ct)
         self.dctx = e(T, H, dtype=ct)
         self.dqkv = e(T, 3 * H, dtype=ct)
-        # split-K for the N=768 products when the grid would not fill the chip
-        tiles = ((T + 63) // 64) * (H // 64)
-        self.ks_h = 1
-        if splitk and tiles < 128:
-            self.ks_h = 4 if tiles * 4 <= 512 else 2
+        # split-K for the N=768 products when the grid would not fill the chip: ~3 K-steps of 128 per workgroup
+        self.tiles = ((T + 63) // 64) * (H // 64)
+        self.splitk = splitk and self.tiles < 128
+        self.ks_h = self.ksplit_for(H) if self.splitk else 1      # >1 <=> the zero-once arenas are needed
+
+    def ksplit_for(self, K):
+        if not self.splitk:
+            return 1
+        per = int(os.environ.get("UNIVL_SPLITK_LEN", "384"))
+        ks = max(1, (K + per - 1) // per)
+        while ks > 1 and self.tiles * ks > 512:
+            ks -= 1
+        return ks
 
     def _names(self, l):
         p = "%s.encoder.layer.%d" % (self.prefix, l)
@@ -321,7 +330,7 @@ class EncoderStack:
                 dt, B, self.NH, S, S, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx"], H, ws["lse"],
                 key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev), sm)
             plan.add("univl_gemm", _gemm_desc(dt, ws["ctx"], H, fl.wop(nm["o_w"]), H, T, H, H, out32=ws["y1"], ldc=H,
-                                              bias=fl.w32(nm["o_b"]), ksplit=self.ks_h), sm)
+                                              bias=fl.w32(nm["o_b"]), ksplit=self.ksplit_for(H)), sm)
             plan.add("univl_layernorm_fwd", ops.layernorm_desc(
                 dt, T, H, x=ws["y1"], residual=x32, gamma=fl.w32(nm["ln1_g"]), beta=fl.w32(nm["ln1_b"]), y=ws["y1"],
                 stats=ws["st1"], out32=ws["a32"], out16=ws["a16"] if self.bf else None, p_pre=p, off_pre=ws["off"][1],
@@ -329,7 +338,7 @@ class EncoderStack:
             plan.add("univl_gemm", _gemm_desc(dt, ws["a16"], H, fl.wop(nm["w1"]), H, T, I, H, out16=ws["f"], ldc=I,
                                               bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd"), sm)
             plan.add("univl_gemm", _gemm_desc(dt, ws["f"], I, fl.wop(nm["w2"]), I, T, H, I, out32=ws["y2"], ldc=H,
-                                              bias=fl.w32(nm["b2"]), ksplit=self.ks_h), sm)
+                                              bias=fl.w32(nm["b2"]), ksplit=self.ksplit_for(I)), sm)
             plan.add("univl_layernorm_fwd", ops.layernorm_desc(
                 dt, T, H, x=ws["y2"], residual=ws["a32"], gamma=fl.w32(nm["ln2_g"]), beta=fl.w32(nm["ln2_b"]), y=ws["y2"],
                 stats=ws["st2"], out32=ws["o32"], out16=ws["o16"] if self.bf else None, p_pre=p, off_pre=ws["off"][2],
@@ -367,7 +376,7 @@ class EncoderStack:
             plan.add("univl_gemm", _gemm_desc(dt, self.du, I, ws["a16"], H, I, H, T, trans_a=1, trans_b=1,
                                               out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=fl.g(nm["b1"])), ss)
             plan.add("univl_gemm", _gemm_desc(dt, self.du, I, fl.wop(nm["w1"]), H, T, H, I, trans_b=1, out32=da, ldc=H,
-                                              residual=dz, ldr=H, ksplit=self.ks_h), sm)
+                                              residual=dz, ldr=H, ksplit=self.ksplit_for(I)), sm)
             # attention-output LayerNorm / dropout backward (BertSelfOutput, module_bert.py:207-211)
             dy = self.gbuf
             plan.add("univl_layernorm_bwd", ops.layernorm_desc(
@@ -389,7 +398,7 @@ class EncoderStack:
                                               dbias=fl.g_fused(nm["qkv_b"])), ss)
             dx = self.garena[l, 1]
             plan.add("univl_gemm", _gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["qkv_w"]), H, T, H, 3 * H, trans_b=1,
-                                              out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ks_h), sm)
+                                              out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ksplit_for(3 * H)), sm)
             plan.join(ss, sm)      # scratch (dxd, dxd2, du, dqkv) is reused by the next layer; grads of layer l done
             gin = dx
             if layer_hook is not None:
