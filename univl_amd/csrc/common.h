@@ -137,6 +137,25 @@ template <> struct Mma<__bf16> {
         u.s[4] = hi[0]; u.s[5] = hi[1]; u.s[6] = hi[2]; u.s[7] = hi[3];
         return u.f;
     }
+    __device__ static __forceinline__ frag pack(bf16x4_t lo, bf16x4_t hi) {
+        frag f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return f;
+    }
+    __device__ static __forceinline__ frag pack16(const unsigned char*) { return frag{}; }      // f32 form only
+    __device__ static __forceinline__ frag gather4(const unsigned char*, const unsigned char*, const unsigned char*,
+                                                   const unsigned char*) { return frag{}; }      // f32 form only
+    // two transpose reads at explicit LDS byte addresses (swizzled layouts)
+    __device__ static __forceinline__ frag tr_pair(const unsigned char* p0, const unsigned char* p1) {
+        typedef __attribute__((address_space(3))) short4_t lds_s4;
+        short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(p0));
+        short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(p1));
+        union { short s[8]; frag f; } u;
+        u.s[0] = lo[0]; u.s[1] = lo[1]; u.s[2] = lo[2]; u.s[3] = lo[3];
+        u.s[4] = hi[0]; u.s[5] = hi[1]; u.s[6] = hi[2]; u.s[7] = hi[3];
+        return u.f;
+    }
     // Two stacked accumulator tiles (contraction rows 0-15 in c0, 16-31 in c1) -> operand fragment.
     __device__ static __forceinline__ frag from_acc(f32x4_t c0, f32x4_t c1) {
         frag f;
@@ -169,6 +188,16 @@ template <> struct Mma<float> {
         const float* p = base + (4 * g) * pitch + i;
         frag f;
         f[0] = p[0]; f[1] = p[pitch]; f[2] = p[2 * pitch]; f[3] = p[3 * pitch];
+        return f;
+    }
+    __device__ static __forceinline__ frag pack(bf16x4_t, bf16x4_t) { return frag{0.f, 0.f, 0.f, 0.f}; }   // bf16 form only
+    __device__ static __forceinline__ frag tr_pair(const unsigned char*, const unsigned char*) { return frag{0.f, 0.f, 0.f, 0.f}; }
+    __device__ static __forceinline__ frag pack16(const unsigned char* p) { return *reinterpret_cast<const f32x4_t*>(p); }
+    __device__ static __forceinline__ frag gather4(const unsigned char* p0, const unsigned char* p1, const unsigned char* p2,
+                                                   const unsigned char* p3) {
+        frag f;
+        f[0] = *reinterpret_cast<const float*>(p0); f[1] = *reinterpret_cast<const float*>(p1);
+        f[2] = *reinterpret_cast<const float*>(p2); f[3] = *reinterpret_cast<const float*>(p3);
         return f;
     }
     // one accumulator tile covers the whole 16-wide chunk

@@ -8,8 +8,8 @@
 // transpose read (ds_read_b64_tr_b16) for bf16, plain strided b32 reads for f32 -- no transposed copies of
 // weights or activations ever exist in HBM.
 //
-// Workgroup = 4 waves (2x2), tile BM x BN in {64x64, 128x128}, BK = 2 chunks (64 bf16 / 32 f32), global ->
-// register ring (D K-tiles in flight) -> double-buffered LDS, one barrier per K step.  Optional split-K over gridDim.z accumulates with fp32 atomics into a pre-zeroed C.
+// Workgroup = 4 waves (2x2), tile BM x BN in {64x64, 128x128}, BK = 2 or 4 chunks; global -> LDS by DMA
+// (global_load_lds_dwordx4) into two XOR-swizzled, unpadded stages, one barrier per K step.  Optional split-K over gridDim.z accumulates with fp32 atomics into a pre-zeroed C.
 //
 // Epilogue (all optional, in this order): *alpha, +bias[n], +residual[m,n] (fp32), erf-GELU forward (saving the
 // pre-activation), *gelu'(saved pre-activation), +C_old (accumulate), store fp32 and/or T.  A wgrad launch can
@@ -33,69 +33,83 @@ struct GemmArgs {
     int ksplit_len;   // contraction length handled by one z-slice (multiple of BK)
 };
 
+// One operand tile in LDS: UNPADDED rows of RB = 128 or 256 bytes, filled by direct global->LDS DMA
+// (global_load_lds_dwordx4: each wave instruction drops 64 x 16 B at wave-uniform base + lane*16, no VGPR round trip,
+// no ds_write -- at one workgroup per CU the ds_write pass of a register-staged tile was ~1/3 of every K step).
+// Since the DMA destination is lane-linear, bank conflicts are removed by an XOR swizzle of the 16-byte piece index
+// applied to the per-lane SOURCE address and, identically, to every fragment read (an involution):
+//      piece (row r, q)  lives at byte  r*RB + ((q ^ swz(r)) << 4)
+// K-major tile ([ROWS][BK], fragment = two 8-byte reads per lane over 16 consecutive rows): swz = r & 15 (RB 256) or
+// (r >> 1) & 7 (RB 128).  T-major tile ([BK][ROWS], transpose-read of 4 k-rows x 32 B per 16 lanes): swz = (r & 7) << 1
+// (RB >= 256) or r & 6 (RB 128).
 template <typename T, bool TR, int ROWS, int BK> struct Tile {
     static constexpr int EPC = Mma<T>::EPC;
-    static constexpr int PITCH = TR ? (ROWS + Mma<T>::tpad) : (BK + Mma<T>::kpad);
-    static constexpr int ELEMS = TR ? BK * PITCH : ROWS * PITCH;
-    static constexpr int CHUNKS = ROWS * BK / EPC;
+    static constexpr int RB = (TR ? ROWS : BK) * (int)sizeof(T);     // bytes per LDS row
+    static constexpr int NR = TR ? BK : ROWS;                        // LDS rows
+    static constexpr int CPR = RB / 16;                              // 16-byte pieces per row
+    static constexpr int BYTES = NR * RB;
+    static constexpr int CHUNKS = BYTES / 16;
     static constexpr int PER_THREAD = CHUNKS / 256;
-    static_assert(CHUNKS % 256 == 0, "tile must split evenly over 256 threads");
+    static_assert(CHUNKS % 256 == 0 && (CPR == 8 || CPR == 16 || CPR == 32), "unsupported tile geometry");
 
-    // Per-thread source pointers of its 16-byte pieces.  Everything that does not change along K (row clamp, piece
-    // coordinates) is folded into the pointer ONCE; a K step is then `load; pointer += step` -- the inner loop of
-    // a small-M GEMM runs one wave per SIMD and is bound by instruction issue, not by MFMA or HBM.
-
-    __device__ static __forceinline__ void coords(int c, int tid, int& row, int& kk) {
-        const int ch = tid + 256 * c;
-        if (TR) { kk = ch / (ROWS / EPC); row = (ch % (ROWS / EPC)) * EPC; }
-        else    { row = ch / (BK / EPC);  kk = (ch % (BK / EPC)) * EPC; }
+    __device__ static __forceinline__ int swz(int r) {
+        if (TR) return CPR == 8 ? (r & 6) : ((r & 7) << 1);
+        return CPR == 8 ? ((r >> 1) & 7) : (r & 15);
     }
-    // Rows beyond rows_total are CLAMPED, not masked: they only feed accumulator rows/columns the epilogue never
-    // stores.  (Only the contraction direction needs zero fill, and only in the last, partial K tile.)
-    __device__ static __forceinline__ void init(const T* (&P)[PER_THREAD], const T* base, long ld, int row0, int k0, int rows_total, int tid) {
+    __device__ static __forceinline__ int byte_of(int r, int q) { return r * RB + ((q ^ swz(r)) << 4); }
+    // LDS piece L (lane-linear) holds tile piece (r, q):  r = L / CPR,  q = (L % CPR) ^ swz(r)
+    __device__ static __forceinline__ void coords(int c, int tid, int& r, int& q) {
+        const int L = tid + 256 * c;
+        r = L / CPR;
+        q = (L % CPR) ^ swz(r);
+    }
+    // Per-thread source pointers.  Everything invariant along K (row clamp, piece coordinates) is folded in once;
+    // rows beyond rows_total are CLAMPED, not masked: they only feed accumulator rows/columns the epilogue never
+    // stores.  Only the contraction direction needs zero fill, and only in the last, partial K tile.
+    __device__ static __forceinline__ void init(const T* (&P)[PER_THREAD], const T* base, long ld, int row0, int k0,
+                                                int rows_total, int tid) {
         const int rmax = TR ? ((rows_total - 1) / EPC) * EPC : rows_total - 1;
 #pragma unroll
         for (int c = 0; c < PER_THREAD; ++c) {
-            int row, kk;
-            coords(c, tid, row, kk);
-            const int gr = min(row0 + row, rmax);
-            P[c] = TR ? (base + (long)(k0 + kk) * ld + gr) : (base + (long)gr * ld + (k0 + kk));
+            int r, q;
+            coords(c, tid, r, q);
+            if (TR) P[c] = base + (long)(k0 + r) * ld + min(row0 + q * EPC, rmax);
+            else    P[c] = base + (long)min(row0 + r, rmax) * ld + (k0 + q * EPC);
         }
     }
     __device__ static __forceinline__ long kstep(long ld) { return TR ? (long)BK * ld : (long)BK; }
-    __device__ static __forceinline__ void load_fast(u32x4_t (&r)[PER_THREAD], const T* const (&P)[PER_THREAD]) {
-#pragma unroll
-        for (int c = 0; c < PER_THREAD; ++c) r[c] = *reinterpret_cast<const u32x4_t*>(P[c]);
-    }
     __device__ static __forceinline__ void advance(const T* (&P)[PER_THREAD], long step) {
 #pragma unroll
         for (int c = 0; c < PER_THREAD; ++c) P[c] += step;
     }
-    __device__ static __forceinline__ void store_fast(const u32x4_t (&r)[PER_THREAD], T* lds, int tid) {
+    // asynchronous fill of one LDS stage
+    __device__ static __forceinline__ void issue(const T* const (&P)[PER_THREAD], unsigned char* stage, int tid) {
+        unsigned char* wbase = stage + (tid & ~63) * 16;          // wave-uniform
 #pragma unroll
-        for (int c = 0; c < PER_THREAD; ++c) {
-            int row, kk;
-            coords(c, tid, row, kk);
-            *reinterpret_cast<u32x4_t*>(lds + (TR ? kk * PITCH + row : row * PITCH + kk)) = r[c];
-        }
+        for (int c = 0; c < PER_THREAD; ++c)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)P[c],
+                                             (__attribute__((address_space(3))) void*)(wbase + c * 4096), 16, 0, 0);
     }
-    // last, partial K tile (krem < BK contraction indices left; P + skip points at the tile start): clamped addresses,
-    // then zero fill of everything at or beyond krem when the registers go to LDS
-    __device__ static __forceinline__ void load_tail(u32x4_t (&r)[PER_THREAD], const T* const (&P)[PER_THREAD], long skip, long ld, int krem, int tid) {
+    // last, partial K tile (krem < BK contraction indices left; P + skip points at the tile start): through
+    // registers, clamped addresses, zero fill of everything at or beyond krem
+    __device__ static __forceinline__ void load_tail(u32x4_t (&r)[PER_THREAD], const T* const (&P)[PER_THREAD], long skip,
+                                                     long ld, int krem, int tid) {
         const int klast = TR ? krem - 1 : ((krem - 1) / EPC) * EPC;
 #pragma unroll
         for (int c = 0; c < PER_THREAD; ++c) {
-            int row, kk;
-            coords(c, tid, row, kk);
+            int rr, q;
+            coords(c, tid, rr, q);
+            const int kk = TR ? rr : q * EPC;
             const long back = (long)(min(kk, klast) - kk) * (TR ? ld : 1);
             r[c] = *reinterpret_cast<const u32x4_t*>(P[c] + skip + back);
         }
     }
-    __device__ static __forceinline__ void store_tail(const u32x4_t (&r)[PER_THREAD], T* lds, int krem, int tid) {
+    __device__ static __forceinline__ void store_tail(const u32x4_t (&r)[PER_THREAD], unsigned char* stage, int krem, int tid) {
 #pragma unroll
         for (int c = 0; c < PER_THREAD; ++c) {
-            int row, kk;
-            coords(c, tid, row, kk);
+            int rr, q;
+            coords(c, tid, rr, q);
+            const int kk = TR ? rr : q * EPC;
             u32x4_t v = r[c];
             const int lim = TR ? (kk < krem ? EPC : 0) : max(0, min(EPC, krem - kk));
             if (lim < EPC) {
@@ -108,13 +122,41 @@ template <typename T, bool TR, int ROWS, int BK> struct Tile {
                     v[d] &= m;
                 }
             }
-            *reinterpret_cast<u32x4_t*>(lds + (TR ? kk * PITCH + row : row * PITCH + kk)) = v;
+            *reinterpret_cast<u32x4_t*>(stage + (tid + 256 * c) * 16) = v;
         }
     }
+    // element (row r, column e) of the tile, for scalar access
+    __device__ static __forceinline__ const T* elem(const unsigned char* stage, int r, int e) {
+        const int b = e * (int)sizeof(T);
+        return reinterpret_cast<const T*>(stage + byte_of(r, b >> 4) + (b & 15));
+    }
     // fragment for the 16 tile rows starting at `r16`, chunk `c` (contraction offset c*CH)
-    __device__ static __forceinline__ typename Mma<T>::frag frag(const T* lds, int r16, int c, int lane) {
-        if (TR) return Mma<T>::lds_tmajor(lds + (c * Mma<T>::CH) * PITCH + r16, PITCH, lane);
-        return Mma<T>::lds_kmajor(lds + (r16 + (lane & 15)) * PITCH + c * Mma<T>::CH, lane >> 4);
+    __device__ static __forceinline__ typename Mma<T>::frag frag(const unsigned char* stage, int r16, int c, int lane) {
+        const int g = lane >> 4, i = lane & 15;
+        typename Mma<T>::frag f;
+        if (!TR) {
+            const int row = r16 + i;
+            if (sizeof(T) == 2) {
+                const int q = c * 4 + (g >> 1), w = (g & 1) * 8;
+                const bf16x4_t lo = *reinterpret_cast<const bf16x4_t*>(stage + byte_of(row, q) + w);
+                const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(stage + byte_of(row, q + 2) + w);
+                return Mma<T>::pack(lo, hi);
+            } else {
+                return Mma<T>::pack16(stage + byte_of(row, c * 4 + g));
+            }
+        } else {
+            if (sizeof(T) == 2) {
+                const int krow = c * 32 + 4 * g + (i >> 2);
+                const int cb = (r16 + 4 * (i & 3)) * 2;
+                return Mma<T>::tr_pair(stage + byte_of(krow, cb >> 4) + (cb & 15), stage + byte_of(krow + 16, cb >> 4) + (cb & 15));
+            } else {
+                const int cb = (r16 + i) * 4;
+                const int k0 = c * 16 + 4 * g;
+                return Mma<T>::gather4(stage + byte_of(k0, cb >> 4) + (cb & 15), stage + byte_of(k0 + 1, cb >> 4) + (cb & 15),
+                                       stage + byte_of(k0 + 2, cb >> 4) + (cb & 15), stage + byte_of(k0 + 3, cb >> 4) + (cb & 15));
+            }
+        }
+        return f;
     }
 };
 
@@ -126,11 +168,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     using TileB = Tile<T, TB, BN, BK>;
     constexpr int WM = BM / 2, WN = BN / 2;      // per-wave sub-tile
     constexpr int MI = WM / 16, NI = WN / 16;
-    static_assert(D == 2, "two register stages");
+    static_assert(D == 2, "two LDS stages");
 
+    // ONE dynamic LDS object (a second __shared__ object makes hipcc drain vmcnt(0) before every ds_read)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* sA = reinterpret_cast<T*>(smem_raw);
-    T* sB = sA + 2 * TileA::ELEMS;
+    unsigned char* sA = smem_raw;
+    unsigned char* sB = sA + 2 * TileA::BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -150,7 +193,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const bool want_dbias = TA && (p.dbias != nullptr) && (blockIdx.x == 0);
     float dbias_acc = 0.0f;
 
-    auto compute = [&](const T* cA, const T* cB) {
+    auto compute = [&](const unsigned char* cA, const unsigned char* cB) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             typename Mma<T>::frag fa[MI], fb[NI];
@@ -167,7 +210,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
             // bias gradient = sum over the contraction (tokens) of A_op rows; A is T-major: [BK][BM]
             if (tid < BM) {
 #pragma unroll 8
-                for (int kk = 0; kk < BK; ++kk) dbias_acc += to_f32<T>(cA[kk * TileA::PITCH + tid]);
+                for (int kk = 0; kk < BK; ++kk) dbias_acc += to_f32<T>(*TileA::elem(cA, kk, tid));
             }
         }
     };
@@ -178,55 +221,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     TileB::init(pb, reinterpret_cast<const T*>(p.B), p.ldb, n0, kbeg, p.N, tid);
     const long stepA = TileA::kstep(p.lda), stepB = TileB::kstep(p.ldb);
 
-    // the partial tile (if any) is fetched first so that its latency hides behind the whole main loop
+    // the partial tile (if any) goes through registers; fetched first so its latency hides behind the main loop
     u32x4_t ta[TileA::PER_THREAD], tb[TileB::PER_THREAD];
     if (krem > 0) {
         TileA::load_tail(ta, pa, stepA * nfull, p.lda, krem, tid);
         TileB::load_tail(tb, pb, stepB * nfull, p.ldb, krem, tid);
     }
     if (nfull > 0) {
-        // Two named register stages (2 x BK contraction indices in flight).  No branch sits between a load and its
-        // use: past the last tile the pointers simply stop advancing (re-reading an L2-resident tile that is never
-        // consumed).  The compiler's counted s_waitcnt vmcnt(N) keeps the younger stage in flight while the older is
-        // written to LDS; __syncthreads() does not drain register-destination loads.  (Named stages, not an array
-        // of stages handed to a lambda: that form was demoted to scratch memory by hipcc.)
-        u32x4_t ra0[TileA::PER_THREAD], rb0[TileB::PER_THREAD], ra1[TileA::PER_THREAD], rb1[TileB::PER_THREAD];
-        int issued = 0;
-#define UNIVL_LOAD_STAGE(RA, RB)                                  \
-        do {                                                      \
-            TileA::load_fast(RA, pa);                             \
-            TileB::load_fast(RB, pb);                             \
-            ++issued;                                             \
-            const long adv__ = issued < nfull ? 1 : 0;            \
-            TileA::advance(pa, stepA * adv__);                    \
-            TileB::advance(pb, stepB * adv__);                    \
-        } while (0)
-#define UNIVL_STEP(RA, RB, CUR, RELOAD)                           \
-        do {                                                      \
-            T* cA__ = sA + (CUR) * TileA::ELEMS;                  \
-            T* cB__ = sB + (CUR) * TileB::ELEMS;                  \
-            TileA::store_fast(RA, cA__, tid);                     \
-            TileB::store_fast(RB, cB__, tid);                     \
-            if (RELOAD) UNIVL_LOAD_STAGE(RA, RB);                 \
-            __syncthreads();                                      \
-            compute(cA__, cB__);                                  \
-        } while (0)
-        UNIVL_LOAD_STAGE(ra0, rb0);
-        UNIVL_LOAD_STAGE(ra1, rb1);
-        const int ngroups = nfull / 2;
-        for (int grp = 0; grp < ngroups; ++grp) {
-            UNIVL_STEP(ra0, rb0, 0, true);
-            UNIVL_STEP(ra1, rb1, 1, true);
+        // double-buffered LDS-DMA pipeline: tile t+1 streams into the other stage while tile t is multiplied; the
+        // __syncthreads() at the end of a step carries the vmcnt(0) that makes tile t+1 visible and releases stage t.
+        TileA::issue(pa, sA, tid);
+        TileB::issue(pb, sB, tid);
+        TileA::advance(pa, stepA);
+        TileB::advance(pb, stepB);
+        __syncthreads();
+        for (int t = 0; t < nfull; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nfull) {
+                TileA::issue(pa, sA + (cur ^ 1) * TileA::BYTES, tid);
+                TileB::issue(pb, sB + (cur ^ 1) * TileB::BYTES, tid);
+                TileA::advance(pa, stepA);
+                TileB::advance(pb, stepB);
+            }
+            compute(sA + cur * TileA::BYTES, sB + cur * TileB::BYTES);
+            __syncthreads();
         }
-        if (nfull & 1) UNIVL_STEP(ra0, rb0, 0, false);
-#undef UNIVL_STEP
-#undef UNIVL_LOAD_STAGE
     }
     if (krem > 0) {
-        const int cur = nfull & 1;
-        T* cA = sA + cur * TileA::ELEMS;
-        T* cB = sB + cur * TileB::ELEMS;
-        __syncthreads();          // every wave is done reading whichever buffer the tail overwrites
+        unsigned char* cA = sA + (nfull & 1) * TileA::BYTES;
+        unsigned char* cB = sB + (nfull & 1) * TileB::BYTES;
         TileA::store_tail(ta, cA, krem, tid);
         TileB::store_tail(tb, cB, krem, tid);
         __syncthreads();
@@ -362,7 +385,7 @@ int launch(const GemmArgs& a, int ksplit, hipStream_t stream) {
     constexpr int BK = NC * Mma<T>::CH;
     using TileA = Tile<T, TA, BM, BK>;
     using TileB = Tile<T, TB, BN, BK>;
-    const size_t smem = 2 * (TileA::ELEMS + TileB::ELEMS) * sizeof(T);
+    const size_t smem = 2 * (TileA::BYTES + TileB::BYTES);
     static bool attr_done = false;   // per instantiation
     if (!attr_done && smem > 48 * 1024) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, TA, TB, BM, BN, D, NC>),
