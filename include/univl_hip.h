@@ -71,6 +71,11 @@ typedef struct UnivlGemm {
     int32_t tile;          /* 0 auto, 64, 128 */
 } UnivlGemm;
 int univl_gemm(const UnivlGemm* desc, hipStream_t stream);
+/* n (1..UNIVL_GEMM_GROUP_MAX) independent problems with the same dtype / trans_a / trans_b in ONE launch: the four
+ * weight-gradient GEMMs autograd runs for one transformer layer (the wgrad halves of the nn.Linear backward of
+ * module_bert.py:172-174,207,233,246).  Members must not alias each other's outputs. */
+#define UNIVL_GEMM_GROUP_MAX 4
+int univl_gemm_group(const UnivlGemm* descs, int32_t n, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------ LayerNorm
  * TF-style LayerNorm (until_module.py:40-53: biased variance, eps inside the sqrt) fused with what surrounds it

@@ -137,6 +137,44 @@ def test_gemm_gelu_epilogues_and_splitk(dtype):
     assert rel_err(Y, ref) < (1e-5 if dtype == torch.float32 else 2e-3)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T", [192, 100, 700])
+def test_gemm_group_wgrads(dtype, T):
+    """One launch for the four weight-gradient GEMMs of a layer == four separate launches (bit-identical) == reference;
+    mixed shapes, ragged contraction length, per-member accumulate / bias-gradient flags, a split-K member."""
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]       # (rows of dY^T, cols of X)
+    descs, outs, refs, dbs, singles, keep = [], [], [], [], [], []
+    for k, (N, K) in enumerate(shapes):
+        dY = gen(T, N, seed=20 + k).to(DEV, dtype)
+        X = gen(T, K, seed=30 + k).to(DEV, dtype)
+        keep += [dY, X]                                    # descriptors hold raw pointers
+        acc = k == 1
+        dW = torch.full((N, K), 1.0 if acc else 0.0, device=DEV)
+        db = torch.zeros(N, device=DEV) if k in (1, 3) else None
+        ks = 2 if (k == 2 and T > 256) else 1
+        descs.append(ops.gemm_desc(dY, X, N, K, T, trans_a=True, trans_b=True, out32=dW, dbias=db, dbias_atomic=db is not None,
+                                   accumulate=acc, ksplit=ks))
+        outs.append(dW)
+        dbs.append((db, dY))
+        refs.append(dY.double().cpu().T @ X.double().cpu() + (1.0 if acc else 0.0))
+        dW1 = torch.full((N, K), 1.0 if acc else 0.0, device=DEV)
+        ops.gemm(dY, X, N, K, T, trans_a=True, trans_b=True, out32=dW1, accumulate=acc, ksplit=ks)
+        singles.append(dW1)
+    ops.gemm_group(descs)
+    for k, (dW, ref) in enumerate(zip(outs, refs)):
+        assert rel_err(dW, ref) < (1e-5 if dtype == torch.float32 else 2e-3), k
+        if not (k == 2 and T > 256):                       # atomics of the split-K member may reorder
+            assert torch.equal(dW, singles[k]), k
+    for db, dY in dbs:
+        if db is not None:
+            assert rel_err(db, dY.double().cpu().sum(0)) < (1e-5 if dtype == torch.float32 else 2e-3)
+    with pytest.raises(RuntimeError):
+        ops.gemm_group(descs + descs[:1])                  # more than GEMM_GROUP_MAX members
+    mixed = [descs[0], ops.gemm_desc(dbs[0][1], dbs[0][1], 4, 4, 64, out32=torch.zeros(4, 4, device=DEV))]
+    with pytest.raises(RuntimeError):
+        ops.gemm_group(mixed)                              # different operand layouts
+
+
 def test_gemm_argument_errors():
     A = torch.zeros(8, 256, device=DEV)
     B = torch.zeros(8, 256, device=DEV)

@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libunivl_hip.so")
 
 DT_F32, DT_BF16 = 0, 1
 GEMM_ACCUM, GEMM_GELU_FWD, GEMM_GELU_BWD, GEMM_DBIAS_ATOMIC = 1, 2, 4, 16
+GEMM_GROUP_MAX = 4
 
 vp, i32, i64, f32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
@@ -88,6 +89,8 @@ def lib():
                  "univl_pool_bwd", "univl_bert_adam"):
         getattr(L, name).argtypes = [vp, vp]
         getattr(L, name).restype = i32
+    L.univl_gemm_group.argtypes = [vp, i32, vp]
+    L.univl_gemm_group.restype = i32
     L.univl_maxmargin_loss.argtypes = [vp, i32, i32, f32, vp, vp, vp, vp]
     L.univl_crossen_loss.argtypes = [vp, i32, i32, vp, vp, vp]
     L.univl_milnce_loss.argtypes = [vp, i32, i32, i32, vp, vp, vp]
@@ -116,7 +119,7 @@ def lib():
     return L
 
 
-EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_device_info", "univl_gemm",
+EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_device_info", "univl_gemm", "univl_gemm_group",
             "univl_layernorm_fwd", "univl_layernorm_bwd", "univl_attention_fwd", "univl_attention_bwd",
             "univl_embed_text_fwd", "univl_embed_text_bwd", "univl_pool_fwd", "univl_pool_bwd",
             "univl_maxmargin_loss", "univl_crossen_loss", "univl_milnce_loss", "univl_scale_by_device_scalar", "univl_pair_concat_fwd", "univl_pair_concat_bwd", "univl_postype_fwd", "univl_postype_bwd", "univl_tanh_fwd",

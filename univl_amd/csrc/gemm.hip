@@ -161,7 +161,7 @@ template <typename T, bool TR, int ROWS, int BK> struct Tile {
 };
 
 template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const int by, const int bz, const int nz) {
     constexpr int CH = Mma<T>::CH;
     constexpr int BK = NC * CH;          // contraction depth of one LDS stage (NC chunks of CH)
     using TileA = Tile<T, TA, BM, BK>;
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i = lane & 15;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * p.ksplit_len;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = bz * p.ksplit_len;
     const int kend = min(p.K, kbeg + p.ksplit_len);
     const int nfull = (kend - kbeg) / BK;              // full K tiles: no masking at all
     const int krem = (kend - kbeg) - nfull * BK;       // > 0: one partial tile at the end
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int b = 0; b < NI; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const bool want_dbias = TA && (p.dbias != nullptr) && (blockIdx.x == 0);
+    const bool want_dbias = TA && (p.dbias != nullptr) && (bx == 0);
     float dbias_acc = 0.0f;
 
     auto compute = [&](const unsigned char* cA, const unsigned char* cB) {
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     // of back-to-back loads from clamped (always valid) addresses; only the stores are predicated.  A per-element
     // "if (flag) load" would serialise 16 dependent round trips per thread.
     const bool atomic = (p.flags & UNIVL_GEMM_ATOMIC) != 0;
-    const bool first_slice = (blockIdx.z == 0);
+    const bool first_slice = (bz == 0);
     T* C16 = reinterpret_cast<T*>(p.C16);
     T* aux = reinterpret_cast<T*>(p.aux);
     long orow[MI][4];
@@ -281,82 +281,65 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         vcol[b] = col < p.N;
         ocol[b] = min(col, p.N - 1);
     }
-    float ev[MI][NI][4];
+    // one 16-row slab of the wave's sub-tile at a time: keeps the live epilogue values to NI x 4 per input instead of
+    // MI x NI x 4 (the 128x128 tile would otherwise need > 256 VGPRs and drop to one wave per SIMD)
+    float bv[NI];
+    if (p.bias && first_slice) {
 #pragma unroll
-    for (int a = 0; a < MI; ++a)
+        for (int b = 0; b < NI; ++b) bv[b] = p.bias[ocol[b]];
+    } else {
+#pragma unroll
+        for (int b = 0; b < NI; ++b) bv[b] = 0.0f;
+    }
+#pragma unroll
+    for (int a = 0; a < MI; ++a) {
+        float ev[NI][4];
 #pragma unroll
         for (int b = 0; b < NI; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ev[a][b][r] = acc[a][b][r] * p.alpha;
-    if (p.bias && first_slice) {
-        float bv[NI];
-#pragma unroll
-        for (int b = 0; b < NI; ++b) bv[b] = p.bias[ocol[b]];
-#pragma unroll
-        for (int a = 0; a < MI; ++a)
+            for (int r = 0; r < 4; ++r) ev[b][r] = acc[a][b][r] * p.alpha + bv[b];
+        if (p.R && first_slice) {
+            float rv[NI][4];
 #pragma unroll
             for (int b = 0; b < NI; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ev[a][b][r] += bv[b];
-    }
-    if (p.R && first_slice) {
-        float rv[MI][NI][4];
-#pragma unroll
-        for (int a = 0; a < MI; ++a)
+                for (int r = 0; r < 4; ++r) rv[b][r] = p.R[orow[a][r] * p.ldr + ocol[b]];
 #pragma unroll
             for (int b = 0; b < NI; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rv[a][b][r] = p.R[orow[a][r] * p.ldr + ocol[b]];
-#pragma unroll
-        for (int a = 0; a < MI; ++a)
-#pragma unroll
-            for (int b = 0; b < NI; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ev[a][b][r] += rv[a][b][r];
-    }
-    if (p.flags & UNIVL_GEMM_GELU_FWD) {
-#pragma unroll
-        for (int a = 0; a < MI; ++a)
+                for (int r = 0; r < 4; ++r) ev[b][r] += rv[b][r];
+        }
+        if (p.flags & UNIVL_GEMM_GELU_FWD) {
 #pragma unroll
             for (int b = 0; b < NI; ++b)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (vrow[a][r] && vcol[b]) aux[orow[a][r] * p.ldaux + ocol[b]] = from_f32<T>(ev[a][b][r]);
-                    ev[a][b][r] = gelu_f(ev[a][b][r]);
+                    if (vrow[a][r] && vcol[b]) aux[orow[a][r] * p.ldaux + ocol[b]] = from_f32<T>(ev[b][r]);
+                    ev[b][r] = gelu_f(ev[b][r]);
                 }
-    }
-    if (p.flags & UNIVL_GEMM_GELU_BWD) {
-        T uv[MI][NI][4];
-#pragma unroll
-        for (int a = 0; a < MI; ++a)
+        }
+        if (p.flags & UNIVL_GEMM_GELU_BWD) {
+            T uv[NI][4];
 #pragma unroll
             for (int b = 0; b < NI; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) uv[a][b][r] = aux[orow[a][r] * p.ldaux + ocol[b]];
-#pragma unroll
-        for (int a = 0; a < MI; ++a)
+                for (int r = 0; r < 4; ++r) uv[b][r] = aux[orow[a][r] * p.ldaux + ocol[b]];
 #pragma unroll
             for (int b = 0; b < NI; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ev[a][b][r] *= gelu_grad_f(to_f32<T>(uv[a][b][r]));
-    }
-    if ((p.flags & UNIVL_GEMM_ACCUM) && !atomic) {
-        float cv[MI][NI][4];
-#pragma unroll
-        for (int a = 0; a < MI; ++a)
+                for (int r = 0; r < 4; ++r) ev[b][r] *= gelu_grad_f(to_f32<T>(uv[b][r]));
+        }
+        if ((p.flags & UNIVL_GEMM_ACCUM) && !atomic) {
+            float cv[NI][4];
 #pragma unroll
             for (int b = 0; b < NI; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cv[a][b][r] = p.C32[orow[a][r] * p.ldc + ocol[b]];
-#pragma unroll
-        for (int a = 0; a < MI; ++a)
+                for (int r = 0; r < 4; ++r) cv[b][r] = p.C32[orow[a][r] * p.ldc + ocol[b]];
 #pragma unroll
             for (int b = 0; b < NI; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ev[a][b][r] += cv[a][b][r];
-    }
-#pragma unroll
-    for (int a = 0; a < MI; ++a)
+                for (int r = 0; r < 4; ++r) ev[b][r] += cv[b][r];
+        }
 #pragma unroll
         for (int b = 0; b < NI; ++b)
 #pragma unroll
@@ -364,20 +347,71 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                 if (!(vrow[a][r] && vcol[b])) continue;
                 const long o = orow[a][r] * p.ldc + ocol[b];
                 if (atomic) {
-                    unsafeAtomicAdd(p.C32 + o, ev[a][b][r]);
+                    unsafeAtomicAdd(p.C32 + o, ev[b][r]);
                 } else {
-                    if (p.C32) p.C32[o] = ev[a][b][r];
-                    if (C16) C16[o] = from_f32<T>(ev[a][b][r]);
+                    if (p.C32) p.C32[o] = ev[b][r];
+                    if (C16) C16[o] = from_f32<T>(ev[b][r]);
                 }
             }
+    }
     if (want_dbias && tid < BM) {
         const int row = m0 + tid;
         if (row < p.M) {
-            if (gridDim.z > 1 || (p.flags & UNIVL_GEMM_DBIAS_ATOMIC)) unsafeAtomicAdd(p.dbias + row, dbias_acc);
+            if (nz > 1 || (p.flags & UNIVL_GEMM_DBIAS_ATOMIC)) unsafeAtomicAdd(p.dbias + row, dbias_acc);
             else if (p.flags & UNIVL_GEMM_ACCUM) p.dbias[row] += dbias_acc;
             else p.dbias[row] = dbias_acc;
         }
     }
+}
+
+template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
+    gemm_tile<T, TA, TB, BM, BN, D, NC>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z);
+}
+
+// Up to UNIVL_GEMM_GROUP_MAX independent problems of the same operand layout in ONE launch (the four weight-gradient
+// GEMMs of an encoder layer: each alone covers a fraction of the 256 CUs for one or two K steps, and four dependent
+// launches cost four launch latencies).  Workgroups are numbered problem by problem; x fastest, then y, then z.
+struct GroupArgs {
+    GemmArgs p[UNIVL_GEMM_GROUP_MAX];
+    int first[UNIVL_GEMM_GROUP_MAX + 1];      // first workgroup of problem i; first[n..] = total
+    int nx[UNIVL_GEMM_GROUP_MAX], nxy[UNIVL_GEMM_GROUP_MAX], nz[UNIVL_GEMM_GROUP_MAX];
+};
+
+template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC>
+__global__ __launch_bounds__(256, 2) void gemm_group_kernel(GroupArgs g) {
+    const int w = blockIdx.x;
+    int idx = 0;
+#pragma unroll
+    for (int i = 1; i < UNIVL_GEMM_GROUP_MAX; ++i) idx += (w >= g.first[i]) ? 1 : 0;
+    // uniform select (no dynamic indexing of the kernel-argument struct)
+    GemmArgs p = g.p[0];
+    int first = g.first[0], nx = g.nx[0], nxy = g.nxy[0], nz = g.nz[0];
+#pragma unroll
+    for (int i = 1; i < UNIVL_GEMM_GROUP_MAX; ++i)
+        if (idx == i) { p = g.p[i]; first = g.first[i]; nx = g.nx[i]; nxy = g.nxy[i]; nz = g.nz[i]; }
+    const int local = w - first;
+    const int bz = local / nxy, rem = local - bz * nxy;
+    const int by = rem / nx, bx = rem - by * nx;
+    gemm_tile<T, TA, TB, BM, BN, D, NC>(p, bx, by, bz, nz);
+}
+
+template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC>
+int launch_group(const GroupArgs& g, hipStream_t stream) {
+    constexpr int BK = NC * Mma<T>::CH;
+    using TileA = Tile<T, TA, BM, BK>;
+    using TileB = Tile<T, TB, BN, BK>;
+    const size_t smem = 2 * (TileA::BYTES + TileB::BYTES);
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done && smem > 48 * 1024) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_group_kernel<T, TA, TB, BM, BN, D, NC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_group_kernel<T, TA, TB, BM, BN, D, NC>), dim3(g.first[UNIVL_GEMM_GROUP_MAX]), dim3(256), smem,
+                       stream, g);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
 }
 
 template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC>
@@ -408,7 +442,8 @@ int dispatch_trans(const GemmArgs& a, int ta, int tb, int ksplit, hipStream_t s)
 
 }  // namespace
 
-extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
+// validation + kernel arguments shared by the single and the grouped entry point
+static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, bool& big, int& nc) {
     UNIVL_CHECK_ARG(d != nullptr, UNIVL_EINVAL, "univl_gemm: null descriptor");
     UNIVL_CHECK_ARG(d->dtype == UNIVL_F32 || d->dtype == UNIVL_BF16, UNIVL_EUNSUPPORTED, "univl_gemm: dtype %d", d->dtype);
     UNIVL_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, UNIVL_EINVAL, "univl_gemm: empty problem %dx%dx%d", d->M, d->N, d->K);
@@ -422,12 +457,11 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
                     "univl_gemm: GELU epilogue needs aux");
     // tile choice: 128x128 once the grid fills the chip, else 64x64 for parallelism.  The small tile stages
     // 4 chunks (128 bf16 / 64 f32) per barrier: at M <= a few hundred the kernel is a latency chain of K steps
-    // (ds_write -> barrier -> ds_read -> MFMA), so fewer, deeper steps win; 2 stages of 32 KB stay in flight.
+    // (DMA -> barrier -> ds_read -> MFMA), so fewer, deeper steps win; 2 stages of 32 KB stay in flight.
     const long tiles128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
-    const bool big = d->tile == 128 || (d->tile == 0 && tiles128 >= 384);
-    static const int small_nc = [] { const char* e = getenv("UNIVL_GEMM_SMALL_NC"); return (e && e[0] == '2') ? 2 : 4; }();
-    const int nc = big ? 2 : small_nc;
-    int ksplit = d->ksplit < 1 ? 1 : d->ksplit;
+    big = d->tile == 128 || (d->tile == 0 && tiles128 >= 384);
+    nc = big ? 2 : 4;
+    ksplit = d->ksplit < 1 ? 1 : d->ksplit;
     const int BK = (d->dtype == UNIVL_BF16 ? 32 : 16) * nc;
     int klen = ((d->K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
     ksplit = (d->K + klen - 1) / klen;
@@ -437,18 +471,71 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
     }
     UNIVL_CHECK_ARG(!(d->dbias && !d->trans_a), UNIVL_EINVAL, "univl_gemm: dbias only with T-major A (wgrad)");
     UNIVL_CHECK_ARG(!((flags & UNIVL_GEMM_ACCUM) && !d->C32), UNIVL_EINVAL, "univl_gemm: ACCUM needs the fp32 output");
-    GemmArgs a;
     a.A = d->A; a.B = d->B; a.lda = d->lda; a.ldb = d->ldb; a.M = d->M; a.N = d->N; a.K = d->K;
     a.C32 = d->C32; a.C16 = d->C16; a.ldc = d->ldc; a.bias = d->bias; a.R = d->R; a.ldr = d->ldr;
     a.aux = d->aux; a.ldaux = d->ldaux; a.dbias = d->dbias; a.alpha = d->alpha;
     a.flags = flags | (ksplit > 1 ? UNIVL_GEMM_ATOMIC : 0);
     a.ksplit_len = klen;
+    return UNIVL_OK;
+}
+
+extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
+    GemmArgs a;
+    int ksplit, nc;
+    bool big;
+    const int rc = prepare(d, a, ksplit, big, nc);
+    if (rc != UNIVL_OK) return rc;
     if (d->dtype == UNIVL_BF16) {
         if (big) return dispatch_trans<__bf16, 128, 128, 2, 2>(a, d->trans_a, d->trans_b, ksplit, stream);
-        return nc == 4 ? dispatch_trans<__bf16, 64, 64, 2, 4>(a, d->trans_a, d->trans_b, ksplit, stream)
-                       : dispatch_trans<__bf16, 64, 64, 2, 2>(a, d->trans_a, d->trans_b, ksplit, stream);
+        return dispatch_trans<__bf16, 64, 64, 2, 4>(a, d->trans_a, d->trans_b, ksplit, stream);
     }
     if (big) return dispatch_trans<float, 128, 128, 2, 2>(a, d->trans_a, d->trans_b, ksplit, stream);
-    return nc == 4 ? dispatch_trans<float, 64, 64, 2, 4>(a, d->trans_a, d->trans_b, ksplit, stream)
-                   : dispatch_trans<float, 64, 64, 2, 2>(a, d->trans_a, d->trans_b, ksplit, stream);
+    return dispatch_trans<float, 64, 64, 2, 4>(a, d->trans_a, d->trans_b, ksplit, stream);
+}
+
+extern "C" int univl_gemm_group(const UnivlGemm* d, int n, hipStream_t stream) {
+    UNIVL_CHECK_ARG(d != nullptr && n >= 1 && n <= UNIVL_GEMM_GROUP_MAX, UNIVL_EINVAL, "univl_gemm_group: n=%d (1..%d)", n,
+                    UNIVL_GEMM_GROUP_MAX);
+    if (n == 1) return univl_gemm(d, stream);
+    GroupArgs g;
+    bool big_all = true;
+    // the group runs one kernel instantiation: the 128x128 tile only if every member would pick it
+    for (int i = 0; i < n; ++i) {
+        UNIVL_CHECK_ARG(d[i].dtype == d[0].dtype && d[i].trans_a == d[0].trans_a && d[i].trans_b == d[0].trans_b, UNIVL_EINVAL,
+                        "univl_gemm_group: members must share dtype and operand layouts");
+        const long tiles128 = (long)((d[i].M + 127) / 128) * ((d[i].N + 127) / 128);
+        big_all = big_all && (d[i].tile == 128 || (d[i].tile == 0 && tiles128 >= 384));
+    }
+    int total = 0;
+    const int bm = big_all ? 128 : 64;
+    for (int i = 0; i < UNIVL_GEMM_GROUP_MAX; ++i) {
+        g.first[i] = total;
+        if (i >= n) { g.p[i] = g.p[0]; g.nx[i] = g.nxy[i] = g.nz[i] = 1; continue; }
+        UnivlGemm di = d[i];
+        di.tile = bm;
+        int ksplit, nc;
+        bool big;
+        const int rc = prepare(&di, g.p[i], ksplit, big, nc);
+        if (rc != UNIVL_OK) return rc;
+        g.nx[i] = (di.N + bm - 1) / bm;
+        g.nxy[i] = g.nx[i] * ((di.M + bm - 1) / bm);
+        g.nz[i] = ksplit;
+        total += g.nxy[i] * ksplit;
+    }
+    g.first[UNIVL_GEMM_GROUP_MAX] = total;
+    const bool ta = d[0].trans_a, tb = d[0].trans_b;
+#define UNIVL_GROUP_CASE(T, BMN, NCV)                                                                        \
+    do {                                                                                                     \
+        if (!ta && !tb) return launch_group<T, false, false, BMN, BMN, 2, NCV>(g, stream);                   \
+        if (!ta && tb) return launch_group<T, false, true, BMN, BMN, 2, NCV>(g, stream);                     \
+        if (ta && tb) return launch_group<T, true, true, BMN, BMN, 2, NCV>(g, stream);                       \
+        return launch_group<T, true, false, BMN, BMN, 2, NCV>(g, stream);                                    \
+    } while (0)
+    if (d[0].dtype == UNIVL_BF16) {
+        if (big_all) UNIVL_GROUP_CASE(__bf16, 128, 2);
+        UNIVL_GROUP_CASE(__bf16, 64, 4);
+    }
+    if (big_all) UNIVL_GROUP_CASE(float, 128, 2);
+    UNIVL_GROUP_CASE(float, 64, 4);
+#undef UNIVL_GROUP_CASE
 }

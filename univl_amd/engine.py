@@ -157,6 +157,19 @@ class Plan:
         self.keep.append(desc)
         self.ops.append(("call", fn, C.byref(desc), fn_name, stream))
 
+    def add_gemm_group(self, descs, stream=0):
+        """Independent GEMMs with the same operand layouts as ONE launch (univl_gemm_group), in chunks of GEMM_GROUP_MAX."""
+        fn = _lib.lib().univl_gemm_group
+        if os.environ.get("UNIVL_GROUP_WGRAD", "1") == "0":           # A/B switch: one launch per member
+            for d in descs:
+                self.add("univl_gemm", d, stream)
+            return
+        for i in range(0, len(descs), _lib.GEMM_GROUP_MAX):
+            chunk = descs[i:i + _lib.GEMM_GROUP_MAX]
+            arr = (_lib.Gemm * len(chunk))(*chunk)
+            self.keep.append(arr)
+            self.ops.append(("group", fn, (arr, len(chunk)), "univl_gemm_group", stream))
+
     def add_callable(self, f, stream=0):
         self.ops.append(("py", f, None, getattr(f, "__name__", "callable"), stream))
 
@@ -187,6 +200,13 @@ class Plan:
                 if h is None:
                     h = handles[sidx] = C.c_void_p(self._stream(sidx, cur).cuda_stream)
                 rc = a(b, h)
+                if rc != 0:
+                    _lib.check(rc, name)
+            elif kind == "group":
+                h = handles.get(sidx)
+                if h is None:
+                    h = handles[sidx] = C.c_void_p(self._stream(sidx, cur).cuda_stream)
+                rc = a(b[0], b[1], h)
                 if rc != 0:
                     _lib.check(rc, name)
             elif kind == "py":
@@ -350,11 +370,10 @@ class EncoderStack:
         """gin: fp32 [T,H] gradient wrt the last layer's output.  Returns the buffer holding the gradient wrt the
         stack input.  `gs` (GradState) decides beta = 0 / 1 per weight-gradient GEMM.
 
-        Stream `sm` carries the critical chain (LayerNorm backward -> dgrad -> ... -> dgrad); the four weight-gradient
-        GEMMs of a layer only CONSUME that chain's tensors, so they run on the side stream `ss` and rejoin at the
-        end of the layer (before scratch buffers are reused and before the layer's all-reduce bucket is launched)."""
+        The chain LayerNorm backward -> dgrad -> ... -> dgrad runs on stream `sm`; the four weight-gradient GEMMs of a
+        layer only CONSUME that chain's tensors and are issued as one grouped launch at the end of the layer."""
         fl, dt, T, H, I, S, B = self.flat, self.flat.dt, self.T, self.H, self.I, self.S, self.B
-        sm, ss = self.sm, self.ss
+        sm = self.sm
         p = self.p if training else 0.0
         if self.ks_h > 1:
             plan.add_callable(self.garena.zero_, stream=sm)
@@ -367,14 +386,12 @@ class EncoderStack:
                 dt, T, H, gamma=fl.w32(nm["ln2_g"]), y=ws["y2"], stats=ws["st2"], dout=gin, dx32=dz, dxd16=self.dxd,
                 dgamma=fl.g(nm["ln2_g"]), dbeta=fl.g(nm["ln2_b"]), dbias=fl.g(nm["b2"]), p_pre=p, off_pre=ws["off"][2],
                 seed_dev=self.seed_dev), sm)
-            plan.fork(sm, ss)
-            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, ws["f"], I, H, I, T, trans_a=1, trans_b=1,
-                                              out32=fl.g(nm["w2"]), ldc=I, accumulate=gs.acc(nm["w2"])), ss)
+            wgrads = [_gemm_desc(dt, self.dxd, H, ws["f"], I, H, I, T, trans_a=1, trans_b=1,
+                                 out32=fl.g(nm["w2"]), ldc=I, accumulate=gs.acc(nm["w2"]))]
             plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, fl.wop(nm["w2"]), I, T, I, H, trans_b=1, out16=self.du,
                                               ldc=I, aux=ws["u"], ldaux=I, gelu="bwd"), sm)
-            plan.fork(sm, ss)
-            plan.add("univl_gemm", _gemm_desc(dt, self.du, I, ws["a16"], H, I, H, T, trans_a=1, trans_b=1,
-                                              out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=fl.g(nm["b1"])), ss)
+            wgrads.append(_gemm_desc(dt, self.du, I, ws["a16"], H, I, H, T, trans_a=1, trans_b=1,
+                                     out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=fl.g(nm["b1"])))
             plan.add("univl_gemm", _gemm_desc(dt, self.du, I, fl.wop(nm["w1"]), H, T, H, I, trans_b=1, out32=da, ldc=H,
                                               residual=dz, ldr=H, ksplit=self.ksplit_for(I)), sm)
             # attention-output LayerNorm / dropout backward (BertSelfOutput, module_bert.py:207-211)
@@ -383,23 +400,23 @@ class EncoderStack:
                 dt, T, H, gamma=fl.w32(nm["ln1_g"]), y=ws["y1"], stats=ws["st1"], dout=da, dx32=dy, dxd16=self.dxd2,
                 dgamma=fl.g(nm["ln1_g"]), dbeta=fl.g(nm["ln1_b"]), dbias=fl.g(nm["o_b"]), p_pre=p, off_pre=ws["off"][1],
                 seed_dev=self.seed_dev), sm)
-            plan.fork(sm, ss)
-            plan.add("univl_gemm", _gemm_desc(dt, self.dxd2, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
-                                              out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"])), ss)
+            wgrads.append(_gemm_desc(dt, self.dxd2, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
+                                     out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"])))
             plan.add("univl_gemm", _gemm_desc(dt, self.dxd2, H, fl.wop(nm["o_w"]), H, T, H, H, trans_b=1, out16=self.dctx, ldc=H), sm)
             qkv, dqkv = ws["qkv"], self.dqkv
             plan.add("univl_attention_bwd", ops.attention_desc(
                 dt, B, self.NH, S, S, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx"], H, ws["lse"],
                 key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev, dout=self.dctx, lddo=H,
                 dq=(dqkv, 0), lddq=3 * H, dk=(dqkv, H), lddk=3 * H, dv=(dqkv, 2 * H), lddv=3 * H), sm)
-            plan.fork(sm, ss)
-            plan.add("univl_gemm", _gemm_desc(dt, dqkv, 3 * H, xin16, H, 3 * H, H, T, trans_a=1, trans_b=1,
-                                              out32=fl.g_fused(nm["qkv_w"]), ldc=H, accumulate=gs.acc(nm["qkv_w"][0]),
-                                              dbias=fl.g_fused(nm["qkv_b"])), ss)
+            wgrads.append(_gemm_desc(dt, dqkv, 3 * H, xin16, H, 3 * H, H, T, trans_a=1, trans_b=1,
+                                     out32=fl.g_fused(nm["qkv_w"]), ldc=H, accumulate=gs.acc(nm["qkv_w"][0]),
+                                     dbias=fl.g_fused(nm["qkv_b"])))
             dx = self.garena[l, 1]
             plan.add("univl_gemm", _gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["qkv_w"]), H, T, H, 3 * H, trans_b=1,
                                               out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ksplit_for(3 * H)), sm)
-            plan.join(ss, sm)      # scratch (dxd, dxd2, du, dqkv) is reused by the next layer; grads of layer l done
+            # the layer's four weight-gradient GEMMs only consume tensors the chain above produced (dxd, du, dxd2, dqkv
+            # are distinct buffers): one grouped launch, after which the scratch may be reused by the next layer
+            plan.add_gemm_group(wgrads, sm)
             gin = dx
             if layer_hook is not None:
                 layer_hook(plan, self.prefix, l, sm)

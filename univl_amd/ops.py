@@ -46,9 +46,8 @@ def probe_layouts():
     return out
 
 
-def gemm(A, B, M, N, K, *, trans_a=False, trans_b=False, out32=None, out16=None, bias=None, residual=None, aux=None,
-         gelu=None, accumulate=False, dbias=None, dbias_atomic=False, ksplit=1, tile=0, alpha=1.0):
-    """C[M,N] = epi(alpha * A_op . B_op^T); A/B are 2-D row-major views ([rows,K] or, if trans_x, [K,rows])."""
+def gemm_desc(A, B, M, N, K, *, trans_a=False, trans_b=False, out32=None, out16=None, bias=None, residual=None, aux=None,
+              gelu=None, accumulate=False, dbias=None, dbias_atomic=False, ksplit=1, tile=0, alpha=1.0):
     _require_gpu(A, B, out32, out16)
     d = _lib.Gemm()
     d.dtype = dtype_code(A.dtype)
@@ -75,7 +74,19 @@ def gemm(A, B, M, N, K, *, trans_a=False, trans_b=False, out32=None, out16=None,
     if dbias_atomic:
         flags |= _lib.GEMM_DBIAS_ATOMIC
     d.flags, d.ksplit, d.tile = flags, ksplit, tile
+    return d
+
+
+def gemm(A, B, M, N, K, **kw):
+    """C[M,N] = epi(alpha * A_op . B_op^T); A/B are 2-D row-major views ([rows,K] or, if trans_x, [K,rows])."""
+    d = gemm_desc(A, B, M, N, K, **kw)
     _lib.check(_lib.lib().univl_gemm(_BYREF(d), _stream()), "gemm")
+
+
+def gemm_group(descs):
+    """Independent GEMMs (same dtype and operand layouts, at most GEMM_GROUP_MAX) in one launch."""
+    arr = (_lib.Gemm * len(descs))(*descs)
+    _lib.check(_lib.lib().univl_gemm_group(arr, len(descs), _stream()), "gemm_group")
 
 
 def layernorm_desc(dtype, rows, N, *, x=None, x_f64=False, residual=None, pos=None, pos_period=0, gamma=None,
