@@ -32,6 +32,9 @@ def get_args():
     ap.add_argument("--batch", type=int, default=4, help="pairs per GPU per step (configs[1]: bs=4)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--loopback", action="store_true",
+                    help="single GPU: run the data-parallel schedule (exchange points, segmented hipGraphs) with identity "
+                         "exchanges on a communication stream -- exercises the N>1 code path without a second GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--profile-tag", default="")
@@ -144,6 +147,8 @@ def main():
     model.to(dev).train()
     if world > 1:
         model.enable_data_parallel()
+    elif args.loopback:
+        model.enable_data_parallel(loopback=True)
     opt = make_optimizer(model, BertAdam)
     n_params = sum(p.numel() for n, p in model.named_parameters() if ".pooler." not in n)
 
@@ -167,34 +172,41 @@ def main():
         opt.zero_grad()
         return loss
 
-    # eager warm-up (builds plans / tables), then hipGraph capture of the whole step for the single-GPU run
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(3):
-            loss = step_body()
-            float(loss)
-    torch.cuda.current_stream().wait_stream(side)
+    # eager warm-up (builds plans / tables), then hipGraph replay of the whole step (univl_amd.graphed): one graph on a
+    # single GPU; with a gradient exchange the collectives stay on the host between captured segments
+    for _ in range(3):
+        float(step_body())
     torch.cuda.synchronize()
-    graph = None
-    use_graph = (not args.no_graph) and world == 1
-    if use_graph:
+    gstep, mode = None, "eager"
+    if not args.no_graph:
+        from univl_amd.graphed import GraphedTrainStep
+        gstep = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=0, persistent_inputs=True)
+        g_args = (inputs["input_ids"], inputs["token_type_ids"], inputs["attention_mask"], inputs["video"], inputs["video_mask"])
+        g_kw = dict(pairs_masked_text=inputs["input_ids"], pairs_token_labels=None, masked_video=inputs["video"],
+                    video_labels_index=None)
+        ok = 1
         try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_loss = step_body()
-            graph.replay()
+            float(gstep(*g_args, **g_kw))
             torch.cuda.synchronize()
-            float(static_loss)
         except Exception as ex:      # noqa: BLE001
-            print("[bench] hipGraph capture failed (%s: %s); running eagerly" % (type(ex).__name__, ex), file=sys.stderr)
-            graph = None
+            print("[bench] rank %d: hipGraph capture failed (%s: %s); running eagerly" % (rank, type(ex).__name__, ex),
+                  file=sys.stderr)
+            ok = 0
+        if dist is not None:         # every rank must take the same path
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag)
+        if ok:
+            mode = gstep.mode
+        else:
+            gstep = None
+            model.graph_backward = False
             torch.cuda.synchronize()
+    graph = gstep
 
     def one_step():
-        if graph is not None:
-            graph.replay()
-            return float(static_loss)          # D2H sync every step, as main_task_retrieval.py:344
+        if gstep is not None:
+            return float(gstep(*g_args, **g_kw))     # D2H sync every step, as main_task_retrieval.py:344
         return float(step_body())
 
     for _ in range(args.warmup):
@@ -253,7 +265,7 @@ def main():
                                         "encoder (12 L) + 6-layer visual encoder, max_words=48, max_frames=48, bs=%d per GPU, "
                                         "fwd+bwd+clip+BertAdam, dropout %.2f, random-init weights" % (args.batch, args.dropout),
                                per_gpu_batch=args.batch, global_batch=args.batch * world, max_words=48, max_frames=48,
-                               parallelism="dp%d" % world, hip_graph=graph is not None, params=n_params,
+                               parallelism="dp%d" % world, hip_graph=graph is not None, graph_mode=mode, params=n_params,
                                last_loss=round(last, 6)),
                    roofline=roofline, cpu_baseline=cpu_base)
         print(json.dumps(out))

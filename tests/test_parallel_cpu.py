@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from univl_amd.parallel import BucketReducer
+from univl_amd.parallel import BucketReducer, BucketSchedule, merge_ranges
 
 
 def _free_port():
@@ -25,9 +25,16 @@ def _worker(rank, world, port, q):
     g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
     red = BucketReducer(g)
     # layer buckets in backward order, then the tail -- every element exactly once
+    sched = BucketSchedule(min_bytes=2000)
+    issued = []
     for s, e in ((600, 900), (300, 600), (0, 300), (900, 1000)):
-        red.reduce_slice(s, e)
+        if sched.add(s, e):
+            issued.append(sched.take())
+            red.reduce_ranges(issued[-1])
+    issued.append(sched.take())
+    red.reduce_ranges(issued[-1])
     red.join()
+    assert issued == [[(300, 900)], [(0, 300), (900, 1000)]]
     expect = torch.arange(1000, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
     ok = torch.allclose(g, expect) and red.bytes_reduced == 4000 and not red.pending
     q.put((rank, bool(ok)))
@@ -53,3 +60,11 @@ def test_bucket_reducer_single_process_is_noop():
     red.reduce_slice(0, 10)
     red.join()
     assert torch.equal(g, torch.ones(10)) and red.bytes_reduced == 0
+
+
+def test_bucket_schedule_and_merge():
+    assert merge_ranges([(10, 20), (0, 10), (30, 40), (35, 50), (5, 5)]) == [(0, 20), (30, 50)]
+    s = BucketSchedule(min_bytes=100, elem_bytes=4)
+    assert not s.add(0, 10) and s.add(10, 30)
+    assert s.take() == [(0, 30)] and s.take() == [] and s.cuts == [[(0, 30)]]
+    assert s.add(100, 200) and s.take() == [(100, 200)]

@@ -151,6 +151,7 @@ class Plan:
         self.ops = []
         self.keep = []
         self._side = {}
+        self._segments = None
 
     def add(self, fn_name, desc, stream=0):
         fn = getattr(_lib.lib(), fn_name)
@@ -170,8 +171,11 @@ class Plan:
             self.keep.append(arr)
             self.ops.append(("group", fn, (arr, len(chunk)), "univl_gemm_group", stream))
 
-    def add_callable(self, f, stream=0):
-        self.ops.append(("py", f, None, getattr(f, "__name__", "callable"), stream))
+    def add_callable(self, f, stream=0, eager=False):
+        """eager=True marks host-driven work that must never be captured into a hipGraph (RCCL collectives): run()
+        treats it like any callable, run_graphed() replays the captured kernels on either side of it and calls it
+        in between, on the calling stream."""
+        self.ops.append(("eager" if eager else "py", f, None, getattr(f, "__name__", "callable"), stream))
 
     def fork(self, src, dst):
         """dst waits for all work enqueued on src so far."""
@@ -190,10 +194,9 @@ class Plan:
             self._side[idx] = st
         return st
 
-    def run(self, upto=None):
-        cur = torch.cuda.current_stream()
+    def _run_ops(self, ops_, cur):
         handles = {}
-        for op in (self.ops if upto is None else self.ops[:upto]):
+        for op in ops_:
             kind, a, b, name, sidx = op
             if kind == "call":
                 h = handles.get(sidx)
@@ -209,6 +212,11 @@ class Plan:
                 rc = a(b[0], b[1], h)
                 if rc != 0:
                     _lib.check(rc, name)
+            elif kind == "eager":
+                for sd in self._side.values():             # host-driven exchange point: everything planned so far
+                    if sd.device == cur.device:
+                        cur.wait_stream(sd)
+                a()
             elif kind == "py":
                 if sidx == 0:
                     a()
@@ -217,6 +225,57 @@ class Plan:
                         a()
             else:
                 self._stream(b, cur).wait_stream(self._stream(a, cur))
+
+    def run(self, upto=None):
+        self._run_ops(self.ops if upto is None else self.ops[:upto], torch.cuda.current_stream())
+
+    def segments(self):
+        """[("graph", ops) | ("eager", op), ...]: maximal runs of capturable ops between eager ops."""
+        out, cur = [], []
+        for op in self.ops:
+            if op[0] == "eager":
+                if cur:
+                    out.append(("graph", cur))
+                    cur = []
+                out.append(("eager", op))
+            else:
+                cur.append(op)
+        if cur:
+            out.append(("graph", cur))
+        return out
+
+    def run_graphed(self):
+        """Replay the plan as hipGraphs: every run of kernels between two eager ops is captured once (on first use)
+        and replayed afterwards; eager ops (collectives) are issued from the host between the replays, on the calling
+        stream.  A captured segment must be self-contained, so side streams are forked from the capture stream at
+        its start and joined back at its end -- a cut inside a forked region costs one extra join, never correctness."""
+        if self._segments is None:
+            segs = []
+            for kind, payload in self.segments():
+                if kind == "eager":
+                    segs.append(["eager", payload, None])
+                else:
+                    sides = sorted({op[4] for op in payload if op[0] != "dep" and op[4] != 0}
+                                   | {x for op in payload if op[0] == "dep" for x in (op[1], op[2]) if x != 0})
+                    segs.append(["graph", payload, None, sides])
+            self._segments = segs
+        for seg in self._segments:
+            if seg[0] == "eager":
+                seg[1][1]()
+                continue
+            if seg[2] is None:
+                g = torch.cuda.CUDAGraph()
+                # thread_local: RCCL's watchdog thread may query events of in-flight collectives during the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    cur = torch.cuda.current_stream()
+                    sides = [self._stream(i, cur) for i in seg[3]]
+                    for sd in sides:
+                        sd.wait_stream(cur)
+                    self._run_ops(seg[1], cur)
+                    for sd in sides:
+                        cur.wait_stream(sd)
+                seg[2] = g
+            seg[2].replay()
 
     @property
     def calls(self):
@@ -367,8 +426,16 @@ class EncoderStack:
 
     # ----------------------------------------------------------------------------------------- backward
     def build_backward(self, plan, gin, x0_32, x0_16, gs, training, layer_hook=None):
-        """gin: fp32 [T,H] gradient wrt the last layer's output.  Returns the buffer holding the gradient wrt the
-        stack input.  `gs` (GradState) decides beta = 0 / 1 per weight-gradient GEMM.
+        """Emit the whole backward; returns the buffer holding the gradient wrt the stack input."""
+        for _ in self.backward_layers(plan, gin, x0_32, x0_16, gs, training, layer_hook):
+            pass
+        return self.bwd_out
+
+    def backward_layers(self, plan, gin, x0_32, x0_16, gs, training, layer_hook=None):
+        """Generator form: emits one layer per next() (last layer first) so that a caller can interleave two stacks in
+        plan order; self.bwd_out holds the gradient wrt the stack input once exhausted.
+        gin: fp32 [T,H] gradient wrt the last layer's output.  `gs` (GradState) decides beta = 0 / 1 per
+        weight-gradient GEMM.
 
         The chain LayerNorm backward -> dgrad -> ... -> dgrad runs on stream `sm`; the four weight-gradient GEMMs of a
         layer only CONSUME that chain's tensors and are issued as one grouped launch at the end of the layer."""
@@ -420,7 +487,9 @@ class EncoderStack:
             gin = dx
             if layer_hook is not None:
                 layer_hook(plan, self.prefix, l, sm)
-        return gin
+            self.bwd_out = gin
+            yield l
+        self.bwd_out = gin
 
 
 class DecoderStack:

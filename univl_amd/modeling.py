@@ -368,6 +368,7 @@ class UniVL(UniVLPreTrainedModel):
         assert bert_config.hidden_size == 768 and bert_config.num_attention_heads == 12 and \
             bert_config.intermediate_size == 3072, "kernels are specialised for H=768, 12 heads, I=3072"
 
+        self.graph_backward = False
         self._stage_one, self._stage_two = True, False
         if _check_attr("stage_two", tc):
             self._stage_one, self._stage_two = False, tc.stage_two
@@ -448,7 +449,7 @@ class UniVL(UniVLPreTrainedModel):
             self._steps = {}
         return self._flat
 
-    def enable_data_parallel(self, process_group=None, broadcast=True):
+    def enable_data_parallel(self, process_group=None, broadcast=True, loopback=False):
         """Re-homes the reference's DDP wrap (main_task_retrieval.py:197-198) onto per-layer RCCL all-reduces of
         the flat gradient buffer, overlapped with backward (univl_amd.parallel).  Call after model.to(device) and
         torch.distributed.init_process_group; with world_size 1 it is a no-op."""
@@ -456,8 +457,8 @@ class UniVL(UniVLPreTrainedModel):
         if broadcast:
             broadcast_parameters(fl.p32, 0, process_group)
             fl.shadow_valid = False
-        self._reducer = BucketReducer(fl.g32, process_group)
-        if self._reducer.world == 1:
+        self._reducer = BucketReducer(fl.g32, process_group, loopback=loopback)
+        if not self._reducer.active:
             self._reducer = None
         self._steps = {}
         return self
@@ -507,7 +508,11 @@ class UniVL(UniVLPreTrainedModel):
         else:
             st.gout.copy_(gout.reshape(1).to(torch.float32))
         fl.grad_version += 1
-        st.backward_plan(fresh).run()
+        plan = st.backward_plan(fresh)
+        if self.graph_backward and not torch.cuda.is_current_stream_capturing():
+            plan.run_graphed()          # captured segments + host-issued gradient exchange (univl_amd.graphed)
+        else:
+            plan.run()
         fl.attach_grads(used)
 
     def forward(self, input_ids, token_type_ids, attention_mask, video, video_mask=None,

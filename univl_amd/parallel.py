@@ -16,36 +16,108 @@ import torch.distributed as dist
 
 
 class BucketReducer:
-    """All-reduce (mean) contiguous slices of a flat gradient buffer, asynchronously, in a fixed order."""
+    """All-reduce (mean) contiguous slices of a flat gradient buffer, asynchronously, in a fixed order.
 
-    def __init__(self, flat_grad, process_group=None):
+    loopback=True is a single-process stand-in used by the single-GPU tests and `bench.py --loopback`: every "exchange"
+    is an identity pass over the slice on a private communication stream, with the same event choreography as the
+    RCCL path (wait for the producer stream, run asynchronously, join before the optimizer) -- so that the bucket
+    schedule, the exchange points and the hipGraph segmentation around them run without a second GPU."""
+
+    def __init__(self, flat_grad, process_group=None, loopback=False):
         self.g = flat_grad
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.loopback = bool(loopback)
+        self.world = dist.get_world_size(process_group) if (dist.is_initialized() and not loopback) else 1
         self.pending = []
         self.bytes_reduced = 0
-        backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
+        self.calls = 0
+        backend = dist.get_backend(process_group) if (dist.is_initialized() and not loopback) else "none"
         self._avg = backend == "nccl"
+        self._comm = None
+
+    @property
+    def active(self):
+        return self.world > 1 or self.loopback
 
     def reduce_slice(self, start, end):
         """Launch the all-reduce of g[start:end]; returns immediately (the collective is stream-/thread-async)."""
-        if self.world == 1 or end <= start:
+        if not self.active or end <= start:
             return
         t = self.g[start:end]
+        self.calls += 1
+        self.bytes_reduced += t.numel() * t.element_size()
+        if self.loopback:
+            if t.is_cuda:
+                if self._comm is None:
+                    self._comm = torch.cuda.Stream(device=t.device)
+                cur = torch.cuda.current_stream()
+                self._comm.wait_stream(cur)
+                with torch.cuda.stream(self._comm):
+                    t.mul_(1.0)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                self.pending.append((ev, t))
+            return
         if self._avg:
             w = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
         else:
             w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self.pending.append((w, t))
-        self.bytes_reduced += t.numel() * t.element_size()
+
+    def reduce_ranges(self, ranges):
+        for s0, e0 in ranges:
+            self.reduce_slice(s0, e0)
 
     def join(self):
         """Make the current stream (or thread, for gloo) wait for every outstanding bucket."""
         for w, t in self.pending:
+            if self.loopback:
+                torch.cuda.current_stream().wait_event(w)
+                continue
             w.wait()
             if not self._avg:
                 t.div_(self.world)
         self.pending = []
+
+
+def merge_ranges(ranges):
+    """Sort [start, end) ranges and fuse the ones that touch or overlap."""
+    out = []
+    for s0, e0 in sorted(ranges):
+        if e0 <= s0:
+            continue
+        if out and s0 <= out[-1][1]:
+            out[-1] = (out[-1][0], max(out[-1][1], e0))
+        else:
+            out.append((s0, e0))
+    return out
+
+
+class BucketSchedule:
+    """Where the gradient exchange points go.  Layers report their gradient slice as soon as their last weight-gradient
+    kernel has been planned (backward order); once at least `min_bytes` are pending, the caller emits one exchange
+    point for everything pending (adjacent layers fuse into one contiguous all-reduce).  Few, large exchanges: an
+    xGMI ring all-reduce is bandwidth-bound per link, and under hipGraph replay every exchange point ends a captured
+    segment (univl_amd.engine.Plan.run_graphed)."""
+
+    def __init__(self, min_bytes, elem_bytes=4):
+        self.min_bytes, self.elem = int(min_bytes), elem_bytes
+        self.pending, self.pending_bytes = [], 0
+        self.cuts = []
+
+    def add(self, start, end):
+        """Returns True when an exchange point is due."""
+        if end > start:
+            self.pending.append((start, end))
+            self.pending_bytes += (end - start) * self.elem
+        return self.pending_bytes >= self.min_bytes
+
+    def take(self):
+        r = merge_ranges(self.pending)
+        self.pending, self.pending_bytes = [], 0
+        if r:
+            self.cuts.append(r)
+        return r
 
 
 def layer_buckets(flat, used_names):

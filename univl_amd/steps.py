@@ -118,7 +118,26 @@ class EncoderPass:
         W32, G, p, B, W, F, D, Tv = fl.w32, fl.g, cx.p, self.B, self.W, self.F, self.D, self.Tv
         ST, SV = self.ST, self.SV
         bwd.fork(ST, SV)
-        dxv = self.vis.build_backward(bwd, self.dvis, self.v0_32, self.v0_16, gs, cx.training, layer_hook=hook)
+        # The two stacks are independent until the join below and run on two streams; they are emitted INTERLEAVED
+        # (text layers : video layers in the ratio of their depths) so that plan order follows time order -- gradient
+        # exchange points and hipGraph segment cuts (Plan.run_graphed) then fall between layers of both stacks.
+        gv = self.vis.backward_layers(bwd, self.dvis, self.v0_32, self.v0_16, gs, cx.training, layer_hook=hook)
+        gt = self.text.backward_layers(bwd, self.dseq, self.t0_32, self.t0_16, gs, cx.training, layer_hook=hook)
+        ratio = max(1, int(round(self.text.L / max(1, self.vis.L))))
+        done_t = done_v = False
+        while not (done_t and done_v):
+            for _ in range(ratio):
+                if not done_t and next(gt, None) is None:
+                    done_t = True
+                    self._text_tail(bwd, self.text.bwd_out)
+            if not done_v and next(gv, None) is None:
+                done_v = True
+                self._video_tail(bwd, gs, self.vis.bwd_out)
+        bwd.join(SV, ST)
+
+    def _video_tail(self, bwd, gs, dxv):
+        cx, n, fl, dt = self.cx, self.N, self.cx.fl, self.cx.dt
+        W32, G, p, F, D, Tv, SV = fl.w32, fl.g, cx.p, self.F, self.D, self.Tv, self.SV
         bwd.add("univl_layernorm_bwd", ops.layernorm_desc(
             dt, Tv, H, gamma=W32(n["vlg"]), y=self.ve, stats=self.vest, dout=dxv, dxd16=self.de_op, dgamma=G(n["vlg"]),
             dbeta=G(n["vlb"]), dbias=G(n["vb"]), dpos=G(n["vpos"]), pos_period=F, p_post=p, seed=cx.seed, off_post=self.off_v,
@@ -129,13 +148,15 @@ class EncoderPass:
                                          accumulate=True), SV)
         bwd.add("univl_layernorm_bwd", ops.layernorm_desc(
             dt, Tv, D, gamma=W32(n["nv_g"]), y=self.vy, stats=self.vst, dout=self.dvnorm, dgamma=G(n["nv_g"]), dbeta=G(n["nv_b"])), SV)
-        dxt = self.text.build_backward(bwd, self.dseq, self.t0_32, self.t0_16, gs, cx.training, layer_hook=hook)
+
+    def _text_tail(self, bwd, dxt):
+        cx, n, fl, dt = self.cx, self.N, self.cx.fl, self.cx.dt
+        W32, G, p, B, W, ST = fl.w32, fl.g, cx.p, self.B, self.W, self.ST
         bwd.add("univl_embed_text_bwd", ops.embed_text_desc(
             dt, B, W, self.ids, W32(n["bw"]), W32(n["bp"]), W32(n["blg"]), W32(n["blb"]), type_ids=self.type_ids,
             type_emb=W32(n["bt"]), y=self.te, stats=self.test, p_post=p, seed=cx.seed, off_post=self.off_t,
             seed_dev=cx.seed_dev, dout=dxt, dword=G(n["bw"]), dpos=G(n["bp"]), dtype_emb=G(n["bt"]), dgamma=G(n["blg"]),
             dbeta=G(n["blb"])), ST)
-        bwd.join(SV, ST)
 
 
 class SimLoss:
@@ -535,18 +556,26 @@ class Step:
 
 
 def _ddp_hook(cx, fl, model):
+    """Gradient exchange points for the data-parallel path (univl_amd.parallel): the hook is called by every encoder
+    stack after each layer (backward order) and emits an eager all-reduce once UNIVL_BUCKET_MB of gradients are
+    pending."""
     red = cx.red
     if red is None:
-        return None, None
-    from .parallel import layer_buckets
+        return None, None, None
+    from .parallel import BucketSchedule, layer_buckets
     buckets = layer_buckets(fl, model.used_parameter_names())
+    sched = BucketSchedule(float(os.environ.get("UNIVL_BUCKET_MB", "80")) * 2 ** 20)
+
+    def emit(plan):
+        ranges = sched.take()
+        if ranges:
+            plan.add_callable(lambda: red.reduce_ranges(ranges), eager=True)
 
     def hook(plan, prefix, l, stream):
         key = (prefix, l)
-        if key in buckets["layers"]:
-            s0, e0 = buckets["layers"][key]
-            plan.add_callable(lambda: red.reduce_slice(s0, e0), stream=stream)
-    return hook, buckets
+        if key in buckets["layers"] and sched.add(*buckets["layers"][key]):
+            emit(plan)
+    return hook, buckets, (sched, emit)
 
 
 def build_step(model, kind, B, W, F, training):
@@ -613,7 +642,7 @@ def build_step(model, kind, B, W, F, training):
     def build_bwd(fresh):
         bwd = Plan()
         gs = GradState(fl, fresh)
-        hook, buckets = _ddp_hook(cx, fl, model)
+        hook, buckets, sched = _ddp_hook(cx, fl, model)
         if fresh:
             bwd.add_callable(fl.g32[:fl.v_end].zero_)
         enc.zero_grads(bwd)
@@ -640,10 +669,11 @@ def build_step(model, kind, B, W, F, training):
             st.enc_m.build_backward(bwd, gs, hook)
         enc.build_backward(bwd, gs, hook)
         if cx.red is not None:
-            done = set(buckets["layers"].values())
             for (s0, e0) in buckets["tail"]:
-                bwd.add_callable(lambda s0=s0, e0=e0: cx.red.reduce_slice(s0, e0))
-            bwd.add_callable(cx.red.join)
+                sched[0].add(s0, e0)
+            sched[1](bwd)                                  # whatever is still pending + the tail
+            bwd.add_callable(cx.red.join, eager=True)
+            st.exchange_points = list(sched[0].cuts)
         return bwd
 
     st._build_bwd = build_bwd
