@@ -345,13 +345,15 @@ def test_embed_text_fwd_bwd(dtype):
 
 
 # ------------------------------------------------------------------------------------- pooling and losses
-def test_pool_fwd_bwd():
-    B, S = 5, 20
+@pytest.mark.parametrize("B,S", [(5, 20), (3, 300), (4, 48)])
+def test_pool_fwd_bwd(B, S):
     x = gen(B, S, 768, seed=1)
     g = torch.Generator().manual_seed(2)
     mask = (torch.arange(S)[None] < torch.randint(2, S + 1, (B, 1), generator=g)).long()
     vmask = mask.clone(); vmask[2] = 0                    # a video with zero valid frames (guarded count)
-    xr = x.double().requires_grad_(True)
+    x[1, -1] = float("inf")                               # garbage at a padded position must not leak (row 1 is masked there)
+    mask[1, -1] = 0; vmask[1, -1] = 0
+    xr = torch.nan_to_num(x, posinf=0.0).double().requires_grad_(True)
     t_ref, v_ref = O.mean_pooling_for_similarity(xr, xr, mask, vmask)
     t_ref, v_ref = torch.nn.functional.normalize(t_ref, dim=-1), torch.nn.functional.normalize(v_ref, dim=-1)
     dout = gen(B, 768, seed=3)
@@ -363,6 +365,26 @@ def test_pool_fwd_bwd():
         ref.backward(dout.double(), retain_graph=True)
         ops.pool_bwd(B, S, x.to(DEV), m.to(DEV), skip_first=skip_first, normalize=True, mean=mean, out=out, dout=dout.to(DEV), dx=dx)
         assert rel_err(dx, xr.grad) < 1e-5
+        base = gen(B, S, 768, seed=9).to(DEV)
+        dx2 = base.clone()
+        ops.pool_bwd(B, S, x.to(DEV), m.to(DEV), skip_first=skip_first, normalize=True, mean=mean, out=out, dout=dout.to(DEV), dx=dx2,
+                     accumulate=True)
+        assert rel_err(dx2 - base, xr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(4, 4, 768), (16, 16, 768), (32, 7, 1023), (1, 1, 5)])
+def test_gemm_small_fp32_dot_path(M, N, K):
+    """B x B similarity products (modeling.py:389) take the one-workgroup-per-output path."""
+    Kp = (K + 3) // 4 * 4
+    A = torch.zeros(M, Kp); A[:, :K] = gen(M, K, seed=1)
+    B_ = torch.zeros(N, Kp); B_[:, :K] = gen(N, K, seed=2)
+    out = torch.full((M, 40), 2.0, device=DEV)
+    ops.gemm(A.to(DEV), B_.to(DEV), M, N, K, out32=out, alpha=0.5)
+    ref = 0.5 * (A.double()[:, :K] @ B_.double()[:, :K].T)
+    assert rel_err(out[:, :N], ref) < 1e-5
+    assert float((out[:, N:] - 2.0).abs().max()) == 0.0
+    ops.gemm(A.to(DEV), B_.to(DEV), M, N, K, out32=out, alpha=0.5, accumulate=True)
+    assert rel_err(out[:, :N], 2 * ref) < 1e-5
 
 
 @pytest.mark.parametrize("n", [4, 16, 37])

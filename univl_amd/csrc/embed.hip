@@ -79,11 +79,12 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(UnivlEmbedText p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     const bool valid = row < p.B * p.S;
-    float dgm[NV][4], dbt[NV][4];
+    float dgm[NV][4], dbt[NV][4], dxs[NV][4];
+    int row_type = -1;
 #pragma unroll
     for (int j = 0; j < NV; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { dgm[j][e] = 0.f; dbt[j][e] = 0.f; }
+        for (int e = 0; e < 4; ++e) { dgm[j][e] = 0.f; dbt[j][e] = 0.f; dxs[j][e] = 0.f; }
     if (valid) {
         const int s = row % p.S;
         const long id = p.ids[row];
@@ -123,22 +124,30 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(UnivlEmbedText p) {
                 const float dx = rstd * (dy[j][e] * ga[j][e] - s1 - xh[j][e] * s2);
                 unsafeAtomicAdd(p.dword + id * N + col + e, dx);
                 unsafeAtomicAdd(p.dpos + (long)s * N + col + e, dx);
-                if (p.dtype_emb) unsafeAtomicAdd(p.dtype_emb + tt * N + col + e, dx);
+                // token types 0 / 1 (every row of a batch hits the same one or two table rows) are combined per
+                // block below; anything else goes straight to the table
+                if (p.dtype_emb && tt > 1) unsafeAtomicAdd(p.dtype_emb + tt * N + col + e, dx);
+                dxs[j][e] = dx;
             }
         }
+        row_type = (int)tt;
     }
-    // dgamma / dbeta: combine the 4 rows of the block, one atomic per column per block
+    // dgamma / dbeta / token-type rows 0 and 1: combine the 4 rows of the block, one atomic per column per block
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 4; ++t) {
+        if (t >= 2 && !p.dtype_emb) break;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) red[wave][4 * lane + 256 * j + e] = t == 0 ? dgm[j][e] : dbt[j][e];
+            for (int e = 0; e < 4; ++e)
+                red[wave][4 * lane + 256 * j + e] = t == 0 ? dgm[j][e] : t == 1 ? dbt[j][e] : (row_type == t - 2 ? dxs[j][e] : 0.f);
         __syncthreads();
-        float* dst = t == 0 ? p.dgamma : p.dbeta;
-        for (int c = threadIdx.x; c < N; c += 256)
-            unsafeAtomicAdd(dst + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+        float* dst = t == 0 ? p.dgamma : t == 1 ? p.dbeta : p.dtype_emb + (long)(t - 2) * N;
+        for (int c = threadIdx.x; c < N; c += 256) {
+            const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+            if (t < 2 || v != 0.0f) unsafeAtomicAdd(dst + c, v);
+        }
     }
 }
 

@@ -442,6 +442,33 @@ int dispatch_trans(const GemmArgs& a, int ta, int tb, int ksplit, hipStream_t s)
 
 }  // namespace
 
+// fp32 products with at most 32 x 32 outputs (the B x B similarity matrix of modeling.py:389 at small batch): one
+// workgroup per output element, a 256-lane dot product -- the tiled kernel would run K/64 dependent steps for one tile.
+__global__ __launch_bounds__(256) void dot_kernel(GemmArgs p) {
+    __shared__ float red[4];
+    const int n = blockIdx.x, m = blockIdx.y, t = threadIdx.x;
+    const float* a = reinterpret_cast<const float*>(p.A) + (long)m * p.lda;
+    const float* b = reinterpret_cast<const float*>(p.B) + (long)n * p.ldb;
+    float acc = 0.f;
+    const int k4 = p.K & ~3;
+    for (int k = 4 * t; k < k4; k += 1024) {
+        const float4 x = *reinterpret_cast<const float4*>(a + k);
+        const float4 y = *reinterpret_cast<const float4*>(b + k);
+        acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    }
+    if (t < p.K - k4) acc += a[k4 + t] * b[k4 + t];
+    acc = wave_sum(acc);
+    if ((t & 63) == 0) red[t >> 6] = acc;
+    __syncthreads();
+    if (t == 0) {
+        float v = ((red[0] + red[1]) + (red[2] + red[3])) * p.alpha;
+        const long o = (long)m * p.ldc + n;
+        if (p.flags & UNIVL_GEMM_ACCUM) v += p.C32[o];
+        if (p.C32) p.C32[o] = v;
+        if (p.C16) reinterpret_cast<float*>(p.C16)[o] = v;
+    }
+}
+
 // validation + kernel arguments shared by the single and the grouped entry point
 static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, bool& big, int& nc) {
     UNIVL_CHECK_ARG(d != nullptr, UNIVL_EINVAL, "univl_gemm: null descriptor");
@@ -485,6 +512,12 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
     bool big;
     const int rc = prepare(d, a, ksplit, big, nc);
     if (rc != UNIVL_OK) return rc;
+    if (d->dtype == UNIVL_F32 && !d->trans_a && !d->trans_b && d->M <= 32 && d->N <= 32 && ksplit == 1 && d->tile == 0 &&
+        !d->bias && !d->R && !d->dbias && !(d->flags & (UNIVL_GEMM_GELU_FWD | UNIVL_GEMM_GELU_BWD))) {
+        hipLaunchKernelGGL(dot_kernel, dim3(d->N, d->M), dim3(256), 0, stream, a);
+        UNIVL_LAUNCH_CHECK();
+        return UNIVL_OK;
+    }
     if (d->dtype == UNIVL_BF16) {
         if (big) return dispatch_trans<__bf16, 128, 128, 2, 2>(a, d->trans_a, d->trans_b, ksplit, stream);
         return dispatch_trans<__bf16, 64, 64, 2, 4>(a, d->trans_a, d->trans_b, ksplit, stream);

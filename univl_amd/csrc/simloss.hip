@@ -35,19 +35,38 @@ __device__ __forceinline__ float pool_weight(const UnivlPool& p, int b, int s) {
     return w;
 }
 
+// One workgroup per pooled row.  The S mask weights are staged in LDS once (a serial "read mask, maybe read row" loop
+// is S dependent L2 round trips); the row loop then issues independent, unconditional loads, 8 sequence positions in
+// flight per thread.  Masked positions contribute exactly 0 (select, not multiply: padded rows may hold anything).
+constexpr int PCHUNK = 256;
+
+__device__ __forceinline__ float stage_weights(const UnivlPool& p, int b, int s0, float* wts, float* red) {
+    const int s = s0 + threadIdx.x;
+    const float w = (s < p.S) ? pool_weight(p, b, s) : 0.0f;
+    wts[threadIdx.x] = w;
+    return block_sum(w, red);          // includes the barrier that publishes wts
+}
+
 __global__ __launch_bounds__(256) void pool_fwd_kernel(UnivlPool p) {
     __shared__ float red[4];
+    __shared__ float wts[PCHUNK];
     const int b = blockIdx.x, t = threadIdx.x;
     float acc[PC] = {0.f, 0.f, 0.f};
     float cnt = 0.f;
-    for (int s = 0; s < p.S; ++s) {
-        const float w = pool_weight(p, b, s);
-        cnt += w;
-        if (w != 0.0f) {
-            const float* x = p.x + ((long)b * p.S + s) * p.ldx_row;
+    for (int s0 = 0; s0 < p.S; s0 += PCHUNK) {
+        cnt += stage_weights(p, b, s0, wts, red);
+        const int n = min(PCHUNK, p.S - s0);
+        const float* x = p.x + ((long)b * p.S + s0) * p.ldx_row + t;
+#pragma unroll 8
+        for (int s = 0; s < n; ++s) {
+            const float w = wts[s];
 #pragma unroll
-            for (int j = 0; j < PC; ++j) acc[j] += x[t + 256 * j] * w;
+            for (int j = 0; j < PC; ++j) {
+                const float v = x[(long)s * p.ldx_row + 256 * j];
+                acc[j] += (w != 0.0f) ? v * w : 0.0f;
+            }
         }
+        __syncthreads();
     }
     if (!p.skip_first && cnt == 0.0f) cnt = 1.0f;   // video_mask_un_sum[== 0] = 1   (modeling.py:336)
     float sq = 0.f;
@@ -62,11 +81,19 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(UnivlPool p) {
     }
 }
 
+// grid (B, ceil(S / PCHUNK)): every block recomputes the row's count (cheap, from LDS-staged weights) and writes its
+// own chunk of sequence positions
 __global__ __launch_bounds__(256) void pool_bwd_kernel(UnivlPool p) {
     __shared__ float red[4];
+    __shared__ float wts[PCHUNK];
+    __shared__ float mine[PCHUNK];
     const int b = blockIdx.x, t = threadIdx.x;
     float cnt = 0.f;
-    for (int s = 0; s < p.S; ++s) cnt += pool_weight(p, b, s);
+    for (int s0 = 0; s0 < p.S; s0 += PCHUNK) {
+        cnt += stage_weights(p, b, s0, wts, red);
+        if (s0 == (int)blockIdx.y * PCHUNK) mine[t] = wts[t];
+        __syncthreads();
+    }
     if (!p.skip_first && cnt == 0.0f) cnt = 1.0f;
     float m[PC], d[PC];
     float sq = 0.f, dot = 0.f;
@@ -83,13 +110,25 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(UnivlPool p) {
 #pragma unroll
         for (int j = 0; j < PC; ++j) d[j] = (d[j] - m[j] * dd) / nrm;
     }
-    for (int s = 0; s < p.S; ++s) {
-        const float w = pool_weight(p, b, s) / cnt;
-        float* dx = p.dx + ((long)b * p.S + s) * PN;
+    const float inv_cnt = 1.0f / cnt;
+    const int s0 = blockIdx.y * PCHUNK, n = min(PCHUNK, p.S - s0);
+    float* dx = p.dx + ((long)b * p.S + s0) * PN + t;
+    if (p.accumulate) {
+#pragma unroll 4
+        for (int s = 0; s < n; ++s) {
+            const float w = mine[s] * inv_cnt;
+            float old[PC];
 #pragma unroll
-        for (int j = 0; j < PC; ++j) {
-            if (p.accumulate) dx[t + 256 * j] += d[j] * w;
-            else dx[t + 256 * j] = d[j] * w;
+            for (int j = 0; j < PC; ++j) old[j] = dx[(long)s * PN + 256 * j];
+#pragma unroll
+            for (int j = 0; j < PC; ++j) dx[(long)s * PN + 256 * j] = old[j] + d[j] * w;
+        }
+    } else {
+#pragma unroll 4
+        for (int s = 0; s < n; ++s) {
+            const float w = mine[s] * inv_cnt;
+#pragma unroll
+            for (int j = 0; j < PC; ++j) dx[(long)s * PN + 256 * j] = d[j] * w;
         }
     }
 }
@@ -214,7 +253,7 @@ extern "C" int univl_pool_fwd(const UnivlPool* d, hipStream_t stream) {
 
 extern "C" int univl_pool_bwd(const UnivlPool* d, hipStream_t stream) {
     UNIVL_CHECK_ARG(d && d->N == 768 && d->B > 0 && d->S > 0 && d->mean && d->dout && d->dx, UNIVL_EINVAL, "univl_pool_bwd: bad argument");
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3(d->B), dim3(256), 0, stream, *d);
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(d->B, (d->S + PCHUNK - 1) / PCHUNK), dim3(256), 0, stream, *d);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
