@@ -328,13 +328,16 @@ class _StepLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, step):
         step.fwd.run()
-        ctx.model, ctx.step = model, step
+        ctx.model, ctx.step, ctx.anchor = model, step, anchor
         return step.loss[0].clone()
 
     @staticmethod
     def backward(ctx, gout):
         ctx.model._run_backward(ctx.step, gout)
-        return None, None, None
+        # Under a stock torch DistributedDataParallel wrapper the anchor is the one parameter DDP still tracks
+        # (UniVL._ddp_params_and_buffers_to_ignore lists all others): its autograd hook must fire every iteration.
+        ganchor = torch.zeros_like(ctx.anchor) if ctx.model._implicit_dp else None
+        return ganchor, None, None
 
 
 class _LossTensor(torch.Tensor):
@@ -346,7 +349,7 @@ class _LossTensor(torch.Tensor):
 
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
         ms = self.__dict__.get("_univl", None)
-        if ms is not None and gradient is None and inputs is None and not create_graph:
+        if ms is not None and gradient is None and inputs is None and not create_graph and not ms[0]._implicit_dp:
             model, step = ms
             model._run_backward(step, None)
             return None
@@ -403,12 +406,41 @@ class UniVL(UniVLPreTrainedModel):
         self._flat = None
         self._steps = {}
         self._reducer = None
+        self._dp_checked, self._implicit_dp = False, False
         self._seed_dev = None
         self._seed = int(getattr(tc, "seed", 42))
         dt = getattr(tc, "compute_dtype", None) or os.environ.get("UNIVL_COMPUTE_DTYPE", "bf16")
         self.compute_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32,
                               "float32": torch.float32}[str(dt).replace("torch.", "")]
         self.dropout_prob = float(getattr(tc, "dropout_prob", bert_config.hidden_dropout_prob))
+        # A stock torch DistributedDataParallel wrapper (main_task_retrieval.py:197-198) must not reduce these
+        # gradients a second time: they never pass through autograd's accumulators (the backward plan writes the flat
+        # gradient buffer directly and exchanges it itself, see _auto_data_parallel).  DDP reads this list.
+        self._ddp_params_and_buffers_to_ignore = self._ddp_ignore_list()
+
+    ANCHOR = "normalize_video.visual_norm2d.bias"
+
+    def _ddp_ignore_list(self):
+        names = []
+        for mn, m in self.named_modules():
+            for pn, _ in list(m.named_parameters(recurse=False)) + list(m.named_buffers(recurse=False)):
+                fqn = "%s.%s" % (mn, pn) if mn else pn
+                if fqn != self.ANCHOR:
+                    names.append(fqn)
+        return names
+
+    def _auto_data_parallel(self):
+        """First training forward inside an initialised process group with no explicit enable_data_parallel(): the model
+        is presumably wrapped the way the reference's scripts wrap it (stock DDP, find_unused_parameters=True).  Turn
+        the built-in gradient exchange on, broadcast rank 0's parameters like DDP's constructor does, and route
+        loss.backward() through autograd so that DDP's bookkeeping for the anchor parameter stays consistent."""
+        self._dp_checked = True
+        import torch.distributed as dist
+        if os.environ.get("UNIVL_AUTO_DP", "1") == "0" or not (dist.is_available() and dist.is_initialized()):
+            return
+        if dist.get_world_size() > 1:
+            self.enable_data_parallel()
+            self._implicit_dp = True
 
     # ------------------------------------------------------------------------------------- housekeeping
     def init_weights(self, module):
@@ -454,6 +486,7 @@ class UniVL(UniVLPreTrainedModel):
         the flat gradient buffer, overlapped with backward (univl_amd.parallel).  Call after model.to(device) and
         torch.distributed.init_process_group; with world_size 1 it is a no-op."""
         fl = self.flat
+        self._dp_checked, self._implicit_dp = True, False
         if broadcast:
             broadcast_parameters(fl.p32, 0, process_group)
             fl.shadow_valid = False
@@ -526,6 +559,8 @@ class UniVL(UniVLPreTrainedModel):
         kind = self.step_kind(input_caption_ids is not None)
         if kind in ("caption", "pretrain") and input_caption_ids is None:
             raise RuntimeError("UniVL.forward: the %s path needs input_caption_ids / decoder_mask / output_caption_ids" % kind)
+        if not self._dp_checked:
+            self._auto_data_parallel()
         fl = self.flat
         fl.refresh_shadow()
         st = self._get_step(kind, B, W, F)
@@ -535,7 +570,7 @@ class UniVL(UniVLPreTrainedModel):
             st.heads.load(pairs_token_labels, video_labels_index)
         if st.decoder is not None:
             st.decoder.load(input_caption_ids, decoder_mask, output_caption_ids)
-        anchor = fl.params["normalize_video.visual_norm2d.bias"]
+        anchor = fl.params[self.ANCHOR]
         if torch.is_grad_enabled() and anchor.requires_grad:
             out = _StepLossFn.apply(anchor, self, st).as_subclass(_LossTensor)
             out._univl = (self, st)
