@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libunivl_hip.so")
+LIB_PATH = os.environ.get("UNIVL_LIB") or os.path.join(_HERE, "lib", "libunivl_hip.so")   # UNIVL_LIB: A/B builds
 
 DT_F32, DT_BF16 = 0, 1
 GEMM_ACCUM, GEMM_GELU_FWD, GEMM_GELU_BWD, GEMM_DBIAS_ATOMIC = 1, 2, 4, 16
