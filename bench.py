@@ -32,6 +32,9 @@ def get_args():
     ap.add_argument("--batch", type=int, default=4, help="pairs per GPU per step (configs[1]: bs=4)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="hand the batch over as pageable HOST tensors every step (the reference's loaders: pin_memory=False, "
+                         "float64 video): the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
     ap.add_argument("--loopback", action="store_true",
                     help="single GPU: run the data-parallel schedule (exchange points, segmented hipGraphs) with identity "
                          "exchanges on a communication stream -- exercises the N>1 code path without a second GPU")
@@ -180,7 +183,9 @@ def main():
     gstep, mode = None, "eager"
     if not args.no_graph:
         from univl_amd.graphed import GraphedTrainStep
-        gstep = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=0, persistent_inputs=True)
+        gstep = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=0, persistent_inputs=not args.host_inputs)
+        if args.host_inputs:
+            inputs = {k: v.cpu() for k, v in inputs.items()}
         g_args = (inputs["input_ids"], inputs["token_type_ids"], inputs["attention_mask"], inputs["video"], inputs["video_mask"])
         g_kw = dict(pairs_masked_text=inputs["input_ids"], pairs_token_labels=None, masked_video=inputs["video"],
                     video_labels_index=None)
@@ -265,7 +270,7 @@ def main():
                                         "encoder (12 L) + 6-layer visual encoder, max_words=48, max_frames=48, bs=%d per GPU, "
                                         "fwd+bwd+clip+BertAdam, dropout %.2f, random-init weights" % (args.batch, args.dropout),
                                per_gpu_batch=args.batch, global_batch=args.batch * world, max_words=48, max_frames=48,
-                               parallelism="dp%d" % world, hip_graph=graph is not None, graph_mode=mode, params=n_params,
+                               parallelism="dp%d" % world, hip_graph=graph is not None, graph_mode=mode, host_inputs=bool(args.host_inputs), params=n_params,
                                last_loss=round(last, 6)),
                    roofline=roofline, cpu_baseline=cpu_base)
         print(json.dumps(out))

@@ -183,6 +183,10 @@ int univl_crossen_loss(const float* sim, int32_t n, int32_t ld, float* loss, flo
 /* MILNCELoss (until_module.py:201-221) for batch_size x n_pair blocks; n = batch_size*n_pair. */
 int univl_milnce_loss(const float* sim, int32_t batch_size, int32_t n_pair, int32_t ld, float* loss, float* dsim,
                       hipStream_t stream);
+/* Retrieval metrics (metrics.py:8-20): for every row i of the [n, ld] similarity matrix, gt[i] = #{j : x[i][j] > x[i][i]}
+ * and eq[i] = #{j : x[i][j] == x[i][i]} (>= 1).  The rank positions `ind` of compute_metrics are range(gt, gt + eq)
+ * per row: R@k / median rank follow on the host from 2n integers instead of an n x n sort. */
+int univl_rank_counts(const float* sim, int32_t n, int64_t ld, int32_t* gt, int32_t* eq, hipStream_t stream);
 /* x[0..n) *= s[0] with s on the device (applies loss.backward()'s upstream gradient without a host sync) */
 int univl_scale_by_device_scalar(float* x, int64_t n, const float* s, hipStream_t stream);
 

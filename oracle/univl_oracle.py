@@ -660,3 +660,15 @@ def param_groups(names, lr, coef_lr=1.0):
         wd = 0.0 if any(nd in n for nd in no_decay) else 0.01
         out[n] = dict(weight_decay=wd, lr=lr * coef_lr if "bert." in n else lr)
     return out
+
+
+def compute_metrics(x):
+    """metrics.py:8-20 restated (numpy): positions of the diagonal score in each descending-sorted row -- ties with the
+    diagonal contribute one entry each, exactly like the reference's `np.where(sx - d == 0)`."""
+    import numpy as np
+    x = np.asarray(x)
+    sx = np.sort(-x, axis=1)
+    d = np.diag(-x)[:, np.newaxis]
+    ind = np.where(sx - d == 0)[1]
+    return dict(R1=float(np.sum(ind == 0)) / len(ind), R5=float(np.sum(ind < 5)) / len(ind),
+                R10=float(np.sum(ind < 10)) / len(ind), MR=np.median(ind) + 1)

@@ -94,6 +94,7 @@ def lib():
     L.univl_maxmargin_loss.argtypes = [vp, i32, i32, f32, vp, vp, vp, vp]
     L.univl_crossen_loss.argtypes = [vp, i32, i32, vp, vp, vp]
     L.univl_milnce_loss.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    L.univl_rank_counts.argtypes = [vp, i32, i64, vp, vp, vp]
     L.univl_scale_by_device_scalar.argtypes = [vp, i64, vp, vp]
     L.univl_pair_concat_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
     L.univl_pair_concat_bwd.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
@@ -122,7 +123,7 @@ def lib():
 EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_device_info", "univl_gemm", "univl_gemm_group",
             "univl_layernorm_fwd", "univl_layernorm_bwd", "univl_attention_fwd", "univl_attention_bwd",
             "univl_embed_text_fwd", "univl_embed_text_bwd", "univl_pool_fwd", "univl_pool_bwd",
-            "univl_maxmargin_loss", "univl_crossen_loss", "univl_milnce_loss", "univl_scale_by_device_scalar", "univl_pair_concat_fwd", "univl_pair_concat_bwd", "univl_postype_fwd", "univl_postype_bwd", "univl_tanh_fwd",
+            "univl_maxmargin_loss", "univl_crossen_loss", "univl_milnce_loss", "univl_rank_counts", "univl_scale_by_device_scalar", "univl_pair_concat_fwd", "univl_pair_concat_bwd", "univl_postype_fwd", "univl_postype_bwd", "univl_tanh_fwd",
             "univl_tanh_bwd", "univl_gelu_bwd", "univl_colsum", "univl_scale_ct_by_device_scalar", "univl_simdense_fwd", "univl_simdense_bwd", "univl_ce_loss", "univl_mfm_nce_loss", "univl_grad_sumsq",
             "univl_clip_coef", "univl_scale_grads", "univl_bert_adam", "univl_cast_bf16", "univl_bump_counter", "univl_probe_layouts"]
 

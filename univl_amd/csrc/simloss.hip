@@ -244,6 +244,34 @@ extern "C" int univl_scale_by_device_scalar(float* x, int64_t n, const float* s,
     return UNIVL_OK;
 }
 
+__global__ __launch_bounds__(256) void rank_counts_kernel(const float* x, int n, long ld, int* gt, int* eq) {
+    __shared__ int red[8];
+    const int i = blockIdx.x, t = threadIdx.x;
+    const float* row = x + (long)i * ld;
+    const float d = row[i];
+    int g = 0, e = 0;
+    for (int j = t; j < n; j += 256) {
+        const float v = row[j];
+        g += v > d ? 1 : 0;
+        e += v == d ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { g += __shfl_down(g, o, 64); e += __shfl_down(e, o, 64); }
+    if ((t & 63) == 0) { red[t >> 6] = g; red[4 + (t >> 6)] = e; }
+    __syncthreads();
+    if (t == 0) {
+        gt[i] = (red[0] + red[1]) + (red[2] + red[3]);
+        eq[i] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+
+extern "C" int univl_rank_counts(const float* sim, int32_t n, int64_t ld, int32_t* gt, int32_t* eq, hipStream_t stream) {
+    UNIVL_CHECK_ARG(sim && gt && eq && n > 0 && ld >= n, UNIVL_EINVAL, "univl_rank_counts: bad argument");
+    hipLaunchKernelGGL(rank_counts_kernel, dim3(n), dim3(256), 0, stream, sim, n, (long)ld, gt, eq);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
 extern "C" int univl_pool_fwd(const UnivlPool* d, hipStream_t stream) {
     UNIVL_CHECK_ARG(d && d->N == 768 && d->B > 0 && d->S > 0 && d->x && d->out, UNIVL_EINVAL, "univl_pool_fwd: bad argument (N must be 768)");
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(d->B), dim3(256), 0, stream, *d);

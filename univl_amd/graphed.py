@@ -16,6 +16,7 @@ captures and runs; later calls only copy the new batch into the static input buf
 import torch
 
 from .optimization import clip_grad_norm_
+from .steps import stage_input
 
 
 class GraphedTrainStep:
@@ -49,7 +50,8 @@ class GraphedTrainStep:
     def _stage(self, args, kw):
         """Bring the new batch into the static input buffers the graphs read from."""
         if self._static_args is None:
-            hold = (lambda t: t) if self.persistent else (lambda t: t.clone())
+            dev = next(self.model.parameters()).device
+            hold = (lambda t: t) if self.persistent else (lambda t: t.to(dev, copy=True))
             self._static_args = [hold(a) if isinstance(a, torch.Tensor) else a for a in args]
             self._static_kw = {k: (hold(v) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
             return
@@ -63,7 +65,7 @@ class GraphedTrainStep:
                                        "second GraphedTrainStep for the other batch shape" %
                                        (tuple(st.shape), tuple(getattr(new, "shape", ()))))
                 if new is not st:
-                    st.copy_(new, non_blocking=True)
+                    stage_input(st, new)           # host batches go through a pinned buffer (one async DMA)
             elif st is not new and st != new:
                 raise RuntimeError("GraphedTrainStep: a non-tensor argument changed after capture")
 

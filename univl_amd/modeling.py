@@ -469,14 +469,30 @@ class UniVL(UniVLPreTrainedModel):
         self.mark_params_dirty()
         return r
 
+    def _replicate_for_data_parallel(self):
+        replica = super()._replicate_for_data_parallel()
+        replica._flat, replica._steps, replica._reducer, replica._seed_dev = None, {}, None, None
+        replica._dp_checked, replica._implicit_dp, replica.graph_backward = True, False, False
+        return replica
+
     @property
     def flat(self):
         if self._flat is None:
-            p0 = next(self.parameters())
+            named = list(self.named_parameters())
+            if not named and getattr(self, "_is_replica", False):
+                # nn.parallel.replicate (util.py:22, the eval path of main_task_retrieval.py:402-436): a replica's
+                # weights are plain tensors kept in _former_parameters; it gets its own flat storage on its device
+                seen = set()
+                for mn, m in self.named_modules():
+                    for k, t in getattr(m, "_former_parameters", {}).items():
+                        if t is not None and id(t) not in seen:
+                            seen.add(id(t))
+                            named.append((("%s.%s" % (mn, k)) if mn else k, t))
+            p0 = named[0][1]
             if not p0.is_cuda:
                 raise RuntimeError("univl_amd.UniVL runs only on a HIP device (call model.to('cuda')); no CPU fallback")
             _lib.lib()
-            self._flat = FlatParams(list(self.named_parameters()), p0.device, self.compute_dtype)
+            self._flat = FlatParams(named, p0.device, self.compute_dtype)
             self._seed_dev = torch.zeros(1, device=p0.device, dtype=torch.int64)
             self._steps = {}
         return self._flat

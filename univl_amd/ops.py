@@ -209,6 +209,17 @@ def scale_by_device_scalar(x, s):
     _lib.check(_lib.lib().univl_scale_by_device_scalar(_p(x), x.numel(), _p(s), _stream()), "scale_by_device_scalar")
 
 
+def rank_counts(sim):
+    """sim: [n, n] fp32 device tensor (row stride >= n).  Returns (gt, eq) int32 [n]."""
+    _require_gpu(sim)
+    n = sim.shape[0]
+    assert sim.shape[1] == n and sim.dtype == torch.float32 and sim.stride(1) == 1
+    gt = torch.empty(n, dtype=torch.int32, device=sim.device)
+    eq = torch.empty(n, dtype=torch.int32, device=sim.device)
+    _lib.check(_lib.lib().univl_rank_counts(_p(sim), n, sim.stride(0), _p(gt), _p(eq), _stream()), "rank_counts")
+    return gt, eq
+
+
 def cast_bf16(src, dst):
     _lib.check(_lib.lib().univl_cast_bf16(_p(src), _p(dst), src.numel(), _stream()), "cast_bf16")
 

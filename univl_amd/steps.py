@@ -41,6 +41,18 @@ class Ctx:
         self.red = model._reducer
 
 
+def stage_input(dst, src):
+    """dst (static device buffer) <- src, asynchronously on the current stream.  Host sources (the reference's loaders
+    hand over pageable tensors: pin_memory=False, float64 video -- SURVEY.md section 8f row 3) are copied as they are:
+    measured on the MI355X box (scripts/mb_h2d.py) the runtime's pageable path moves the 1.6 MB float64 video in 40 us,
+    a private pinned staging buffer is no faster and shows 60-90 ms stalls, and a host-side float32 cast costs more
+    than the bytes it saves.  The float64 -> float32 conversion happens inside the NormalizeVideo LayerNorm kernel."""
+    src = torch.as_tensor(src)
+    if src.dtype != dst.dtype:
+        src = src.to(dst.dtype)
+    dst.copy_(src.reshape(dst.shape), non_blocking=True)
+
+
 class EncoderPass:
     """NormalizeVideo + BertModel + VisualModel for one set of inputs (modeling.py:196-202, 299-313)."""
 
@@ -80,11 +92,11 @@ class EncoderPass:
 
     def load(self, input_ids, token_type_ids, attention_mask, video, video_mask):
         B, W, F = self.B, self.W, self.F
-        self.ids.copy_(input_ids.reshape(B, W), non_blocking=True)
-        self.type_ids.copy_(token_type_ids.reshape(B, W), non_blocking=True)
-        self.amask.copy_(attention_mask.reshape(B, W), non_blocking=True)
-        self.video.copy_(torch.as_tensor(video).reshape(B * F, -1), non_blocking=True)
-        self.vmask.copy_(video_mask.reshape(B, F), non_blocking=True)
+        stage_input(self.ids, input_ids)
+        stage_input(self.type_ids, token_type_ids)
+        stage_input(self.amask, attention_mask)
+        stage_input(self.video, video)
+        stage_input(self.vmask, video_mask)
 
     def build_forward(self, fwd):
         cx, n, fl, dt, bf = self.cx, self.N, self.cx.fl, self.cx.dt, self.cx.bf
