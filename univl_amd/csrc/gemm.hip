@@ -482,11 +482,12 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, bool& big, int&
     const int flags = d->flags;
     UNIVL_CHECK_ARG(!((flags & (UNIVL_GEMM_GELU_FWD | UNIVL_GEMM_GELU_BWD)) && !d->aux), UNIVL_EINVAL,
                     "univl_gemm: GELU epilogue needs aux");
-    // tile choice: 128x128 once the grid fills the chip, else 64x64 for parallelism.  The small tile stages
+    // tile choice: 128x128 once the grid fills the chip (>= 256 tiles, measured: +6 % at bs 128 over 384, same at bs 16), else 64x64 for parallelism.  The small tile stages
     // 4 chunks (128 bf16 / 64 f32) per barrier: at M <= a few hundred the kernel is a latency chain of K steps
     // (DMA -> barrier -> ds_read -> MFMA), so fewer, deeper steps win; 2 stages of 32 KB stay in flight.
     const long tiles128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
-    big = d->tile == 128 || (d->tile == 0 && tiles128 >= 384);
+    static const long big_min = [] { const char* e = getenv("UNIVL_GEMM_BIG_MIN"); return e ? atol(e) : 256L; }();
+    big = d->tile == 128 || (d->tile == 0 && tiles128 >= big_min);
     nc = big ? 2 : 4;
     ksplit = d->ksplit < 1 ? 1 : d->ksplit;
     const int BK = (d->dtype == UNIVL_BF16 ? 32 : 16) * nc;
@@ -537,7 +538,8 @@ extern "C" int univl_gemm_group(const UnivlGemm* d, int n, hipStream_t stream) {
         UNIVL_CHECK_ARG(d[i].dtype == d[0].dtype && d[i].trans_a == d[0].trans_a && d[i].trans_b == d[0].trans_b, UNIVL_EINVAL,
                         "univl_gemm_group: members must share dtype and operand layouts");
         const long tiles128 = (long)((d[i].M + 127) / 128) * ((d[i].N + 127) / 128);
-        big_all = big_all && (d[i].tile == 128 || (d[i].tile == 0 && tiles128 >= 384));
+        static const long big_min = [] { const char* e = getenv("UNIVL_GEMM_BIG_MIN"); return e ? atol(e) : 256L; }();
+        big_all = big_all && (d[i].tile == 128 || (d[i].tile == 0 && tiles128 >= big_min));
     }
     int total = 0;
     const int bm = big_all ? 128 : 64;

@@ -34,11 +34,21 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, const UnivlS
     const int len = chunk_len[c];
     float acc = 0.f;
     const int nv = ((((uintptr_t)p) & 15) == 0) ? len / 4 : 0;
-    for (int i = threadIdx.x; i < nv; i += 256) {
-        const float4 v = reinterpret_cast<const float4*>(p)[i];
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    int i = threadIdx.x;
+    // full chunks (8192 floats = 8 float4 per thread): all 8 loads in flight before the first use
+    for (; i + 7 * 256 < nv; i += 8 * 256) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p4[i + 256 * u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
+    }
+    for (; i < nv; i += 256) {
+        const float4 v = p4[i];
         acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     }
-    for (int i = nv * 4 + threadIdx.x; i < len; i += 256) acc += p[i] * p[i];
+    for (int j = nv * 4 + threadIdx.x; j < len; j += 256) acc += p[j] * p[j];
     const float s = block_sum256(acc, red);
     if (threadIdx.x == 0) unsafeAtomicAdd(sumsq + seg, s);
 }
@@ -103,11 +113,7 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(UnivlAdam a) {
     float* p = a.p + off; const float* g = a.g + off; float* m = a.m + off; float* v = a.v + off;
     __bf16* p16 = a.p16 ? reinterpret_cast<__bf16*>(a.p16) + off : nullptr;
     const int nv = ((off & 3) == 0) ? len / 4 : 0;
-    for (int i = threadIdx.x; i < nv; i += 256) {
-        float4 pp = reinterpret_cast<float4*>(p)[i];
-        const float4 gg = reinterpret_cast<const float4*>(g)[i];
-        float4 mm = reinterpret_cast<float4*>(m)[i];
-        float4 vv = reinterpret_cast<float4*>(v)[i];
+    auto update = [&](int i, float4 pp, const float4 gg, float4 mm, float4 vv) {
         float* pe = reinterpret_cast<float*>(&pp); const float* ge = reinterpret_cast<const float*>(&gg);
         float* me = reinterpret_cast<float*>(&mm); float* ve = reinterpret_cast<float*>(&vv);
 #pragma unroll
@@ -126,7 +132,21 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(UnivlAdam a) {
             w[0] = (__bf16)pe[0]; w[1] = (__bf16)pe[1]; w[2] = (__bf16)pe[2]; w[3] = (__bf16)pe[3];
             reinterpret_cast<bf16x4_t*>(p16)[i] = w;
         }
+    };
+    int i = threadIdx.x;
+    // two vectors per thread per trip: all eight 16-byte loads are issued before the first store (p, m, v are read and
+    // written through the same pointers, so the compiler cannot hoist the next trip's loads above this trip's stores)
+    for (; i + 256 < nv; i += 512) {
+        const float4 p0 = reinterpret_cast<const float4*>(p)[i], p1 = reinterpret_cast<const float4*>(p)[i + 256];
+        const float4 g0 = reinterpret_cast<const float4*>(g)[i], g1 = reinterpret_cast<const float4*>(g)[i + 256];
+        const float4 m0 = reinterpret_cast<const float4*>(m)[i], m1 = reinterpret_cast<const float4*>(m)[i + 256];
+        const float4 v0 = reinterpret_cast<const float4*>(v)[i], v1 = reinterpret_cast<const float4*>(v)[i + 256];
+        update(i, p0, g0, m0, v0);
+        update(i + 256, p1, g1, m1, v1);
     }
+    for (; i < nv; i += 256)
+        update(i, reinterpret_cast<const float4*>(p)[i], reinterpret_cast<const float4*>(g)[i],
+               reinterpret_cast<const float4*>(m)[i], reinterpret_cast<const float4*>(v)[i]);
     for (int i = nv * 4 + threadIdx.x; i < len; i += 256) {
         const float gr = g[i] * gs;
         const float mi = m[i] * b1 + (1.0f - b1) * gr;
