@@ -83,20 +83,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(UnivlAttention p, int Sk_
     const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
     const T* Kg = reinterpret_cast<const T*>(p.k) + (long)b * p.Sk * p.ldk + h * HD;
     const T* Vg = reinterpret_cast<const T*>(p.v) + (long)b * p.Sk * p.ldv + h * HD;
-    stage_rows<T>(sK, Kg, p.ldk, p.Sk, Sk_pad, tid);
-    stage_rows<T>(sV, Vg, p.ldv, p.Sk, Sk_pad, tid);
-    stage_mask(sM, p.key_mask, b, p.Sk, Sk_pad, tid);
-    __syncthreads();
-
+    // per-wave operands straight from global memory are requested BEFORE the K/V staging round trip (clamped rows:
+    // lanes / waves beyond Sq read a valid row and never store), so the kernel pays one global latency, not two
     const int q0 = blockIdx.y * 64 + wave * 16;
-    if (q0 >= p.Sq) return;
     const int q = q0 + i;
     const bool qv = q < p.Sq;
-    const int qc = min(q, p.Sq - 1);      // clamped row: lanes beyond Sq compute on a valid row and never store
+    const int qc = min(q, p.Sq - 1);
     const T* Qg = reinterpret_cast<const T*>(p.q) + ((long)b * p.Sq + qc) * p.ldq + h * HD;
     typename M::frag fq[C::NCD];
 #pragma unroll
     for (int c = 0; c < C::NCD; ++c) fq[c] = M::gmem_kmajor(Qg + c * C::CH, g);
+    const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+    stage_rows<T>(sK, Kg, p.ldk, p.Sk, Sk_pad, tid);
+    stage_rows<T>(sV, Vg, p.ldv, p.Sk, Sk_pad, tid);
+    stage_mask(sM, p.key_mask, b, p.Sk, Sk_pad, tid);
+    __syncthreads();
+    if (q0 >= p.Sq) return;
 
     const int nkt = Sk_pad / 16;
     f32x4_t s[MAXKT];
@@ -135,7 +137,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(UnivlAttention p, int Sk_
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     if (p.lse && qv && g == 0) p.lse[((long)bh) * p.Sq + q] = mx + logf(sum);
-    const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
     const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
     const uint64_t drow = ((uint64_t)bh * p.Sq + q) * (uint64_t)p.Sk;
 #pragma unroll
@@ -191,28 +192,30 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_
         T* sK = reinterpret_cast<T*>(smem_raw);
         T* sV = sK + Sk_pad * C::P;
         float* sM = reinterpret_cast<float*>(sV + Sk_pad * C::P);
+        const int q0 = blockIdx.y * 64 + wave * 16;
+        const int q = q0 + i;
+        const bool qv = q < p.Sq;
+        typename M::frag fq[C::NCD], fdo[C::NCD], fo[C::NCD];
+        const int qc = min(q, p.Sq - 1);
+#pragma unroll
+        for (int c = 0; c < C::NCD; ++c) {                      // requested before the staging round trip (see forward)
+            fq[c] = M::gmem_kmajor(Qb + (long)qc * p.ldq + c * C::CH, g);
+            fdo[c] = M::gmem_kmajor(dOb + (long)qc * p.lddo + c * C::CH, g);
+            fo[c] = M::gmem_kmajor(Ob + (long)qc * p.ldo + c * C::CH, g);
+        }
+        const float lse = p.lse[(long)bh * p.Sq + qc];
         stage_rows<T>(sK, Kb, p.ldk, p.Sk, Sk_pad, tid);
         stage_rows<T>(sV, Vb, p.ldv, p.Sk, Sk_pad, tid);
         stage_mask(sM, p.key_mask, b, p.Sk, Sk_pad, tid);
         __syncthreads();
-        const int q0 = blockIdx.y * 64 + wave * 16;
         if (q0 >= p.Sq) return;
-        const int q = q0 + i;
-        const bool qv = q < p.Sq;
-        typename M::frag fq[C::NCD], fdo[C::NCD];
         float dsum = 0.f;
-        const int qc = min(q, p.Sq - 1);
 #pragma unroll
-        for (int c = 0; c < C::NCD; ++c) {
-            fq[c] = M::gmem_kmajor(Qb + (long)qc * p.ldq + c * C::CH, g);
-            fdo[c] = M::gmem_kmajor(dOb + (long)qc * p.lddo + c * C::CH, g);
-            const typename M::frag fo = M::gmem_kmajor(Ob + (long)qc * p.ldo + c * C::CH, g);
+        for (int c = 0; c < C::NCD; ++c)
 #pragma unroll
-            for (int e = 0; e < C::EPC; ++e) dsum += to_f32<T>(fdo[c][e]) * to_f32<T>(fo[e]);
-        }
+            for (int e = 0; e < C::EPC; ++e) dsum += to_f32<T>(fdo[c][e]) * to_f32<T>(fo[c][e]);
         dsum += __shfl_xor(dsum, 16, 64);
         dsum += __shfl_xor(dsum, 32, 64);
-        const float lse = p.lse[(long)bh * p.Sq + qc];
         const uint64_t drow = ((uint64_t)bh * p.Sq + q) * (uint64_t)p.Sk;
         f32x4_t dq[4];
 #pragma unroll
@@ -256,37 +259,46 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_
         float* sM = reinterpret_cast<float*>(sDO + Sq_pad * C::P);   // [Sk_pad]
         float* sL = sM + Sk_pad;                                      // [Sq_pad] lse
         float* sD = sL + Sq_pad;                                      // [Sq_pad] rowsum(dO*O)
-        stage_rows<T>(sQ, Qb, p.ldq, p.Sq, Sq_pad, tid);
-        stage_rows<T>(sDO, dOb, p.lddo, p.Sq, Sq_pad, tid);
-        stage_mask(sM, p.key_mask, b, p.Sk, Sk_pad, tid);
-        // D[q] = sum_d dO[q,d] O[q,d]: 4 threads per query row, 16 d each
-        for (int qq = tid >> 2; qq < Sq_pad; qq += 64) {
-            float acc = 0.f;
-            if (qq < p.Sq) {
-                const T* o = Ob + (long)qq * p.ldo + (tid & 3) * 16;
-                const T* d = dOb + (long)qq * p.lddo + (tid & 3) * 16;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc += to_f32<T>(o[e]) * to_f32<T>(d[e]);
-            }
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            if ((tid & 3) == 0) {
-                sD[qq] = acc;
-                sL[qq] = qq < p.Sq ? p.lse[(long)bh * p.Sq + qq] : 0.0f;
-            }
-        }
-        __syncthreads();
         const int k0 = ((int)blockIdx.y - nqb) * 64 + wave * 16;
-        if (k0 >= p.Sk) return;
         const int key = k0 + i;
         const bool kv = key < p.Sk;
         typename M::frag fk[C::NCD], fv[C::NCD];
         const int keyc = min(key, p.Sk - 1);
 #pragma unroll
-        for (int c = 0; c < C::NCD; ++c) {
+        for (int c = 0; c < C::NCD; ++c) {                      // requested before the staging round trip
             fk[c] = M::gmem_kmajor(Kb + (long)keyc * p.ldk + c * C::CH, g);
             fv[c] = M::gmem_kmajor(Vb + (long)keyc * p.ldv + c * C::CH, g);
         }
+        stage_rows<T>(sQ, Qb, p.ldq, p.Sq, Sq_pad, tid);
+        stage_rows<T>(sDO, dOb, p.lddo, p.Sq, Sq_pad, tid);
+        stage_mask(sM, p.key_mask, b, p.Sk, Sk_pad, tid);
+        // D[q] = sum_d dO[q,d] O[q,d]: 4 threads per query row, 16 d each, as 16-byte vectors from a clamped row
+        for (int qq = tid >> 2; qq < Sq_pad; qq += 64) {
+            const int qr = min(qq, p.Sq - 1);
+            const T* o = Ob + (long)qr * p.ldo + (tid & 3) * 16;
+            const T* d = dOb + (long)qr * p.lddo + (tid & 3) * 16;
+            const float l = p.lse[(long)bh * p.Sq + qr];
+            constexpr int NV = 16 / C::EPC;                      // 16-byte vectors per 16 elements
+            typename M::frag vo[NV], vd[NV];
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                vo[u] = *reinterpret_cast<const typename M::frag*>(o + u * C::EPC);
+                vd[u] = *reinterpret_cast<const typename M::frag*>(d + u * C::EPC);
+            }
+            float acc = 0.f;
+#pragma unroll
+            for (int u = 0; u < NV; ++u)
+#pragma unroll
+                for (int e = 0; e < C::EPC; ++e) acc += to_f32<T>(vo[u][e]) * to_f32<T>(vd[u][e]);
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            if ((tid & 3) == 0) {
+                sD[qq] = qq < p.Sq ? acc : 0.0f;
+                sL[qq] = qq < p.Sq ? l : 0.0f;
+            }
+        }
+        __syncthreads();
+        if (k0 >= p.Sk) return;
         const float mkey = kv ? sM[key] : 0.0f;
         f32x4_t dk[4], dv[4];
 #pragma unroll
