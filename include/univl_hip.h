@@ -134,6 +134,9 @@ typedef struct UnivlAttention {
     void* dq; int64_t lddq;
     void* dk; int64_t lddk;
     void* dv; int64_t lddv;
+    /* optional batch strides (elements) of k and v: 0 = Sk*ld (densely packed rows).  A key/value cache of capacity
+     * Tmax >= Sk per sequence (incremental caption decoding, main_task_caption.py:434-470) passes Tmax*ld. */
+    int64_t bsk, bsv;
 } UnivlAttention;
 int univl_attention_fwd(const UnivlAttention* d, hipStream_t stream);
 int univl_attention_bwd(const UnivlAttention* d, hipStream_t stream);
@@ -213,6 +216,13 @@ int univl_gelu_bwd(int32_t dtype, const float* dg, const void* u, void* du, int6
  * (dx written, dw/db accumulated with atomics) */
 /* out[c] += sum_r x[r, c] over a [rows, ld] matrix in the compute type (atomics) */
 int univl_colsum(int32_t dtype, const void* x, int64_t ld, int32_t rows, int32_t n, float* out, hipStream_t stream);
+/* dst[r, 0:copy_bytes) = src[idx[r], 0:copy_bytes) for r < rows; rows are row_stride bytes apart in both buffers, all
+ * byte counts multiples of 16 (beam re-ordering of the decoder's key/value cache: Beam.get_current_origin, beam.py:54) */
+int univl_gather_rows(const void* src, void* dst, const int32_t* idx, int32_t rows, int64_t row_stride, int64_t copy_bytes,
+                      hipStream_t stream);
+/* x[r, 0:n) <- log_softmax(x[r, 0:n)) in place, fp32 rows ld apart (torch.nn.functional.log_softmax of
+ * main_task_caption.py:454 over the vocabulary) */
+int univl_log_softmax_rows(float* x, int32_t rows, int32_t n, int64_t ld, hipStream_t stream);
 /* x (compute type) *= s[0], s on the device */
 int univl_scale_ct_by_device_scalar(int32_t dtype, void* x, int64_t n, const float* s, hipStream_t stream);
 int univl_simdense_fwd(const float* x, const float* w, const float* b, int32_t rows, float* out, hipStream_t stream);

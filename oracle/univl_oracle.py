@@ -672,3 +672,62 @@ def compute_metrics(x):
     ind = np.where(sx - d == 0)[1]
     return dict(R1=float(np.sum(ind == 0)) / len(ind), R5=float(np.sum(ind < 5)) / len(ind),
                 R10=float(np.sum(ind < 10)) / len(ind), MR=np.median(ind) + 1)
+
+
+def beam_search_caption(P, cfg, seq_out, vis_out, attention_mask, video_mask, n_bm, max_words, bos, eos):
+    """The caption decoding procedure of main_task_caption.py:434-618 + modules/beam.py restated: every step re-runs
+    decoder_caption on the complete prefixes of all beams of the still-active instances and keeps the last position's
+    log-softmax; per instance: first step top-k of beam 0's distribution (beam.py:69), later steps top-k over the
+    flattened (beam x vocab) sums (beam.py:67,71-72), back-pointer = id // vocab, token = id % vocab (beam.py:77-79),
+    done when the top beam emits EOS (beam.py:84); result = best-scored beam walked back (beam.py:108-116,
+    collect_hypothesis_and_scores n_best=1).  Returns (list of token lists, list of best scores)."""
+    n = seq_out.shape[0]
+    v = lambda t: t.view(-1, t.shape[-1])
+    attention_mask, video_mask = v(attention_mask), v(video_mask)
+    scores = [torch.zeros(n_bm) for _ in range(n)]
+    prev_ks = [[] for _ in range(n)]
+    next_ys = [[torch.full((n_bm,), bos, dtype=torch.long)] for _ in range(n)]
+    done = [False] * n
+
+    def hypothesis(i, k):
+        hyp = []
+        for j in range(len(prev_ks[i]) - 1, -1, -1):
+            hyp.append(int(next_ys[i][j + 1][k]))
+            k = int(prev_ks[i][j][k])
+        return hyp[::-1]
+
+    for length in range(1, max_words + 1):
+        active = [i for i in range(n) if not done[i]]
+        if not active:
+            break
+        rows, owner = [], []
+        for i in active:
+            if len(next_ys[i]) == 1:
+                seqs = next_ys[i][0].unsqueeze(1)
+            else:
+                keys = torch.sort(scores[i], 0, True)[1]
+                seqs = torch.tensor([[bos] + hypothesis(i, int(k)) for k in keys], dtype=torch.long)
+            rows.append(seqs)
+            owner += [i] * n_bm
+        ids = torch.cat(rows, 0)
+        idx = torch.tensor(owner)
+        logits = decoder_caption(P, cfg, seq_out[idx], vis_out[idx], attention_mask[idx], video_mask[idx], ids,
+                                 torch.ones_like(ids))
+        word_prob = F.log_softmax(logits[:, -1, :], dim=1).view(len(active), n_bm, -1)
+        V = word_prob.shape[-1]
+        for pos, i in enumerate(active):
+            wp = word_prob[pos]
+            beam_lk = wp + scores[i].unsqueeze(1) if prev_ks[i] else wp[0]
+            best, best_id = beam_lk.reshape(-1).topk(n_bm, 0, True, True)
+            scores[i] = best
+            pk = best_id // V
+            prev_ks[i].append(pk)
+            next_ys[i].append(best_id - pk * V)
+            if int(next_ys[i][-1][0]) == eos:
+                done[i] = True
+    hyps, best_scores = [], []
+    for i in range(n):
+        sc, order = torch.sort(scores[i], 0, True)
+        hyps.append(hypothesis(i, int(order[0])))
+        best_scores.append(float(sc[0]))
+    return hyps, best_scores

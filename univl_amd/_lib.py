@@ -34,7 +34,7 @@ class Attention(C.Structure):
                 ("k", vp), ("ldk", i64), ("v", vp), ("ldv", i64), ("key_mask", vp), ("causal", i32),
                 ("out", vp), ("ldo", i64), ("lse", vp), ("p_drop", f32), ("seed", u64), ("offset", u64), ("seed_dev", vp),
                 ("dout", vp), ("lddo", i64), ("dq", vp), ("lddq", i64), ("dk", vp), ("lddk", i64),
-                ("dv", vp), ("lddv", i64)]
+                ("dv", vp), ("lddv", i64), ("bsk", i64), ("bsv", i64)]
 
 
 class EmbedText(C.Structure):
@@ -94,6 +94,8 @@ def lib():
     L.univl_maxmargin_loss.argtypes = [vp, i32, i32, f32, vp, vp, vp, vp]
     L.univl_crossen_loss.argtypes = [vp, i32, i32, vp, vp, vp]
     L.univl_milnce_loss.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    L.univl_gather_rows.argtypes = [vp, vp, vp, i32, i64, i64, vp]
+    L.univl_log_softmax_rows.argtypes = [vp, i32, i32, i64, vp]
     L.univl_rank_counts.argtypes = [vp, i32, i64, vp, vp, vp]
     L.univl_scale_by_device_scalar.argtypes = [vp, i64, vp, vp]
     L.univl_pair_concat_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
@@ -123,7 +125,7 @@ def lib():
 EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_device_info", "univl_gemm", "univl_gemm_group",
             "univl_layernorm_fwd", "univl_layernorm_bwd", "univl_attention_fwd", "univl_attention_bwd",
             "univl_embed_text_fwd", "univl_embed_text_bwd", "univl_pool_fwd", "univl_pool_bwd",
-            "univl_maxmargin_loss", "univl_crossen_loss", "univl_milnce_loss", "univl_rank_counts", "univl_scale_by_device_scalar", "univl_pair_concat_fwd", "univl_pair_concat_bwd", "univl_postype_fwd", "univl_postype_bwd", "univl_tanh_fwd",
+            "univl_maxmargin_loss", "univl_crossen_loss", "univl_milnce_loss", "univl_rank_counts", "univl_gather_rows", "univl_log_softmax_rows", "univl_scale_by_device_scalar", "univl_pair_concat_fwd", "univl_pair_concat_bwd", "univl_postype_fwd", "univl_postype_bwd", "univl_tanh_fwd",
             "univl_tanh_bwd", "univl_gelu_bwd", "univl_colsum", "univl_scale_ct_by_device_scalar", "univl_simdense_fwd", "univl_simdense_bwd", "univl_ce_loss", "univl_mfm_nce_loss", "univl_grad_sumsq",
             "univl_clip_coef", "univl_scale_grads", "univl_bert_adam", "univl_cast_bf16", "univl_bump_counter", "univl_probe_layouts"]
 

@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(UnivlAttention p, int Sk_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
-    const T* Kg = reinterpret_cast<const T*>(p.k) + (long)b * p.Sk * p.ldk + h * HD;
-    const T* Vg = reinterpret_cast<const T*>(p.v) + (long)b * p.Sk * p.ldv + h * HD;
+    const T* Kg = reinterpret_cast<const T*>(p.k) + (long)b * (p.bsk ? p.bsk : (long)p.Sk * p.ldk) + h * HD;
+    const T* Vg = reinterpret_cast<const T*>(p.v) + (long)b * (p.bsv ? p.bsv : (long)p.Sk * p.ldv) + h * HD;
     // per-wave operands straight from global memory are requested BEFORE the K/V staging round trip (clamped rows:
     // lanes / waves beyond Sq read a valid row and never store), so the kernel pays one global latency, not two
     const int q0 = blockIdx.y * 64 + wave * 16;
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_
     const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
     const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
     const T* Qb = reinterpret_cast<const T*>(p.q) + (long)b * p.Sq * p.ldq + h * HD;
-    const T* Kb = reinterpret_cast<const T*>(p.k) + (long)b * p.Sk * p.ldk + h * HD;
-    const T* Vb = reinterpret_cast<const T*>(p.v) + (long)b * p.Sk * p.ldv + h * HD;
+    const T* Kb = reinterpret_cast<const T*>(p.k) + (long)b * (p.bsk ? p.bsk : (long)p.Sk * p.ldk) + h * HD;
+    const T* Vb = reinterpret_cast<const T*>(p.v) + (long)b * (p.bsv ? p.bsv : (long)p.Sk * p.ldv) + h * HD;
     const T* Ob = reinterpret_cast<const T*>(p.out) + (long)b * p.Sq * p.ldo + h * HD;
     const T* dOb = reinterpret_cast<const T*>(p.dout) + (long)b * p.Sq * p.lddo + h * HD;
 

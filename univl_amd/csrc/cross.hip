@@ -335,6 +335,57 @@ extern "C" int univl_scale_ct_by_device_scalar(int32_t dtype, void* x, int64_t n
     return UNIVL_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* src, uint4* dst, const int32_t* idx, long stride16, long n16) {
+    const int r = blockIdx.y;
+    const uint4* s = src + (long)idx[r] * stride16;
+    uint4* d = dst + (long)r * stride16;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) d[i] = s[i];
+}
+
+__global__ __launch_bounds__(256) void log_softmax_rows_kernel(float* x, int n, long ld) {
+    __shared__ float red[4];
+    float* row = x + (long)blockIdx.x * ld;
+    const int t = threadIdx.x;
+    float mx = -INFINITY;
+    for (int i = t; i < n; i += 256) mx = fmaxf(mx, row[i]);
+    mx = wave_max(mx);
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = t; i < n; i += 256) sum += expf(row[i] - mx);
+    sum = wave_sum(sum);
+    if ((t & 63) == 0) red[t >> 6] = sum;
+    __syncthreads();
+    const float lse = mx + logf((red[0] + red[1]) + (red[2] + red[3]));
+    for (int i = t; i < n; i += 256) row[i] -= lse;
+}
+}  // namespace
+
+extern "C" int univl_gather_rows(const void* src, void* dst, const int32_t* idx, int32_t rows, int64_t row_stride, int64_t copy_bytes,
+                                 hipStream_t stream) {
+    UNIVL_CHECK_ARG(src && dst && idx && rows > 0 && copy_bytes >= 0 && copy_bytes <= row_stride, UNIVL_EINVAL,
+                    "univl_gather_rows: bad argument");
+    UNIVL_CHECK_ARG(aligned16(src) && aligned16(dst) && row_stride % 16 == 0 && copy_bytes % 16 == 0, UNIVL_EALIGN,
+                    "univl_gather_rows: pointers, row stride and copy size must be multiples of 16 bytes");
+    if (copy_bytes == 0) return UNIVL_OK;
+    const long n16 = copy_bytes / 16;
+    long bx = (n16 + 255) / 256; if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)bx, rows), dim3(256), 0, stream, reinterpret_cast<const uint4*>(src),
+                       reinterpret_cast<uint4*>(dst), idx, (long)(row_stride / 16), n16);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+extern "C" int univl_log_softmax_rows(float* x, int32_t rows, int32_t n, int64_t ld, hipStream_t stream) {
+    UNIVL_CHECK_ARG(x && rows > 0 && n > 0 && ld >= n, UNIVL_EINVAL, "univl_log_softmax_rows: bad argument");
+    hipLaunchKernelGGL(log_softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, x, n, (long)ld);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
 extern "C" int univl_simdense_fwd(const float* x, const float* w, const float* b, int32_t rows, float* out, hipStream_t stream) {
     UNIVL_CHECK_ARG(x && w && b && out && rows > 0, UNIVL_EINVAL, "univl_simdense_fwd: bad argument");
     hipLaunchKernelGGL(simdense_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, w, b, rows, out);

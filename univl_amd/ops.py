@@ -116,7 +116,7 @@ def layernorm_bwd(**kw):
 
 def attention_desc(dtype, B, H, Sq, Sk, q, ldq, k, ldk, v, ldv, out, ldo, lse, *, key_mask=None, causal=False,
                    p_drop=0.0, seed=0, offset=0, seed_dev=None, dout=None, lddo=0, dq=None, lddq=0, dk=None, lddk=0,
-                   dv=None, lddv=0):
+                   dv=None, lddv=0, bsk=0, bsv=0):
     """q/k/v/out/... are (tensor, element_offset) pairs or tensors; ld in elements."""
     def ptr(t):
         if t is None:
@@ -131,6 +131,7 @@ def attention_desc(dtype, B, H, Sq, Sk, q, ldq, k, ldk, v, ldv, out, ldo, lse, *
     d.out, d.ldo, d.lse = ptr(out), ldo, _p(lse)
     d.p_drop, d.seed, d.offset, d.seed_dev = p_drop, seed, offset, _p(seed_dev)
     d.dout, d.lddo, d.dq, d.lddq, d.dk, d.lddk, d.dv, d.lddv = ptr(dout), lddo, ptr(dq), lddq, ptr(dk), lddk, ptr(dv), lddv
+    d.bsk, d.bsv = bsk, bsv
     return d
 
 
@@ -207,6 +208,17 @@ def milnce_loss(sim, batch_size, n_pair, loss, dsim):
 
 def scale_by_device_scalar(x, s):
     _lib.check(_lib.lib().univl_scale_by_device_scalar(_p(x), x.numel(), _p(s), _stream()), "scale_by_device_scalar")
+
+
+def gather_rows(src, dst, idx, rows, row_stride_bytes, copy_bytes):
+    _require_gpu(src, dst, idx)
+    _lib.check(_lib.lib().univl_gather_rows(_p(src), _p(dst), _p(idx), rows, row_stride_bytes, copy_bytes, _stream()), "gather_rows")
+
+
+def log_softmax_rows(x, n):
+    """x: [rows, ld] fp32 (ld >= n), in place over the first n columns."""
+    _require_gpu(x)
+    _lib.check(_lib.lib().univl_log_softmax_rows(_p(x), x.shape[0], n, x.stride(0), _stream()), "log_softmax_rows")
 
 
 def rank_counts(sim):
