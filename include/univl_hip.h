@@ -69,6 +69,13 @@ typedef struct UnivlGemm {
     int32_t flags;
     int32_t ksplit;        /* >1: split the contraction over gridDim.z, fp32 atomics into pre-zeroed C32 */
     int32_t tile;          /* 0 auto, 64, 128 */
+    /* optional, no split-K: every wave stores the sum of squares of the FINAL values it wrote to
+     *   sumsq[(m0 / sumsq_rows) * sumsq_stride + (((m0 % sumsq_rows) / tile) * tiles_x + tile_x) * 4 + wave]
+     * (sumsq_rows = 0: the whole output is one tensor).  Partial sums, no atomics: thousands of workgroups adding to one
+     * address serialise in L2.  univl_sumsq_finish folds them into per-tensor sums.  Lets the weight-gradient GEMMs
+     * produce the gradient norms clip_grad_norm_ (main_task_retrieval.py:347) and BertAdam's per-parameter clip
+     * (optimization.py:135-136) need, instead of a separate 4 B/param pass.  sumsq_rows must be a multiple of 128. */
+    float* sumsq; int32_t sumsq_rows; int32_t sumsq_stride;
 } UnivlGemm;
 int univl_gemm(const UnivlGemm* desc, hipStream_t stream);
 /* n (1..UNIVL_GEMM_GROUP_MAX) independent problems with the same dtype / trans_a / trans_b in ONE launch: the four
@@ -223,6 +230,10 @@ int univl_gather_rows(const void* src, void* dst, const int32_t* idx, int32_t ro
 /* x[r, 0:n) <- log_softmax(x[r, 0:n)) in place, fp32 rows ld apart (torch.nn.functional.log_softmax of
  * main_task_caption.py:454 over the vocabulary) */
 int univl_log_softmax_rows(float* x, int32_t rows, int32_t n, int64_t ld, hipStream_t stream);
+/* out[seg[e]] = sum(partials[start[e] .. start[e] + count[e])) for e < n: folds the per-wave partial sums written by the
+ * weight-gradient GEMMs (UnivlGemm.sumsq) into the per-tensor sums of squares */
+int univl_sumsq_finish(const float* partials, const int32_t* seg, const int32_t* start, const int32_t* count, int32_t n,
+                       float* out, hipStream_t stream);
 /* x (compute type) *= s[0], s on the device */
 int univl_scale_ct_by_device_scalar(int32_t dtype, void* x, int64_t n, const float* s, hipStream_t stream);
 int univl_simdense_fwd(const float* x, const float* w, const float* b, int32_t rows, float* out, hipStream_t stream);

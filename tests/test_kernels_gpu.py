@@ -175,6 +175,39 @@ def test_gemm_group_wgrads(dtype, T):
         ops.gemm_group(mixed)                              # different operand layouts
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_fused_sum_of_squares(dtype):
+    """UnivlGemm.sumsq: the wgrad epilogue accumulates the per-tensor sum of squares of what it stores (single tensor,
+    fused q/k/v group with one accumulator per 768 rows, accumulate mode = squares of the FINAL values)."""
+    T = 200
+    dY = gen(T, 2304, seed=1).to(DEV, dtype)
+    X = gen(T, 768, seed=2).to(DEV, dtype)
+    out = torch.full((2304, 768), 0.5, device=DEV)
+    stride = (768 // 64) * (768 // 64) * 4
+    part = torch.zeros(3 * stride + 8, device=DEV)
+    for tile in (64, 128):
+        part.zero_()
+        out.fill_(0.5)
+        ops.gemm(dY, X, 2304, 768, T, trans_a=True, trans_b=True, out32=out, accumulate=True, sumsq=part, sumsq_rows=768,
+                 sumsq_stride=stride, tile=tile)
+        ref = (out.double() ** 2).view(3, -1).sum(1).cpu()
+        assert float(part[3 * stride:].abs().max()) == 0.0
+        assert rel_err(part[:3 * stride].view(3, stride).sum(1), ref) < 1e-5
+        seg = torch.tensor([4, 0, 2], dtype=torch.int32, device=DEV)
+        start = torch.tensor([0, stride, 2 * stride], dtype=torch.int32, device=DEV)
+        count = torch.full((3,), stride, dtype=torch.int32, device=DEV)
+        res = torch.full((5,), -1.0, device=DEV)
+        ops.sumsq_finish(part, seg, start, count, res)
+        assert rel_err(res[[4, 0, 2]], ref) < 1e-5 and float(res[1]) == -1.0 and float(res[3]) == -1.0
+    one = torch.zeros(stride, device=DEV)
+    o2 = torch.zeros(768, 768, device=DEV)
+    d0 = ops.gemm_desc(dY[:, :768].contiguous(), X, 768, 768, T, trans_a=True, trans_b=True, out32=o2, sumsq=one)
+    ops.gemm_group([d0, ops.gemm_desc(dY, X, 2304, 768, T, trans_a=True, trans_b=True, out32=out)])
+    assert rel_err(one.sum().reshape(1), (o2.double() ** 2).sum().cpu().reshape(1)) < 1e-5
+    with pytest.raises(RuntimeError):
+        ops.gemm(dY, X, 2304, 768, T, trans_a=True, trans_b=True, out32=out, sumsq=part, ksplit=2)
+
+
 def test_gemm_argument_errors():
     A = torch.zeros(8, 256, device=DEV)
     B = torch.zeros(8, 256, device=DEV)
@@ -548,3 +581,45 @@ def test_mfm_nce_loss():
     ops.mfm_nce_loss(buf, vmask.to(DEV), lab.to(DEV), scr, loss, buf)          # gradient written in place
     assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
     assert rel_err(buf, x.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------- decoding / evaluation helpers
+def test_gather_rows_and_log_softmax_rows():
+    R, T, W2 = 7, 6, 1536
+    src = torch.randn(R, T, W2, generator=torch.Generator().manual_seed(1)).to(DEV, torch.bfloat16)
+    dst = torch.zeros_like(src)
+    idx = torch.tensor([3, 3, 0, 6, 1, 2, 5], dtype=torch.int32, device=DEV)
+    ops.gather_rows(src, dst, idx, R, T * W2 * 2, 4 * W2 * 2)          # positions [0, 4) of the parent rows
+    assert torch.equal(dst[:, :4], src[idx.long(), :4]) and float(dst[:, 4:].abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        ops.gather_rows(src, dst, idx, R, T * W2 * 2, 4 * W2 * 2 + 8)  # not a multiple of 16 bytes
+    x = gen(5, 30528, seed=2, scale=3.0).to(DEV)
+    ref = torch.log_softmax(x[:, :30522].double().cpu(), dim=-1)
+    tail = x[:, 30522:].clone()
+    ops.log_softmax_rows(x, 30522)
+    assert float((x[:, :30522].double().cpu() - ref).abs().max()) < 1e-5
+    assert torch.equal(x[:, 30522:], tail)                              # padding columns untouched
+
+
+def test_rank_counts():
+    x = gen(33, 33, seed=4).to(DEV)
+    x[5, 7] = x[5, 5]
+    gt, eq = ops.rank_counts(x)
+    d = x.diag()[:, None]
+    assert torch.equal(gt.long(), (x > d).sum(1)) and torch.equal(eq.long(), (x == d).sum(1))
+
+
+def test_attention_kv_cache_strides():
+    """Sq = 1 queries over a key/value cache of capacity Tmax > Sk (batch strides) == dense attention on the prefix."""
+    dt = ops.dtype_code(torch.float32)
+    B, NH, Tmax, t = 3, 12, 10, 6
+    cache = gen(B, Tmax, 2 * 768, seed=5).to(DEV)
+    q = gen(B, 768, seed=6).to(DEV)
+    out = torch.zeros(B, 768, device=DEV); lse = torch.zeros(B * NH, device=DEV)
+    ops.attention_fwd(dt, B, NH, 1, t, q, 768, (cache, 0), 2 * 768, (cache, 768), 2 * 768, out, 768, lse,
+                      bsk=Tmax * 2 * 768, bsv=Tmax * 2 * 768)
+    k = cache[:, :t, :768].reshape(B, t, NH, 64).permute(0, 2, 1, 3).double().cpu()
+    v = cache[:, :t, 768:].reshape(B, t, NH, 64).permute(0, 2, 1, 3).double().cpu()
+    qq = q.reshape(B, 1, NH, 64).permute(0, 2, 1, 3).double().cpu()
+    ref = (torch.softmax(qq @ k.transpose(-1, -2) / 8.0, -1) @ v).permute(0, 2, 1, 3).reshape(B, 768)
+    assert rel_err(out, ref) < 1e-5

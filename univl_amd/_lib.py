@@ -18,7 +18,7 @@ class Gemm(C.Structure):
     _fields_ = [("dtype", i32), ("trans_a", i32), ("trans_b", i32), ("M", i32), ("N", i32), ("K", i32),
                 ("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C32", vp), ("C16", vp), ("ldc", i64),
                 ("bias", vp), ("R", vp), ("ldr", i64), ("aux", vp), ("ldaux", i64), ("dbias", vp),
-                ("alpha", f32), ("flags", i32), ("ksplit", i32), ("tile", i32)]
+                ("alpha", f32), ("flags", i32), ("ksplit", i32), ("tile", i32), ("sumsq", vp), ("sumsq_rows", i32), ("sumsq_stride", i32)]
 
 
 class LayerNorm(C.Structure):
@@ -112,6 +112,7 @@ def lib():
     L.univl_ce_loss.argtypes = [i32, vp, i64, vp, i32, i32, i32, vp, vp, vp, i64, vp]
     L.univl_mfm_nce_loss.argtypes = [vp, i64, vp, vp, i32, vp, vp, vp, i64, vp]
     L.univl_grad_sumsq.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp]
+    L.univl_sumsq_finish.argtypes = [vp, vp, vp, vp, i32, vp, vp]
     L.univl_clip_coef.argtypes = [vp, vp, i32, f32, vp, vp]
     L.univl_scale_grads.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
     L.univl_cast_bf16.argtypes = [vp, vp, i64, vp]
@@ -126,7 +127,7 @@ EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_dev
             "univl_layernorm_fwd", "univl_layernorm_bwd", "univl_attention_fwd", "univl_attention_bwd",
             "univl_embed_text_fwd", "univl_embed_text_bwd", "univl_pool_fwd", "univl_pool_bwd",
             "univl_maxmargin_loss", "univl_crossen_loss", "univl_milnce_loss", "univl_rank_counts", "univl_gather_rows", "univl_log_softmax_rows", "univl_scale_by_device_scalar", "univl_pair_concat_fwd", "univl_pair_concat_bwd", "univl_postype_fwd", "univl_postype_bwd", "univl_tanh_fwd",
-            "univl_tanh_bwd", "univl_gelu_bwd", "univl_colsum", "univl_scale_ct_by_device_scalar", "univl_simdense_fwd", "univl_simdense_bwd", "univl_ce_loss", "univl_mfm_nce_loss", "univl_grad_sumsq",
+            "univl_tanh_bwd", "univl_gelu_bwd", "univl_colsum", "univl_scale_ct_by_device_scalar", "univl_simdense_fwd", "univl_simdense_bwd", "univl_ce_loss", "univl_mfm_nce_loss", "univl_grad_sumsq", "univl_sumsq_finish",
             "univl_clip_coef", "univl_scale_grads", "univl_bert_adam", "univl_cast_bf16", "univl_bump_counter", "univl_probe_layouts"]
 
 

@@ -31,6 +31,7 @@ struct GemmArgs {
     float alpha;
     int flags;
     int ksplit_len;   // contraction length handled by one z-slice (multiple of BK)
+    float* sumsq; int sumsq_rows, sumsq_stride;
 };
 
 // One operand tile in LDS: UNPADDED rows of RB = 128 or 256 bytes, filled by direct global->LDS DMA
@@ -291,6 +292,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #pragma unroll
         for (int b = 0; b < NI; ++b) bv[b] = 0.0f;
     }
+    float ssq = 0.0f;
 #pragma unroll
     for (int a = 0; a < MI; ++a) {
         float ev[NI][4];
@@ -351,8 +353,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 } else {
                     if (p.C32) p.C32[o] = ev[b][r];
                     if (C16) C16[o] = from_f32<T>(ev[b][r]);
+                    ssq += ev[b][r] * ev[b][r];
                 }
             }
+    }
+    if (p.sumsq) {                               // per-wave partial sums, plain stores (see univl_hip.h)
+        ssq = wave_sum(ssq);
+        const int tensor = p.sumsq_rows > 0 ? m0 / p.sumsq_rows : 0;
+        const int mloc = p.sumsq_rows > 0 ? m0 % p.sumsq_rows : m0;
+        const int nx = (p.N + BN - 1) / BN;
+        if (lane == 0) p.sumsq[(long)tensor * p.sumsq_stride + ((mloc / BM) * nx + bx) * 4 + wave] = ssq;
     }
     if (want_dbias && tid < BM) {
         const int row = m0 + tid;
@@ -499,11 +509,14 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, bool& big, int&
     }
     UNIVL_CHECK_ARG(!(d->dbias && !d->trans_a), UNIVL_EINVAL, "univl_gemm: dbias only with T-major A (wgrad)");
     UNIVL_CHECK_ARG(!((flags & UNIVL_GEMM_ACCUM) && !d->C32), UNIVL_EINVAL, "univl_gemm: ACCUM needs the fp32 output");
+    UNIVL_CHECK_ARG(!(d->sumsq && (ksplit > 1 || d->sumsq_rows < 0 || d->sumsq_rows % 128 != 0)), UNIVL_EINVAL,
+                    "univl_gemm: sumsq needs ksplit = 1 and sumsq_rows a multiple of 128");
     a.A = d->A; a.B = d->B; a.lda = d->lda; a.ldb = d->ldb; a.M = d->M; a.N = d->N; a.K = d->K;
     a.C32 = d->C32; a.C16 = d->C16; a.ldc = d->ldc; a.bias = d->bias; a.R = d->R; a.ldr = d->ldr;
     a.aux = d->aux; a.ldaux = d->ldaux; a.dbias = d->dbias; a.alpha = d->alpha;
     a.flags = flags | (ksplit > 1 ? UNIVL_GEMM_ATOMIC : 0);
     a.ksplit_len = klen;
+    a.sumsq = d->sumsq; a.sumsq_rows = d->sumsq_rows; a.sumsq_stride = d->sumsq_stride;
     return UNIVL_OK;
 }
 
@@ -514,7 +527,7 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
     const int rc = prepare(d, a, ksplit, big, nc);
     if (rc != UNIVL_OK) return rc;
     if (d->dtype == UNIVL_F32 && !d->trans_a && !d->trans_b && d->M <= 32 && d->N <= 32 && ksplit == 1 && d->tile == 0 &&
-        !d->bias && !d->R && !d->dbias && !(d->flags & (UNIVL_GEMM_GELU_FWD | UNIVL_GEMM_GELU_BWD))) {
+        !d->bias && !d->R && !d->dbias && !d->sumsq && !(d->flags & (UNIVL_GEMM_GELU_FWD | UNIVL_GEMM_GELU_BWD))) {
         hipLaunchKernelGGL(dot_kernel, dim3(d->N, d->M), dim3(256), 0, stream, a);
         UNIVL_LAUNCH_CHECK();
         return UNIVL_OK;

@@ -181,6 +181,25 @@ extern "C" int univl_grad_sumsq(const float* g, const UnivlSeg* segs, int32_t ns
     return UNIVL_OK;
 }
 
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* partials, const int32_t* seg, const int32_t* start,
+                                                           const int32_t* count, float* out) {
+    __shared__ float red[4];
+    const int e = blockIdx.x;
+    const float* p = partials + start[e];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < count[e]; i += 256) acc += p[i];
+    const float s = block_sum256(acc, red);
+    if (threadIdx.x == 0) out[seg[e]] = s;
+}
+
+extern "C" int univl_sumsq_finish(const float* partials, const int32_t* seg, const int32_t* start, const int32_t* count,
+                                  int32_t n, float* out, hipStream_t stream) {
+    UNIVL_CHECK_ARG(partials && seg && start && count && out && n > 0, UNIVL_EINVAL, "univl_sumsq_finish: bad argument");
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(n), dim3(256), 0, stream, partials, seg, start, count, out);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
 extern "C" int univl_clip_coef(const float* sumsq, const UnivlSeg* segs, int32_t nseg, float max_norm, float* coef,
                                hipStream_t stream) {
     UNIVL_CHECK_ARG(sumsq && segs && coef && nseg > 0, UNIVL_EINVAL, "univl_clip_coef: bad argument");

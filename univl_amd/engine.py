@@ -68,6 +68,13 @@ class FlatParams:
         self.grad_version = 0        # bumped by every backward; pairs a clip measurement with the gradients it saw
         self._clip = None
         self._pending = None
+        # per-tensor sums of squared gradients written by the weight-gradient GEMMs themselves (UnivlGemm.sumsq)
+        self.seg_of = {n: i for i, n in enumerate(self.order)}
+        self.sumsq = torch.zeros(len(self.order), device=self.device, dtype=torch.float32)
+        # per-wave partial sums: <= 4 per 64x64 output tile of every matrix
+        m_elems = self.total - self.v_end
+        self.partials = torch.zeros(m_elems // 1024 + 8 * len(self.order) + 64, device=self.device, dtype=torch.float32)
+        self.fused = None            # dict(version=grad_version, names=frozenset) once a backward produced them
         FLAT_REGISTRY.add(self)
 
     def is_atomic(self, name):
@@ -127,8 +134,30 @@ class GradState:
     a module that runs twice in one step) and every backward under gradient accumulation use beta = 1.  Tensors of the
     atomic region are zeroed by one memset when fresh and always accumulated into."""
 
-    def __init__(self, flat, fresh):
+    def __init__(self, flat, fresh, fuse_sumsq=False):
         self.flat, self.fresh, self.written = flat, fresh, set()
+        self.fuse_sumsq, self.covered = bool(fuse_sumsq), set()
+        self.slots, self.entries = 0, []             # partial-sum slots handed out; (segment, start, count) per tensor
+
+    def sumsq_args(self, names, rows_per_tensor, cols):
+        """Keyword arguments for the weight-gradient GEMM that writes `names` (one matrix, or the adjacent matrices of a
+        fused projection, each rows_per_tensor x cols): have its epilogue store per-wave partial sums of squares.
+        Only in configurations where every matrix has exactly one writer per backward (checked here)."""
+        if isinstance(names, str):
+            names = [names]
+        if not self.fuse_sumsq or any(self.flat.is_atomic(n) for n in names) or rows_per_tensor % 128 != 0:
+            return {}
+        if any(n in self.covered for n in names):
+            raise RuntimeError("fused gradient norms: %s has a second writer in this backward" % (names,))
+        self.covered.update(names)
+        stride = (rows_per_tensor // 64) * ((cols + 63) // 64) * 4          # slots per tensor with the smallest tile
+        start = self.slots
+        for t, n in enumerate(names):
+            self.entries.append((self.flat.seg_of[n], start + t * stride, stride))
+        self.slots += stride * len(names)
+        if self.slots > self.flat.partials.numel():
+            raise RuntimeError("fused gradient norms: partial-sum buffer too small")
+        return dict(sumsq=self.flat.partials[start:], sumsq_rows=rows_per_tensor if len(names) > 1 else 0, sumsq_stride=stride)
 
     def acc(self, name):
         if self.flat.is_atomic(name):
@@ -136,6 +165,15 @@ class GradState:
         a = (not self.fresh) or (name in self.written)
         self.written.add(name)
         return a
+
+    def finish(self, plan):
+        """Zeroing of the partial sums goes to the front of the backward (caller), this fold to its end."""
+        if not self.entries:
+            return
+        dev = self.flat.device
+        seg, start, count = (torch.tensor(x, dtype=torch.int32, device=dev) for x in zip(*self.entries))
+        out = self.flat.sumsq
+        plan.add_callable(lambda: ops.sumsq_finish(self.flat.partials, seg, start, count, out))
 
 
 class Plan:
@@ -286,7 +324,8 @@ class Plan:
 
 
 def _gemm_desc(dt, A, lda, B, ldb, M, N, K, *, trans_a=0, trans_b=0, out32=None, out16=None, ldc=0, bias=None,
-               residual=None, ldr=0, aux=None, ldaux=0, gelu=None, accumulate=False, dbias=None, ksplit=1, tile=0):
+               residual=None, ldr=0, aux=None, ldaux=0, gelu=None, accumulate=False, dbias=None, ksplit=1, tile=0,
+               sumsq=None, sumsq_rows=0, sumsq_stride=0):
     d = _lib.Gemm()
     d.dtype, d.trans_a, d.trans_b, d.M, d.N, d.K = dt, trans_a, trans_b, M, N, K
     d.A, d.lda, d.B, d.ldb = A.data_ptr(), lda, B.data_ptr(), ldb
@@ -306,6 +345,7 @@ def _gemm_desc(dt, A, lda, B, ldb, M, N, K, *, trans_a=0, trans_b=0, out32=None,
     elif gelu == "bwd":
         flags |= _lib.GEMM_GELU_BWD
     d.flags, d.ksplit, d.tile = flags, ksplit, tile
+    d.sumsq, d.sumsq_rows, d.sumsq_stride = (sumsq.data_ptr() if sumsq is not None else None), sumsq_rows, sumsq_stride
     return d
 
 
@@ -454,11 +494,12 @@ class EncoderStack:
                 dgamma=fl.g(nm["ln2_g"]), dbeta=fl.g(nm["ln2_b"]), dbias=fl.g(nm["b2"]), p_pre=p, off_pre=ws["off"][2],
                 seed_dev=self.seed_dev), sm)
             wgrads = [_gemm_desc(dt, self.dxd, H, ws["f"], I, H, I, T, trans_a=1, trans_b=1,
-                                 out32=fl.g(nm["w2"]), ldc=I, accumulate=gs.acc(nm["w2"]))]
+                                 out32=fl.g(nm["w2"]), ldc=I, accumulate=gs.acc(nm["w2"]), **gs.sumsq_args(nm["w2"], H, I))]
             plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, fl.wop(nm["w2"]), I, T, I, H, trans_b=1, out16=self.du,
                                               ldc=I, aux=ws["u"], ldaux=I, gelu="bwd"), sm)
             wgrads.append(_gemm_desc(dt, self.du, I, ws["a16"], H, I, H, T, trans_a=1, trans_b=1,
-                                     out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=fl.g(nm["b1"])))
+                                     out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=fl.g(nm["b1"]),
+                                     **gs.sumsq_args(nm["w1"], I, H)))
             plan.add("univl_gemm", _gemm_desc(dt, self.du, I, fl.wop(nm["w1"]), H, T, H, I, trans_b=1, out32=da, ldc=H,
                                               residual=dz, ldr=H, ksplit=self.ksplit_for(I)), sm)
             # attention-output LayerNorm / dropout backward (BertSelfOutput, module_bert.py:207-211)
@@ -468,7 +509,7 @@ class EncoderStack:
                 dgamma=fl.g(nm["ln1_g"]), dbeta=fl.g(nm["ln1_b"]), dbias=fl.g(nm["o_b"]), p_pre=p, off_pre=ws["off"][1],
                 seed_dev=self.seed_dev), sm)
             wgrads.append(_gemm_desc(dt, self.dxd2, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
-                                     out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"])))
+                                     out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"]), **gs.sumsq_args(nm["o_w"], H, H)))
             plan.add("univl_gemm", _gemm_desc(dt, self.dxd2, H, fl.wop(nm["o_w"]), H, T, H, H, trans_b=1, out16=self.dctx, ldc=H), sm)
             qkv, dqkv = ws["qkv"], self.dqkv
             plan.add("univl_attention_bwd", ops.attention_desc(
@@ -477,7 +518,7 @@ class EncoderStack:
                 dq=(dqkv, 0), lddq=3 * H, dk=(dqkv, H), lddk=3 * H, dv=(dqkv, 2 * H), lddv=3 * H), sm)
             wgrads.append(_gemm_desc(dt, dqkv, 3 * H, xin16, H, 3 * H, H, T, trans_a=1, trans_b=1,
                                      out32=fl.g_fused(nm["qkv_w"]), ldc=H, accumulate=gs.acc(nm["qkv_w"][0]),
-                                     dbias=fl.g_fused(nm["qkv_b"])))
+                                     dbias=fl.g_fused(nm["qkv_b"]), **gs.sumsq_args(nm["qkv_w"], H, H)))
             dx = self.garena[l, 1]
             plan.add("univl_gemm", _gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["qkv_w"]), H, T, H, 3 * H, trans_b=1,
                                               out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ksplit_for(3 * H)), sm)

@@ -562,6 +562,7 @@ class UniVL(UniVLPreTrainedModel):
             plan.run_graphed()          # captured segments + host-issued gradient exchange (univl_amd.graphed)
         else:
             plan.run()
+        fl.fused = dict(version=fl.grad_version, names=plan.fused_names) if plan.fused_names else None
         fl.attach_grads(used)
 
     def forward(self, input_ids, token_type_ids, attention_mask, video, video_mask=None,

@@ -47,7 +47,8 @@ def probe_layouts():
 
 
 def gemm_desc(A, B, M, N, K, *, trans_a=False, trans_b=False, out32=None, out16=None, bias=None, residual=None, aux=None,
-              gelu=None, accumulate=False, dbias=None, dbias_atomic=False, ksplit=1, tile=0, alpha=1.0):
+              gelu=None, accumulate=False, dbias=None, dbias_atomic=False, ksplit=1, tile=0, alpha=1.0, sumsq=None,
+              sumsq_rows=0, sumsq_stride=0):
     _require_gpu(A, B, out32, out16)
     d = _lib.Gemm()
     d.dtype = dtype_code(A.dtype)
@@ -74,6 +75,7 @@ def gemm_desc(A, B, M, N, K, *, trans_a=False, trans_b=False, out32=None, out16=
     if dbias_atomic:
         flags |= _lib.GEMM_DBIAS_ATOMIC
     d.flags, d.ksplit, d.tile = flags, ksplit, tile
+    d.sumsq, d.sumsq_rows, d.sumsq_stride = _p(sumsq), sumsq_rows, sumsq_stride
     return d
 
 
@@ -208,6 +210,11 @@ def milnce_loss(sim, batch_size, n_pair, loss, dsim):
 
 def scale_by_device_scalar(x, s):
     _lib.check(_lib.lib().univl_scale_by_device_scalar(_p(x), x.numel(), _p(s), _stream()), "scale_by_device_scalar")
+
+
+def sumsq_finish(partials, seg, start, count, out):
+    _lib.check(_lib.lib().univl_sumsq_finish(_p(partials), _p(seg), _p(start), _p(count), seg.numel(), _p(out), _stream()),
+               "sumsq_finish")
 
 
 def gather_rows(src, dst, idx, rows, row_stride_bytes, copy_bytes):

@@ -48,6 +48,8 @@ class _Tables:
             lr, wd, mgn, active = seg_cfg.get(n, (0.0, 0.0, 0.0, 0))
             segs[s].offset, segs[s].numel = off, numel
             segs[s].lr, segs[s].weight_decay, segs[s].max_grad_norm, segs[s].active = lr, wd, mgn, int(active)
+            if not active:
+                continue                    # no workgroups for tensors that take no part
             for o in range(0, numel, CHUNK):
                 c_seg.append(s)
                 c_off.append(off + o)
@@ -68,11 +70,33 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _sumsq(fl, tb):
-    tb.sumsq.zero_()
-    _lib.check(_lib.lib().univl_grad_sumsq(fl.g32.data_ptr(), tb.segs.data_ptr(), tb.nseg, tb.chunk_seg.data_ptr(),
-                                           tb.chunk_off.data_ptr(), tb.chunk_len.data_ptr(), tb.nchunk,
-                                           tb.sumsq.data_ptr(), _stream()), "grad_sumsq")
+def _sumsq(fl, tb, out=None, zero=True):
+    out = tb.sumsq if out is None else out
+    if zero:
+        out.zero_()
+    if tb.nchunk > 0:
+        _lib.check(_lib.lib().univl_grad_sumsq(fl.g32.data_ptr(), tb.segs.data_ptr(), tb.nseg, tb.chunk_seg.data_ptr(),
+                                               tb.chunk_off.data_ptr(), tb.chunk_len.data_ptr(), tb.nchunk,
+                                               out.data_ptr(), _stream()), "grad_sumsq")
+
+
+def _measure(fl, cfg, tb):
+    """Per-tensor sums of squares of the gradients in `cfg` -> device tensor [nseg].  Tensors whose weight-gradient GEMM
+    already accumulated its own sum during this backward (engine.GradState.sumsq_args) are not read again: only the
+    rest (embedding tables, vectors, a few small matrices) goes through the streaming kernel."""
+    fused = fl.fused
+    if fused is not None and fused["version"] == fl.grad_version and fused["names"] <= set(cfg) and not fused.get("consumed"):
+        fused["consumed"] = True          # fl.sumsq may be completed once per backward; later callers re-measure
+        rest = {n: c for n, c in cfg.items() if n not in fused["names"]}
+        key = tuple(sorted(rest))
+        tr = fl._rest[1] if (getattr(fl, "_rest", None) is not None and fl._rest[0] == key) else None
+        if tr is None:
+            tr = _Tables(fl, rest)
+            fl._rest = (key, tr)
+        _sumsq(fl, tr, out=fl.sumsq, zero=False)       # the backward zeroed fl.sumsq before its GEMMs added to it
+        return fl.sumsq
+    _sumsq(fl, tb)
+    return tb.sumsq
 
 
 def _active_cfg(fl, params_with_cfg):
@@ -87,6 +111,7 @@ def _active_cfg(fl, params_with_cfg):
         if p.grad.data_ptr() != fl.g(n).data_ptr():
             fl.g(n).copy_(p.grad)          # a foreign gradient tensor: bring it into the flat buffer
             p.grad = fl.g(n)
+            fl.fused = None                # ... whose norm nobody has measured
         cfg[n] = (float(lr), float(wd), float(mgn), 1)
     return cfg
 
@@ -109,17 +134,18 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, deferred=True):
     if tb is None:
         tb = _Tables(fl, cfg)
         fl._clip = (key, tb)
-    _sumsq(fl, tb)
+    sumsq = _measure(fl, cfg, tb)
     L = _lib.lib()
-    _lib.check(L.univl_clip_coef(tb.sumsq.data_ptr(), tb.segs.data_ptr(), tb.nseg, float(max_norm), tb.coef.data_ptr(),
+    _lib.check(L.univl_clip_coef(sumsq.data_ptr(), tb.segs.data_ptr(), tb.nseg, float(max_norm), tb.coef.data_ptr(),
                                  _stream()), "clip_coef")
     if not deferred:
         _lib.check(L.univl_scale_grads(fl.g32.data_ptr(), tb.segs.data_ptr(), tb.chunk_seg.data_ptr(),
                                        tb.chunk_off.data_ptr(), tb.chunk_len.data_ptr(), tb.nchunk, tb.coef.data_ptr(),
                                        _stream()), "scale_grads")
         fl._pending = None
+        fl.fused = None                    # the gradients were rescaled in place
     else:
-        fl._pending = dict(version=fl.grad_version, names=key, sumsq=tb.sumsq, coef=tb.coef)
+        fl._pending = dict(version=fl.grad_version, names=key, sumsq=sumsq, coef=tb.coef)
     return tb.coef[1]
 
 
@@ -204,8 +230,7 @@ class BertAdam(Optimizer):
         if pend is not None and pend["version"] == fl.grad_version and pend["names"] == tuple(sorted(cfg)):
             sumsq, coef_ptr = pend["sumsq"], pend["coef"].data_ptr()      # clip already measured these gradients
         else:
-            _sumsq(fl, tb)
-            sumsq = tb.sumsq
+            sumsq = _measure(fl, cfg, tb)
         fl._pending = None
         g0 = self.param_groups[0]
         d = _lib.Adam()

@@ -653,8 +653,14 @@ def build_step(model, kind, B, W, F, training):
 
     def build_bwd(fresh):
         bwd = Plan()
-        gs = GradState(fl, fresh)
+        # gradient norms from the wgrad epilogues: single-GPU only (after an all-reduce the local sums are not the
+        # norms of the averaged gradients) and only where every matrix has one writer per backward
+        fuse = (cx.red is None and kind in ("joint", "align", "caption") and os.environ.get("UNIVL_FUSED_NORMS", "1") != "0")
+        gs = GradState(fl, fresh, fuse_sumsq=fuse)
         hook, buckets, sched = _ddp_hook(cx, fl, model)
+        if fuse:
+            bwd.add_callable(fl.sumsq.zero_)
+            bwd.add_callable(fl.partials.zero_)
         if fresh:
             bwd.add_callable(fl.g32[:fl.v_end].zero_)
         enc.zero_grads(bwd)
@@ -686,6 +692,8 @@ def build_step(model, kind, B, W, F, training):
             sched[1](bwd)                                  # whatever is still pending + the tail
             bwd.add_callable(cx.red.join, eager=True)
             st.exchange_points = list(sched[0].cuts)
+        gs.finish(bwd)
+        bwd.fused_names = frozenset(gs.covered)
         return bwd
 
     st._build_bwd = build_bwd
