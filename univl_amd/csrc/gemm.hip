@@ -139,8 +139,13 @@ template <typename T, bool TR, int ROWS, int BK> struct Tile {
             const int row = r16 + i;
             if (sizeof(T) == 2) {
                 const int q = c * 4 + (g >> 1), w = (g & 1) * 8;
-                const bf16x4_t lo = *reinterpret_cast<const bf16x4_t*>(stage + byte_of(row, q) + w);
-                const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(stage + byte_of(row, q + 2) + w);
+                // The two row tiles of a wave sit a constant 4096 B apart and hipcc fuses their reads into
+                // ds_read2st64_b64 -- which the LDS serves at 1/4 of the ds_read_b64 rate (32-bank mode, 16-lane
+                // groups: SQ_LDS_BANK_CONFLICT showed 8 extra cycles per instruction).  Opaque offsets keep them apart.
+                int o0 = byte_of(row, q) + w, o1 = byte_of(row, q + 2) + w;
+                asm volatile("" : "+v"(o0), "+v"(o1));
+                const bf16x4_t lo = *reinterpret_cast<const bf16x4_t*>(stage + o0);
+                const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(stage + o1);
                 return Mma<T>::pack(lo, hi);
             } else {
                 return Mma<T>::pack16(stage + byte_of(row, c * 4 + g));
