@@ -162,9 +162,15 @@ typedef struct UnivlEmbedText {
     const uint64_t* seed_dev;
     const float* dout;
     float* dword; float* dpos; float* dtype_emb; float* dgamma; float* dbeta;
+    /* optional [B*S, N]: store each token's word-table gradient row here INSTEAD of scatter-adding it into dword.  Under
+     * data parallelism the dense table gradient (30522 x 768 fp32 = 94 MB, at most B*S non-zero rows) is then exchanged
+     * as (ids, rows) and rebuilt by univl_embed_scatter on every rank. */
+    float* drows;
 } UnivlEmbedText;
 int univl_embed_text_fwd(const UnivlEmbedText* d, hipStream_t stream);
 int univl_embed_text_bwd(const UnivlEmbedText* d, hipStream_t stream);
+/* dword[ids[t]] += scale * rows[t] for t < n (fp32 atomics; rows [n, 768]): the second half of the sparse exchange */
+int univl_embed_scatter(const int64_t* ids, const float* rows, int64_t n, float scale, float* dword, hipStream_t stream);
 
 /* ------------------------------------------------------------------------- pooling / similarity / loss
  * _mean_pooling_for_similarity + F.normalize (modeling.py:327-339, 385-388): masked mean over tokens

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from univl_amd.parallel import BucketReducer, BucketSchedule, merge_ranges
+from univl_amd.parallel import BucketReducer, BucketSchedule, merge_ranges, subtract_range
 
 
 def _free_port():
@@ -68,3 +68,11 @@ def test_bucket_schedule_and_merge():
     assert not s.add(0, 10) and s.add(10, 30)
     assert s.take() == [(0, 30)] and s.take() == [] and s.cuts == [[(0, 30)]]
     assert s.add(100, 200) and s.take() == [(100, 200)]
+
+
+def test_subtract_range():
+    r = [(0, 100), (200, 300)]
+    assert subtract_range(r, 20, 50) == [(0, 20), (50, 100), (200, 300)]
+    assert subtract_range(r, 0, 100) == [(200, 300)]
+    assert subtract_range(r, 90, 250) == [(0, 90), (250, 300)]
+    assert subtract_range(r, 100, 200) == r

@@ -41,7 +41,7 @@ class EmbedText(C.Structure):
     _fields_ = [("dtype", i32), ("B", i32), ("S", i32), ("N", i32), ("ids", vp), ("type_ids", vp), ("word", vp),
                 ("pos", vp), ("type", vp), ("gamma", vp), ("beta", vp), ("eps", f32), ("y", vp), ("stats", vp),
                 ("out32", vp), ("out16", vp), ("p_post", f32), ("seed", u64), ("off_post", u64), ("seed_dev", vp), ("dout", vp),
-                ("dword", vp), ("dpos", vp), ("dtype_emb", vp), ("dgamma", vp), ("dbeta", vp)]
+                ("dword", vp), ("dpos", vp), ("dtype_emb", vp), ("dgamma", vp), ("dbeta", vp), ("drows", vp)]
 
 
 class Pool(C.Structure):
@@ -91,6 +91,7 @@ def lib():
         getattr(L, name).restype = i32
     L.univl_gemm_group.argtypes = [vp, i32, vp]
     L.univl_gemm_group.restype = i32
+    L.univl_embed_scatter.argtypes = [vp, vp, i64, f32, vp, vp]
     L.univl_maxmargin_loss.argtypes = [vp, i32, i32, f32, vp, vp, vp, vp]
     L.univl_crossen_loss.argtypes = [vp, i32, i32, vp, vp, vp]
     L.univl_milnce_loss.argtypes = [vp, i32, i32, i32, vp, vp, vp]
@@ -125,7 +126,7 @@ def lib():
 
 EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_device_info", "univl_gemm", "univl_gemm_group",
             "univl_layernorm_fwd", "univl_layernorm_bwd", "univl_attention_fwd", "univl_attention_bwd",
-            "univl_embed_text_fwd", "univl_embed_text_bwd", "univl_pool_fwd", "univl_pool_bwd",
+            "univl_embed_text_fwd", "univl_embed_text_bwd", "univl_embed_scatter", "univl_pool_fwd", "univl_pool_bwd",
             "univl_maxmargin_loss", "univl_crossen_loss", "univl_milnce_loss", "univl_rank_counts", "univl_gather_rows", "univl_log_softmax_rows", "univl_scale_by_device_scalar", "univl_pair_concat_fwd", "univl_pair_concat_bwd", "univl_postype_fwd", "univl_postype_bwd", "univl_tanh_fwd",
             "univl_tanh_bwd", "univl_gelu_bwd", "univl_colsum", "univl_scale_ct_by_device_scalar", "univl_simdense_fwd", "univl_simdense_bwd", "univl_ce_loss", "univl_mfm_nce_loss", "univl_grad_sumsq", "univl_sumsq_finish",
             "univl_clip_coef", "univl_scale_grads", "univl_bert_adam", "univl_cast_bf16", "univl_bump_counter", "univl_probe_layouts"]

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(UnivlEmbedText p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float dx = rstd * (dy[j][e] * ga[j][e] - s1 - xh[j][e] * s2);
-                unsafeAtomicAdd(p.dword + id * N + col + e, dx);
+                if (p.drows) p.drows[(long)row * N + col + e] = dx;
+                else unsafeAtomicAdd(p.dword + id * N + col + e, dx);
                 unsafeAtomicAdd(p.dpos + (long)s * N + col + e, dx);
                 // token types 0 / 1 (every row of a batch hits the same one or two table rows) are combined per
                 // block below; anything else goes straight to the table
@@ -161,6 +162,21 @@ extern "C" int univl_embed_text_fwd(const UnivlEmbedText* d, hipStream_t stream)
     dim3 grid((d->B * d->S + 3) / 4), block(256);
     if (d->dtype == UNIVL_DT_BF16) hipLaunchKernelGGL((embed_fwd_kernel<__bf16>), grid, block, 0, stream, *d);
     else hipLaunchKernelGGL((embed_fwd_kernel<float>), grid, block, 0, stream, *d);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* ids, const float* rows, float scale, float* dword) {
+    const long t = blockIdx.x;
+    const long id = ids[t];
+    for (int c = threadIdx.x; c < N; c += 256) unsafeAtomicAdd(dword + id * N + c, rows[t * N + c] * scale);
+}
+}  // namespace
+
+extern "C" int univl_embed_scatter(const int64_t* ids, const float* rows, int64_t n, float scale, float* dword, hipStream_t stream) {
+    UNIVL_CHECK_ARG(ids && rows && dword && n > 0, UNIVL_EINVAL, "univl_embed_scatter: bad argument");
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3((unsigned)n), dim3(256), 0, stream, ids, rows, scale, dword);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }

@@ -149,7 +149,7 @@ def attention_bwd(*a, **kw):
 
 def embed_text_desc(dtype, B, S, ids, word, pos, gamma, beta, *, type_ids=None, type_emb=None, eps=1e-12, y=None,
                     stats=None, out32=None, out16=None, p_post=0.0, seed=0, off_post=0, seed_dev=None, dout=None,
-                    dword=None, dpos=None, dtype_emb=None, dgamma=None, dbeta=None):
+                    dword=None, dpos=None, dtype_emb=None, dgamma=None, dbeta=None, drows=None):
     d = _lib.EmbedText()
     d.dtype, d.B, d.S, d.N = dtype, B, S, 768
     d.ids, d.type_ids = _p(ids), _p(type_ids)
@@ -158,6 +158,7 @@ def embed_text_desc(dtype, B, S, ids, word, pos, gamma, beta, *, type_ids=None, 
     d.y, d.stats, d.out32, d.out16 = _p(y), _p(stats), _p(out32), _p(out16)
     d.p_post, d.seed, d.off_post, d.seed_dev = p_post, seed, off_post, _p(seed_dev)
     d.dout, d.dword, d.dpos, d.dtype_emb, d.dgamma, d.dbeta = _p(dout), _p(dword), _p(dpos), _p(dtype_emb), _p(dgamma), _p(dbeta)
+    d.drows = _p(drows)
     return d
 
 
@@ -210,6 +211,11 @@ def milnce_loss(sim, batch_size, n_pair, loss, dsim):
 
 def scale_by_device_scalar(x, s):
     _lib.check(_lib.lib().univl_scale_by_device_scalar(_p(x), x.numel(), _p(s), _stream()), "scale_by_device_scalar")
+
+
+def embed_scatter(ids, rows, scale, dword):
+    _require_gpu(ids, rows, dword)
+    _lib.check(_lib.lib().univl_embed_scatter(_p(ids), _p(rows), ids.numel(), float(scale), _p(dword), _stream()), "embed_scatter")
 
 
 def sumsq_finish(partials, seg, start, count, out):

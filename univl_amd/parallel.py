@@ -64,6 +64,23 @@ class BucketReducer:
             w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self.pending.append((w, t))
 
+    def gather(self, t, out):
+        """out[r] <- rank r's t (all-gather), asynchronously like reduce_slice; out: [world, *t.shape]."""
+        self.calls += 1
+        self.bytes_reduced += out.numel() * out.element_size()
+        if self.loopback:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=t.device)
+            self._comm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm):
+                out[0].copy_(t)
+                ev = torch.cuda.Event()
+                ev.record()
+            self.pending.append((ev, None))
+            return
+        w = dist.all_gather([out[r] for r in range(self.world)], t, group=self.pg, async_op=True)
+        self.pending.append((w, None))
+
     def reduce_ranges(self, ranges):
         for s0, e0 in ranges:
             self.reduce_slice(s0, e0)
@@ -75,7 +92,7 @@ class BucketReducer:
                 torch.cuda.current_stream().wait_event(w)
                 continue
             w.wait()
-            if not self._avg:
+            if not self._avg and t is not None:
                 t.div_(self.world)
         self.pending = []
 
@@ -118,6 +135,20 @@ class BucketSchedule:
         if r:
             self.cuts.append(r)
         return r
+
+
+def subtract_range(ranges, lo, hi):
+    """ranges minus [lo, hi)."""
+    out = []
+    for s0, e0 in ranges:
+        if e0 <= lo or s0 >= hi:
+            out.append((s0, e0))
+            continue
+        if s0 < lo:
+            out.append((s0, lo))
+        if e0 > hi:
+            out.append((hi, e0))
+    return out
 
 
 def layer_buckets(flat, used_names):

@@ -164,11 +164,14 @@ class EncoderPass:
     def _text_tail(self, bwd, dxt):
         cx, n, fl, dt = self.cx, self.N, self.cx.fl, self.cx.dt
         W32, G, p, B, W, ST = fl.w32, fl.g, cx.p, self.B, self.W, self.ST
+        sparse = getattr(self, "sparse_word_grad", False)
+        if sparse and getattr(self, "drows", None) is None:
+            self.drows = cx.e(self.Tt, H)
         bwd.add("univl_embed_text_bwd", ops.embed_text_desc(
             dt, B, W, self.ids, W32(n["bw"]), W32(n["bp"]), W32(n["blg"]), W32(n["blb"]), type_ids=self.type_ids,
             type_emb=W32(n["bt"]), y=self.te, stats=self.test, p_post=p, seed=cx.seed, off_post=self.off_t,
             seed_dev=cx.seed_dev, dout=dxt, dword=G(n["bw"]), dpos=G(n["bp"]), dtype_emb=G(n["bt"]), dgamma=G(n["blg"]),
-            dbeta=G(n["blb"])), ST)
+            dbeta=G(n["blb"]), drows=self.drows if sparse else None), ST)
 
 
 class SimLoss:
@@ -653,6 +656,10 @@ def build_step(model, kind, B, W, F, training):
 
     def build_bwd(fresh):
         bwd = Plan()
+        # Sparse exchange of the word-embedding gradient (94 MB dense, <= B*W non-zero rows): only where the token
+        # gather is the table's sole gradient source (no tied decoder / MLM head in this step).
+        sparse = (cx.red is not None and kind in ("joint", "align") and os.environ.get("UNIVL_SPARSE_EMB", "1") != "0")
+        enc.sparse_word_grad = sparse
         # gradient norms from the wgrad epilogues: single-GPU only (after an all-reduce the local sums are not the
         # norms of the averaged gradients) and only where every matrix has one writer per backward
         fuse = (cx.red is None and kind in ("joint", "align", "caption") and os.environ.get("UNIVL_FUSED_NORMS", "1") != "0")
@@ -687,10 +694,27 @@ def build_step(model, kind, B, W, F, training):
             st.enc_m.build_backward(bwd, gs, hook)
         enc.build_backward(bwd, gs, hook)
         if cx.red is not None:
-            for (s0, e0) in buckets["tail"]:
+            red, tail = cx.red, buckets["tail"]
+            if sparse:
+                from .parallel import subtract_range
+                wname = EncoderPass.N["bw"]
+                wo, wk, _ = fl.index[wname]
+                tail = subtract_range(tail, wo, wo + (wk + 63) // 64 * 64)
+                world = max(1, red.world)
+                ids_all = torch.zeros(world, enc.Tt, dtype=torch.int64, device=cx.dev)
+                rows_all = torch.zeros(world, enc.Tt, H, device=cx.dev)
+                st.sparse_exchange = dict(tokens=enc.Tt, bytes=rows_all.numel() * 4 + ids_all.numel() * 8)
+
+                def gather_tokens():
+                    red.gather(enc.ids.view(-1), ids_all)
+                    red.gather(enc.drows, rows_all)
+                bwd.add_callable(gather_tokens, eager=True)
+            for (s0, e0) in tail:
                 sched[0].add(s0, e0)
             sched[1](bwd)                                  # whatever is still pending + the tail
-            bwd.add_callable(cx.red.join, eager=True)
+            bwd.add_callable(red.join, eager=True)
+            if sparse:                                     # rebuild the dense table gradient: mean over ranks
+                bwd.add_callable(lambda: ops.embed_scatter(ids_all.view(-1), rows_all.view(-1, H), 1.0 / world, fl.g(wname)))
             st.exchange_points = list(sched[0].cuts)
         gs.finish(bwd)
         bwd.fused_names = frozenset(gs.covered)
