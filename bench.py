@@ -262,6 +262,14 @@ def main():
                     traffic=traffic, algorithmic_bytes_per_launch=alg_bytes, avg_launch_ms=round(upd_ms, 4),
                     step_model=dict(flops_per_pair=37.30e9, achieved_tflops=round(pairs_per_s * 37.30e9 / 1e12, 2),
                                     mfma_peak_tflops=2500.0))
+    exchange = None
+    if model._reducer is not None:
+        stp = [v for v in model._steps.values() if hasattr(v, "exchange_points")]
+        if stp:
+            pts = stp[0].exchange_points
+            exchange = dict(points=len(pts), dense_mb=round(sum(e - s for c in pts for s, e in c) * 4 / 2 ** 20, 1),
+                            sparse_word_embedding=getattr(stp[0], "sparse_exchange", None),
+                            backend="loopback" if model._reducer.loopback else "rccl")
     if rank == 0:
         out = dict(metric="video-text pairs/sec (retrieval finetune, 48x48)", value=round(pairs_per_s, 2), unit="pairs/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
@@ -270,7 +278,7 @@ def main():
                                         "encoder (12 L) + 6-layer visual encoder, max_words=48, max_frames=48, bs=%d per GPU, "
                                         "fwd+bwd+clip+BertAdam, dropout %.2f, random-init weights" % (args.batch, args.dropout),
                                per_gpu_batch=args.batch, global_batch=args.batch * world, max_words=48, max_frames=48,
-                               parallelism="dp%d" % world, hip_graph=graph is not None, graph_mode=mode, host_inputs=bool(args.host_inputs), params=n_params,
+                               parallelism="dp%d" % world, hip_graph=graph is not None, graph_mode=mode, host_inputs=bool(args.host_inputs), exchange=exchange, params=n_params,
                                last_loss=round(last, 6)),
                    roofline=roofline, cpu_baseline=cpu_base)
         print(json.dumps(out))
