@@ -29,16 +29,44 @@ template <typename T> struct AttnCfg {
     static constexpr int EPC = Mma<T>::EPC;
 };
 
-// stage `rows` x 64 of a [.., ld] matrix (head slice) into LDS, zero-filling up to rows_pad
-template <typename T>
-__device__ __forceinline__ void stage_rows(T* lds, const T* g, long ld, int rows, int rows_pad, int tid) {
+// Stage `rows` x 64 of TWO [.., ld] matrices (head slices: K and V, or Q and dO) into LDS, zero-filling up to rows_pad.
+// All global loads of a trip (2 pieces x 2 matrices per thread, clamped rows) are issued before the first LDS store: at
+// S = 48 that is the whole tile in ONE memory round trip -- a plain "load, store, next piece" loop is not unrolled by
+// hipcc (rows_pad is a run-time value) and pays one round trip per piece and matrix.
+// TRIPS > 0: compile-time trip count (rows_pad <= 64 * TRIPS for bf16), no run-time loop at all -- a loop header makes
+// hipcc drain every load that is already in flight (the per-wave Q / mask / seed requests issued before the staging).
+template <typename T, int TRIPS>
+__device__ __forceinline__ void stage_pair(T* ldsA, const T* gA, long ldA, T* ldsB, const T* gB, long ldB, int rows, int rows_pad,
+                                           int tid) {
     constexpr int EPC = AttnCfg<T>::EPC, P = AttnCfg<T>::P;
     constexpr int CPR = HD / EPC;   // 16-byte pieces per row
-    for (int c = tid; c < rows_pad * CPR; c += 256) {
-        const int r = c / CPR, e = (c % CPR) * EPC;
-        uint4 v = *reinterpret_cast<const uint4*>(g + (long)min(r, rows - 1) * ld + e);   // unconditional load
-        if (r >= rows) v = make_uint4(0u, 0u, 0u, 0u);
-        *reinterpret_cast<uint4*>(lds + r * P + e) = v;
+    constexpr int UNR = 2;
+    const int total = rows_pad * CPR;
+    const int c_end = TRIPS > 0 ? tid + TRIPS * 256 * UNR : total;
+#pragma unroll
+    for (int c0 = tid; c0 < c_end; c0 += 256 * UNR) {
+        uint4 va[UNR], vb[UNR];
+        int rr[UNR], ee[UNR];
+        bool ok[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int c = c0 + 256 * u;
+            ok[u] = c < total;
+            const int cc = min(c, total - 1);
+            rr[u] = cc / CPR;
+            ee[u] = (cc % CPR) * EPC;
+            const long row = min(rr[u], rows - 1);
+            va[u] = *reinterpret_cast<const uint4*>(gA + row * ldA + ee[u]);
+            vb[u] = *reinterpret_cast<const uint4*>(gB + row * ldB + ee[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (rr[u] >= rows) { va[u] = make_uint4(0u, 0u, 0u, 0u); vb[u] = make_uint4(0u, 0u, 0u, 0u); }
+            if (ok[u]) {
+                *reinterpret_cast<uint4*>(ldsA + rr[u] * P + ee[u]) = va[u];
+                *reinterpret_cast<uint4*>(ldsB + rr[u] * P + ee[u]) = vb[u];
+            }
+        }
     }
 }
 
@@ -50,12 +78,28 @@ __device__ __forceinline__ float key_bias(const float* sM, int key, int q, int S
     return m;
 }
 
-__device__ __forceinline__ void stage_mask(float* sM, const int64_t* key_mask, int b, int Sk, int Sk_pad, int tid) {
-    for (int k = tid; k < Sk_pad; k += 256) {
-        float m = 0.0f;
-        if (k < Sk && key_mask != nullptr && key_mask[(long)b * Sk + k] == 0) m = -10000.0f;
-        sM[k] = m;
+// Additive key mask into LDS in two halves so that its global load travels together with the tile staging loads:
+// mask_fetch issues the loads (clamped index; a null mask reads a dummy word through a SELECTED pointer -- a branch
+// around a load makes hipcc wait for every outstanding load at the join), mask_store writes sM after the staging.
+struct MaskRegs { long v[2]; };
+__device__ __forceinline__ MaskRegs mask_fetch(const int64_t* key_mask, const void* dummy, int b, int Sk, int tid) {
+    const int64_t* km = key_mask ? key_mask + (long)b * Sk : reinterpret_cast<const int64_t*>(dummy);
+    MaskRegs m;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) m.v[u] = km[key_mask ? min(tid + 256 * u, Sk - 1) : 0];
+    return m;
+}
+__device__ __forceinline__ void mask_store(float* sM, const MaskRegs& m, bool has_mask, int Sk, int Sk_pad, int tid) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int k = tid + 256 * u;
+        if (k < Sk_pad) sM[k] = (has_mask && k < Sk && m.v[u] == 0) ? -10000.0f : 0.0f;
     }
+}
+__device__ __forceinline__ uint64_t seed_fetch(const UnivlAttention& p) {
+    const uint64_t* sp = p.seed_dev ? p.seed_dev : reinterpret_cast<const uint64_t*>(p.q);
+    const uint64_t dv = *sp;
+    return p.seed + (p.seed_dev ? dv : 0ull);
 }
 
 template <typename T>
@@ -93,10 +137,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(UnivlAttention p, int Sk_
     typename M::frag fq[C::NCD];
 #pragma unroll
     for (int c = 0; c < C::NCD; ++c) fq[c] = M::gmem_kmajor(Qg + c * C::CH, g);
-    const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
-    stage_rows<T>(sK, Kg, p.ldk, p.Sk, Sk_pad, tid);
-    stage_rows<T>(sV, Vg, p.ldv, p.Sk, Sk_pad, tid);
-    stage_mask(sM, p.key_mask, b, p.Sk, Sk_pad, tid);
+    const uint64_t seed = seed_fetch(p);
+    const MaskRegs mk = mask_fetch(p.key_mask, p.q, b, p.Sk, tid);
+    constexpr int TRIPS = (MAXKT * 16 * (HD / C::EPC) <= 1024) ? (MAXKT * 16 * (HD / C::EPC) + 511) / 512 : 0;
+    stage_pair<T, TRIPS>(sK, Kg, p.ldk, sV, Vg, p.ldv, p.Sk, Sk_pad, tid);
+    mask_store(sM, mk, p.key_mask != nullptr, p.Sk, Sk_pad, tid);
     __syncthreads();
     if (q0 >= p.Sq) return;
 
@@ -172,14 +217,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(UnivlAttention p, int Sk_
 
 // ------------------------------------------------------------------------------------------------ backward
 // role A (blockIdx.y < nqb): dQ for a block of 64 queries.   role B: dK, dV for a block of 64 keys.
-template <typename T>
+template <typename T, int TRIPS>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_pad, int Sq_pad, int nqb, float scale) {
     using C = AttnCfg<T>;
     using M = Mma<T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
-    const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+    const uint64_t seed = seed_fetch(p);
+    const MaskRegs mk = mask_fetch(p.key_mask, p.q, b, p.Sk, tid);
     const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
     const T* Qb = reinterpret_cast<const T*>(p.q) + (long)b * p.Sq * p.ldq + h * HD;
     const T* Kb = reinterpret_cast<const T*>(p.k) + (long)b * (p.bsk ? p.bsk : (long)p.Sk * p.ldk) + h * HD;
@@ -204,9 +250,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_
             fo[c] = M::gmem_kmajor(Ob + (long)qc * p.ldo + c * C::CH, g);
         }
         const float lse = p.lse[(long)bh * p.Sq + qc];
-        stage_rows<T>(sK, Kb, p.ldk, p.Sk, Sk_pad, tid);
-        stage_rows<T>(sV, Vb, p.ldv, p.Sk, Sk_pad, tid);
-        stage_mask(sM, p.key_mask, b, p.Sk, Sk_pad, tid);
+        stage_pair<T, TRIPS>(sK, Kb, p.ldk, sV, Vb, p.ldv, p.Sk, Sk_pad, tid);
+        mask_store(sM, mk, p.key_mask != nullptr, p.Sk, Sk_pad, tid);
         __syncthreads();
         if (q0 >= p.Sq) return;
         float dsum = 0.f;
@@ -269,22 +314,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_
             fk[c] = M::gmem_kmajor(Kb + (long)keyc * p.ldk + c * C::CH, g);
             fv[c] = M::gmem_kmajor(Vb + (long)keyc * p.ldv + c * C::CH, g);
         }
-        stage_rows<T>(sQ, Qb, p.ldq, p.Sq, Sq_pad, tid);
-        stage_rows<T>(sDO, dOb, p.lddo, p.Sq, Sq_pad, tid);
-        stage_mask(sM, p.key_mask, b, p.Sk, Sk_pad, tid);
-        // D[q] = sum_d dO[q,d] O[q,d]: 4 threads per query row, 16 d each, as 16-byte vectors from a clamped row
-        for (int qq = tid >> 2; qq < Sq_pad; qq += 64) {
+        // D[q] = sum_d dO[q,d] O[q,d]: 4 threads per query row, 16 d each, as 16-byte vectors from a clamped row.  With at
+        // most 64 query rows (TRIPS > 0) the row of this thread is known up front and its loads join the staging loads.
+        constexpr int NV = 16 / C::EPC;                          // 16-byte vectors per 16 elements
+        auto d_fetch = [&](int qq, typename M::frag (&vo)[NV], typename M::frag (&vd)[NV], float& l) {
             const int qr = min(qq, p.Sq - 1);
             const T* o = Ob + (long)qr * p.ldo + (tid & 3) * 16;
             const T* d = dOb + (long)qr * p.lddo + (tid & 3) * 16;
-            const float l = p.lse[(long)bh * p.Sq + qr];
-            constexpr int NV = 16 / C::EPC;                      // 16-byte vectors per 16 elements
-            typename M::frag vo[NV], vd[NV];
+            l = p.lse[(long)bh * p.Sq + qr];
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 vo[u] = *reinterpret_cast<const typename M::frag*>(o + u * C::EPC);
                 vd[u] = *reinterpret_cast<const typename M::frag*>(d + u * C::EPC);
             }
+        };
+        auto d_store = [&](int qq, const typename M::frag (&vo)[NV], const typename M::frag (&vd)[NV], float l) {
             float acc = 0.f;
 #pragma unroll
             for (int u = 0; u < NV; ++u)
@@ -292,9 +336,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_
                 for (int e = 0; e < C::EPC; ++e) acc += to_f32<T>(vo[u][e]) * to_f32<T>(vd[u][e]);
             acc += __shfl_xor(acc, 1, 64);
             acc += __shfl_xor(acc, 2, 64);
-            if ((tid & 3) == 0) {
+            if ((tid & 3) == 0 && qq < Sq_pad) {
                 sD[qq] = qq < p.Sq ? acc : 0.0f;
                 sL[qq] = qq < p.Sq ? l : 0.0f;
+            }
+        };
+        typename M::frag vo0[NV], vd0[NV];
+        float l0 = 0.f;
+        if (TRIPS > 0) d_fetch(tid >> 2, vo0, vd0, l0);
+        stage_pair<T, TRIPS>(sQ, Qb, p.ldq, sDO, dOb, p.lddo, p.Sq, Sq_pad, tid);
+        mask_store(sM, mk, p.key_mask != nullptr, p.Sk, Sk_pad, tid);
+        if (TRIPS > 0) {
+            d_store(tid >> 2, vo0, vd0, l0);
+        } else {
+            for (int qq = tid >> 2; qq < Sq_pad; qq += 64) {
+                typename M::frag vo[NV], vd[NV];
+                float l;
+                d_fetch(qq, vo, vd, l);
+                d_store(qq, vo, vd, l);
             }
         }
         __syncthreads();
@@ -404,14 +463,25 @@ int dispatch_bwd(const UnivlAttention* d, hipStream_t stream) {
     const size_t smemA = (size_t)2 * Sk_pad * AttnCfg<T>::P * sizeof(T) + Sk_pad * sizeof(float);
     const size_t smemB = (size_t)2 * Sq_pad * AttnCfg<T>::P * sizeof(T) + (Sk_pad + 2 * Sq_pad) * sizeof(float);
     const size_t smem = smemA > smemB ? smemA : smemB;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<T>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    constexpr int PIECES64 = 64 * (HD / AttnCfg<T>::EPC);          // 16-byte pieces of a 64-row tile
+    const bool small = Sk_pad <= 64 && Sq_pad <= 64;
+    constexpr int TR = (PIECES64 + 511) / 512;
     dim3 grid(d->B * d->H, nqb + nkb);
-    hipLaunchKernelGGL((attn_bwd_kernel<T>), grid, dim3(256), smem, stream, *d, Sk_pad, Sq_pad, nqb, 0.125f);
+    if (small) {
+        static bool attr_small = false;
+        if (!attr_small) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<T, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_small = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_kernel<T, TR>), grid, dim3(256), smem, stream, *d, Sk_pad, Sq_pad, nqb, 0.125f);
+    } else {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_kernel<T, 0>), grid, dim3(256), smem, stream, *d, Sk_pad, Sq_pad, nqb, 0.125f);
+    }
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
