@@ -43,7 +43,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(UnivlEmbedText p) {
         for (int e = 0; e < 4; ++e) { const float c = v[j][e] - mean; q += c * c; }
     const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / N) + p.eps);
     if (p.stats && lane == 0) { p.stats[2 * (long)row] = mean; p.stats[2 * (long)row + 1] = rstd; }
-    const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+    const uint64_t* sp = p.seed_dev ? p.seed_dev : reinterpret_cast<const uint64_t*>(p.gamma);
+    const uint64_t sdv = *sp;
+    const uint64_t seed = p.seed + (p.seed_dev ? sdv : 0ull);
     const float inv_keep = p.p_post > 0.f ? 1.0f / (1.0f - p.p_post) : 1.0f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -90,7 +92,9 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(UnivlEmbedText p) {
         const long id = p.ids[row];
         const long tt = (p.dtype_emb && p.type_ids) ? p.type_ids[row] : 0;
         const float mean = p.stats[2 * (long)row], rstd = p.stats[2 * (long)row + 1];
-        const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+        const uint64_t* sp = p.seed_dev ? p.seed_dev : reinterpret_cast<const uint64_t*>(p.gamma);
+    const uint64_t sdv = *sp;
+    const uint64_t seed = p.seed + (p.seed_dev ? sdv : 0ull);
     const float inv_keep = p.p_post > 0.f ? 1.0f / (1.0f - p.p_post) : 1.0f;
         float dy[NV][4], xh[NV][4], ga[NV][4];
         float s1 = 0.f, s2 = 0.f;

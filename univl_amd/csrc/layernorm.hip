@@ -15,11 +15,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(UnivlLayerNorm p) {
     const int row = blockIdx.x * 4 + wave;
     if (row >= p.rows) return;
     float v[NV][4];
-    const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+    // Every global operand of the row (seed, x, residual, position row, gamma, beta) is requested up front, from
+    // SELECTED (always valid) pointers instead of inside "if (ptr)" blocks: a branch per operand kind costs one full
+    // memory round trip each (hipcc drains the loads in flight at every join), five in a row for the post-GEMM LayerNorm.
+    const uint64_t* sp = p.seed_dev ? p.seed_dev : reinterpret_cast<const uint64_t*>(p.gamma);
+    const uint64_t sdv = *sp;
+    const uint64_t seed = p.seed + (p.seed_dev ? sdv : 0ull);
     const float inv_keep_pre = p.p_pre > 0.f ? 1.0f / (1.0f - p.p_pre) : 1.0f;
     const float inv_keep_post = p.p_post > 0.f ? 1.0f / (1.0f - p.p_post) : 1.0f;
-    // all loads of one kind are issued back to back inside ONE flag-uniform branch (a branch per load would drain
-    // vmcnt(0) behind each of them)
+    const float* rp = p.residual ? p.residual + (long)row * N : p.gamma;
+    const float* pp = p.pos ? p.pos + (long)(row % (p.pos ? p.pos_period : 1)) * N : p.gamma;
+    float4 rr[NV], pr[NV], gav[NV], bev[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const long o = (long)row * N + 4 * lane + 256 * j;
@@ -33,6 +39,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(UnivlLayerNorm p) {
             v[j][0] = a.x; v[j][1] = a.y; v[j][2] = a.z; v[j][3] = a.w;
         }
     }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int col = 4 * lane + 256 * j;
+        rr[j] = *reinterpret_cast<const float4*>(rp + col);
+        pr[j] = *reinterpret_cast<const float4*>(pp + col);
+        gav[j] = *reinterpret_cast<const float4*>(p.gamma + col);
+        bev[j] = *reinterpret_cast<const float4*>(p.beta + col);
+    }
     if (p.p_pre > 0.f) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -41,20 +55,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(UnivlLayerNorm p) {
             for (int e = 0; e < 4; ++e) v[j][e] *= dropout_scale(seed, p.off_pre, (uint64_t)(o + e), p.p_pre, inv_keep_pre);
         }
     }
-    if (p.residual) {
-        float4 r[NV];
+    const bool useR = p.residual != nullptr, useP = p.pos != nullptr;      // selects, not multiplies: dummy words may be anything
 #pragma unroll
-        for (int j = 0; j < NV; ++j) r[j] = *reinterpret_cast<const float4*>(p.residual + (long)row * N + 4 * lane + 256 * j);
-#pragma unroll
-        for (int j = 0; j < NV; ++j) { v[j][0] += r[j].x; v[j][1] += r[j].y; v[j][2] += r[j].z; v[j][3] += r[j].w; }
-    }
-    if (p.pos) {
-        float4 r[NV];
-        const float* pp = p.pos + (long)(row % p.pos_period) * N;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) r[j] = *reinterpret_cast<const float4*>(pp + 4 * lane + 256 * j);
-#pragma unroll
-        for (int j = 0; j < NV; ++j) { v[j][0] += r[j].x; v[j][1] += r[j].y; v[j][2] += r[j].z; v[j][3] += r[j].w; }
+    for (int j = 0; j < NV; ++j) {
+        v[j][0] += (useR ? rr[j].x : 0.f) + (useP ? pr[j].x : 0.f); v[j][1] += (useR ? rr[j].y : 0.f) + (useP ? pr[j].y : 0.f);
+        v[j][2] += (useR ? rr[j].z : 0.f) + (useP ? pr[j].z : 0.f); v[j][3] += (useR ? rr[j].w : 0.f) + (useP ? pr[j].w : 0.f);
     }
     if (p.y) {
 #pragma unroll
@@ -77,8 +82,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(UnivlLayerNorm p) {
     for (int j = 0; j < NV; ++j) {
         const int col = 4 * lane + 256 * j;
         const long o = (long)row * N + col;
-        const float4 ga = *reinterpret_cast<const float4*>(p.gamma + col);
-        const float4 be = *reinterpret_cast<const float4*>(p.beta + col);
+        const float4 ga = gav[j], be = bev[j];
         float r[4];
         r[0] = (v[j][0] - mean) * rstd * ga.x + be.x;
         r[1] = (v[j][1] - mean) * rstd * ga.y + be.y;
@@ -126,7 +130,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(UnivlLayerNorm p, int rpw) 
     constexpr int NV = N / 256;
     __shared__ float red[4][N];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+    const uint64_t* sp = p.seed_dev ? p.seed_dev : reinterpret_cast<const uint64_t*>(p.gamma);
+    const uint64_t sdv = *sp;
+    const uint64_t seed = p.seed + (p.seed_dev ? sdv : 0ull);
     const float inv_keep_pre = p.p_pre > 0.f ? 1.0f / (1.0f - p.p_pre) : 1.0f;
     const float inv_keep_post = p.p_post > 0.f ? 1.0f / (1.0f - p.p_post) : 1.0f;
     float dg[NV][4], db[NV][4], dbi[NV][4];
