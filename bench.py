@@ -143,7 +143,6 @@ def main():
         cpu_base = cpu_baseline(args.batch)
 
     from univl_amd import UniVL, BertAdam, clip_grad_norm_
-    from univl_amd import _lib
     torch.manual_seed(0)
     tc = task_config(args, world)
     model = UniVL.from_pretrained("bert-base-uncased", "visual-base", "cross-base", "decoder-base", task_config=tc)

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
     from univl_amd import metrics as M
-    from univl_amd.eval import eval_retrieval, similarity_matrix
+    from univl_amd.eval import eval_retrieval
     from test_model_gpu import build
 
 DEV = "cuda"

@@ -21,11 +21,9 @@ Same results as the reference's procedure on the same logits: first step uses be
 an instance is done when its top beam emits EOS (beam.py:84), the reported hypothesis is the best-scored beam walked
 back through the back-pointers (beam.py:108-116, collect_hypothesis_and_scores n_best = 1).
 """
-import ctypes as C
-
 import torch
 
-from . import _lib, ops
+from . import ops
 from .engine import Plan, _gemm_desc
 from .steps import Ctx, CrossRun, RowFeatures, VocabHead, H
 

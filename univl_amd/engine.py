@@ -16,7 +16,6 @@ import weakref
 import torch
 
 from . import _lib, ops
-from ._lib import DT_BF16, DT_F32
 
 _ALIGN = 64  # elements; keeps every tensor 256-byte aligned in fp32 and 128-byte in bf16
 FLAT_REGISTRY = weakref.WeakSet()   # lets the fused optimizer find the flat buffers that own a Parameter

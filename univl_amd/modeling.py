@@ -11,13 +11,12 @@ import json
 import logging
 import os
 
-import numpy as np
 import torch
 from torch import nn
 
 from . import _lib, ops
-from .engine import EncoderStack, FlatParams, Plan, _SiteCounter, _gemm_desc
-from .parallel import BucketReducer, broadcast_parameters, layer_buckets
+from .engine import FlatParams, Plan
+from .parallel import BucketReducer, broadcast_parameters
 
 logger = logging.getLogger(__name__)
 

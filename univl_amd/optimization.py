@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 from torch.optim import Optimizer
 
-from . import _lib, ops
+from . import _lib
 from .engine import FLAT_REGISTRY
 
 CHUNK = 8192   # elements per workgroup
