@@ -114,14 +114,26 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(UnivlPool p) {
     const int s0 = blockIdx.y * PCHUNK, n = min(PCHUNK, p.S - s0);
     float* dx = p.dx + ((long)b * p.S + s0) * PN + t;
     if (p.accumulate) {
-#pragma unroll 4
-        for (int s = 0; s < n; ++s) {
-            const float w = mine[s] * inv_cnt;
-            float old[PC];
+        // read-modify-write of dx: the old values of 8 sequence positions are fetched before the first store (the loads
+        // of position s+1 may not be hoisted above the stores of position s by the compiler: same array)
+        constexpr int UB = 8;
+        for (int s0b = 0; s0b < n; s0b += UB) {
+            float old[UB][PC];
 #pragma unroll
-            for (int j = 0; j < PC; ++j) old[j] = dx[(long)s * PN + 256 * j];
+            for (int u = 0; u < UB; ++u) {
+                const int s = min(s0b + u, n - 1);
 #pragma unroll
-            for (int j = 0; j < PC; ++j) dx[(long)s * PN + 256 * j] = old[j] + d[j] * w;
+                for (int j = 0; j < PC; ++j) old[u][j] = dx[(long)s * PN + 256 * j];
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int s = s0b + u;
+                if (s < n) {
+                    const float w = mine[s] * inv_cnt;
+#pragma unroll
+                    for (int j = 0; j < PC; ++j) dx[(long)s * PN + 256 * j] = old[u][j] + d[j] * w;
+                }
+            }
         }
     } else {
 #pragma unroll 4
