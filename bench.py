@@ -260,7 +260,12 @@ def main():
                     achieved=round(achieved, 1), peak=8000.0, unit="GB/s", frac=round(achieved / 8000.0, 4),
                     traffic=traffic, algorithmic_bytes_per_launch=alg_bytes, avg_launch_ms=round(upd_ms, 4),
                     step_model=dict(flops_per_pair=37.30e9, achieved_tflops=round(pairs_per_s * 37.30e9 / 1e12, 2),
-                                    mfma_peak_tflops=2500.0))
+                                    mfma_peak_tflops=2500.0,
+                                    # parameter-proportional HBM bytes of one step: weight reads fwd +
+                                    # dgrad (2+2 B), gradient write (4 B), optimizer (30 / 28 B), embedding-region norm pass
+                                    hbm_bytes_per_step=int((8 + bpp) * n_params + 1.0e8),
+                                    step_frac_of_hbm_peak=round(((8 + bpp) * n_params + 1.0e8) / 8.0e12 /
+                                                                (ms_per_step * 1e-3), 4)))
     exchange = None
     if model._reducer is not None:
         stp = [v for v in model._steps.values() if hasattr(v, "exchange_points")]
