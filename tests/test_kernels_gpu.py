@@ -331,6 +331,34 @@ def test_attention_fwd_bwd(dtype, B, Sq, Sk, causal):
     assert rel_err(dkv.float()[:, H * D:].reshape(B, Sk, -1), v.grad) < t
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_maximum_sequence_and_limit(dtype):
+    """Largest sequence the single-pass kernels hold in LDS (384 bf16 / 256 fp32) and the loud failure one past it."""
+    H, D = 12, 64
+    S = 384 if dtype == torch.bfloat16 else 256
+    dt = ops.dtype_code(dtype)
+    qkv = gen(S, 3 * H * D, seed=1).to(DEV, dtype)
+    out = torch.zeros(S, H * D, device=DEV, dtype=dtype); lse = torch.zeros(H * S, device=DEV)
+    a = (dt, 1, H, S, S, (qkv, 0), 3 * H * D, (qkv, H * D), 3 * H * D, (qkv, 2 * H * D), 3 * H * D)
+    ops.attention_fwd(*a, out, H * D, lse)
+    x = qkv.double().cpu()
+    q, k, v = (x[:, i * H * D:(i + 1) * H * D].reshape(1, S, H * D).requires_grad_(True) for i in range(3))
+    ref = O.attention_core(q, k, v, torch.zeros(1, 1, 1, S, dtype=torch.float64), H)
+    assert rel_err(out.float().view(1, S, -1), ref) < tol(dtype)
+    dout = gen(S, H * D, seed=2).to(DEV, dtype)
+    ref.backward(dout.double().cpu().view(1, S, -1))
+    dqkv = torch.zeros_like(qkv)
+    ops.attention_bwd(*a, out, H * D, lse, dout=dout, lddo=H * D, dq=(dqkv, 0), lddq=3 * H * D, dk=(dqkv, H * D), lddk=3 * H * D,
+                      dv=(dqkv, 2 * H * D), lddv=3 * H * D)
+    t = tol(dtype) * (2 if dtype == torch.bfloat16 else 1)
+    for i, g_ in enumerate((q.grad, k.grad, v.grad)):
+        assert rel_err(dqkv.float()[:, i * H * D:(i + 1) * H * D].reshape(1, S, -1), g_) < t
+    big = torch.zeros(S + 8, 3 * H * D, device=DEV, dtype=dtype)
+    with pytest.raises(RuntimeError):
+        ops.attention_fwd(dt, 1, H, S + 8, S + 8, (big, 0), 3 * H * D, (big, H * D), 3 * H * D, (big, 2 * H * D), 3 * H * D,
+                          torch.zeros(S + 8, H * D, device=DEV, dtype=dtype), H * D, torch.zeros(H * (S + 8), device=DEV))
+
+
 def test_attention_dropout_statistics():
     """p_drop = 0.1: E[out] matches the no-dropout output within sampling noise and fwd/bwd masks agree
     (checked through dV = P_drop^T dO with dO = 1, whose column sums equal sum of dropped probabilities)."""

@@ -78,7 +78,10 @@ class BucketReducer:
                 ev.record()
             self.pending.append((ev, None))
             return
-        w = dist.all_gather([out[r] for r in range(self.world)], t, group=self.pg, async_op=True)
+        if self._avg:          # RCCL: one contiguous output, no per-rank staging copies
+            w = dist.all_gather_into_tensor(out.view(-1, *t.shape[1:]), t, group=self.pg, async_op=True)
+        else:
+            w = dist.all_gather([out[r] for r in range(self.world)], t, group=self.pg, async_op=True)
         self.pending.append((w, None))
 
     def reduce_ranges(self, ranges):
