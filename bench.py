@@ -179,7 +179,7 @@ def main():
     for _ in range(3):
         float(step_body())
     torch.cuda.synchronize()
-    gstep, mode = None, "eager"
+    gstep, mode = None, ("per-plan graphs (UniVL._run_plan)" if model.auto_graph else "eager")
     if not args.no_graph:
         from univl_amd.graphed import GraphedTrainStep
         gstep = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=0, persistent_inputs=not args.host_inputs)

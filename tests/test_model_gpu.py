@@ -344,3 +344,31 @@ def test_graphed_and_data_parallel_schedules_match_eager(case):
             assert info["mode"] == "segmented"
             assert info["nseg"].count("eager") == len(info["points"]) + 2                  # exchanges + token gather + join
             assert info["nseg"].count("graph") >= len(info["points"])
+
+
+def test_unchanged_training_loop_switches_to_graph_replay():
+    """The eager loop of main_task_retrieval.py:333-352: after a few iterations the forward / backward plans are replayed
+    as hipGraphs (UniVL._run_plan) and keep producing what the plain enqueue produces."""
+    def run(auto):
+        cfg, rows, dseed = case_config("joint_small")
+        model, P = build(cfg, torch.float32)
+        model.auto_graph = auto
+        model.train()
+        opt = BertAdam(model.parameters(), lr=1e-5, warmup=-1, t_total=-1, weight_decay=0.01, max_grad_norm=1.0)
+        batch = O.synthetic_batch(cfg, rows, seed=dseed)
+        losses = []
+        for _ in range(6):
+            loss = call(model, batch)
+            loss.backward()
+            clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+            opt.zero_grad()
+            losses.append(float(loss))
+        st = next(iter(model._steps.values()))
+        return losses, st
+    l_graph, st = run(True)
+    l_eager, st_e = run(False)
+    assert st.fwd._segments is not None and st.backward_plan(True)._segments is not None
+    assert [s[0] for s in st.fwd._segments] == ["graph"]
+    assert st_e.fwd._segments is None
+    np.testing.assert_allclose(l_graph, l_eager, rtol=2e-4, atol=2e-5)

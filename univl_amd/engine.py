@@ -74,6 +74,8 @@ class FlatParams:
         m_elems = self.total - self.v_end
         self.partials = torch.zeros(m_elems // 1024 + 8 * len(self.order) + 64, device=self.device, dtype=torch.float32)
         self.fused = None            # dict(version=grad_version, names=frozenset) once a backward produced them
+        self._gviews = {}
+        self.name_of = {id(p): n for n, p in self.params.items()}
         FLAT_REGISTRY.add(self)
 
     def is_atomic(self, name):
@@ -85,8 +87,13 @@ class FlatParams:
         return self.p32[o:o + k].view(shp)
 
     def g(self, name):
-        o, k, shp = self.index[name]
-        return self.g32[o:o + k].view(shp)
+        """Gradient view of a parameter (one cached tensor object per name: `p.grad is flat.g(name)` identifies our own
+        gradient storage without touching data pointers)."""
+        v = self._gviews.get(name)
+        if v is None:
+            o, k, shp = self.index[name]
+            v = self._gviews[name] = self.g32[o:o + k].view(shp)
+        return v
 
     def wop(self, name):
         """compute-type view of a weight (bf16 shadow or the fp32 master itself)."""
@@ -122,9 +129,9 @@ class FlatParams:
     def attach_grads(self, used_names):
         """p.grad <- view of g32 for every parameter that receives a gradient in this configuration."""
         for n in used_names:
-            p = self.params[n]
-            if p.grad is None or p.grad.data_ptr() != self.g(n).data_ptr():
-                p.grad = self.g(n)
+            p, gv = self.params[n], self.g(n)
+            if p.grad is not gv:
+                p.grad = gv
 
 
 class GradState:

@@ -326,7 +326,7 @@ class _StepLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, model, step):
-        step.fwd.run()
+        model._run_plan(step.fwd, step)
         ctx.model, ctx.step, ctx.anchor = model, step, anchor
         return step.loss[0].clone()
 
@@ -371,6 +371,7 @@ class UniVL(UniVLPreTrainedModel):
             bert_config.intermediate_size == 3072, "kernels are specialised for H=768, 12 heads, I=3072"
 
         self.graph_backward = False
+        self.auto_graph = os.environ.get("UNIVL_AUTO_GRAPH", "1") != "0"
         self._stage_one, self._stage_two = True, False
         if _check_attr("stage_two", tc):
             self._stage_one, self._stage_two = False, tc.stage_two
@@ -471,6 +472,7 @@ class UniVL(UniVLPreTrainedModel):
     def _replicate_for_data_parallel(self):
         replica = super()._replicate_for_data_parallel()
         replica._flat, replica._steps, replica._reducer, replica._seed_dev = None, {}, None, None
+        replica._used_names = {}
         replica._dp_checked, replica._implicit_dp, replica.graph_backward = True, False, False
         return replica
 
@@ -526,7 +528,10 @@ class UniVL(UniVLPreTrainedModel):
         """Parameters that receive a gradient in this configuration (the reference leaves `.grad = None` on the rest:
         dead poolers modeling.py:307,310; the cross pooler / similarity_dense on the caption path)."""
         kind = kind or self.step_kind(True)
-        out = []
+        cached = self.__dict__.setdefault("_used_names", {}).get(kind)
+        if cached is not None:
+            return cached
+        out = self._used_names[kind] = []
         for n, _ in self.named_parameters():
             if n.startswith("bert.pooler") or n.startswith("visual.pooler"):
                 continue
@@ -547,6 +552,21 @@ class UniVL(UniVLPreTrainedModel):
             self._steps[key] = st
         return st
 
+    AUTO_GRAPH_AFTER = 2
+
+    def _run_plan(self, plan, st):
+        """Enqueue a forward / backward plan.  Launched kernel by kernel from Python the host is the bottleneck at small
+        batch (~10 us per launch against 2-10 us kernels), so once a step signature has been run AUTO_GRAPH_AFTER times
+        eagerly its plans are captured into hipGraphs (engine.Plan.run_graphed: one graph, or captured segments around
+        host-issued collectives) and replayed from then on -- the unchanged training loop of main_task_retrieval.py:333-352
+        then runs close to the fully captured step of graphed.GraphedTrainStep.  UNIVL_AUTO_GRAPH=0 turns it off; inside
+        somebody else's capture the plan is always enqueued directly."""
+        hot = self.auto_graph and st.calls > self.AUTO_GRAPH_AFTER
+        if (self.graph_backward or hot) and not torch.cuda.is_current_stream_capturing():
+            plan.run_graphed()
+        else:
+            plan.run()
+
     def _run_backward(self, st, gout):
         fl = self.flat
         used = self.used_parameter_names(st.kind)
@@ -556,11 +576,8 @@ class UniVL(UniVLPreTrainedModel):
         else:
             st.gout.copy_(gout.reshape(1).to(torch.float32))
         fl.grad_version += 1
+        self._run_plan(st.backward_plan(fresh), st)
         plan = st.backward_plan(fresh)
-        if self.graph_backward and not torch.cuda.is_current_stream_capturing():
-            plan.run_graphed()          # captured segments + host-issued gradient exchange (univl_amd.graphed)
-        else:
-            plan.run()
         fl.fused = dict(version=fl.grad_version, names=plan.fused_names) if plan.fused_names else None
         fl.attach_grads(used)
 
@@ -587,11 +604,12 @@ class UniVL(UniVLPreTrainedModel):
         if st.decoder is not None:
             st.decoder.load(input_caption_ids, decoder_mask, output_caption_ids)
         anchor = fl.params[self.ANCHOR]
+        st.calls += 1
         if torch.is_grad_enabled() and anchor.requires_grad:
             out = _StepLossFn.apply(anchor, self, st).as_subclass(_LossTensor)
             out._univl = (self, st)
             return out
-        st.fwd.run()
+        self._run_plan(st.fwd, st)
         return st.loss[0].clone()
 
     def get_sequence_visual_output(self, input_ids, token_type_ids, attention_mask, video, video_mask, shaped=False):

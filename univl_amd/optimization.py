@@ -100,19 +100,24 @@ def _measure(fl, cfg, tb):
 
 
 def _active_cfg(fl, params_with_cfg):
+    """{name: (lr, weight_decay, max_grad_norm, 1)} for the parameters that currently hold a gradient.  Runs once per clip
+    and once per step over ~300 parameters, so it sticks to identity checks (flat.name_of, cached gradient views)."""
     cfg = {}
-    ptr2name = {fl.params[n].data_ptr(): n for n in fl.order}
+    name_of, gviews = fl.name_of, fl.g
     for p, (lr, wd, mgn) in params_with_cfg:
-        n = ptr2name.get(p.data_ptr())
+        n = name_of.get(id(p))
         if n is None:
             raise RuntimeError("univl_amd.optimization: parameter not found in the model's flat buffer")
-        if p.grad is None:
+        gr = p.grad
+        if gr is None:
             continue
-        if p.grad.data_ptr() != fl.g(n).data_ptr():
-            fl.g(n).copy_(p.grad)          # a foreign gradient tensor: bring it into the flat buffer
-            p.grad = fl.g(n)
-            fl.fused = None                # ... whose norm nobody has measured
-        cfg[n] = (float(lr), float(wd), float(mgn), 1)
+        gv = gviews(n)
+        if gr is not gv:
+            if gr.data_ptr() != gv.data_ptr():
+                gv.copy_(gr)               # a foreign gradient tensor: bring it into the flat buffer
+                fl.fused = None            # ... whose norm nobody has measured
+            p.grad = gv
+        cfg[n] = (lr, wd, mgn, 1)
     return cfg
 
 

@@ -552,6 +552,7 @@ class Step:
         self.fwd = Plan()
         self.bwd = {}
         self.loss_terms = []
+        self.calls = 0               # training forwards through this step (UniVL._run_plan: eager first, graphs later)
 
     def finish_forward(self):
         terms = self.loss_terms
