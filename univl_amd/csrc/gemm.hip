@@ -416,7 +416,8 @@ int launch_group(const GroupArgs& g, hipStream_t stream) {
     constexpr int BK = NC * Mma<T>::CH;
     using TileA = Tile<T, TA, BM, BK>;
     using TileB = Tile<T, TB, BN, BK>;
-    const size_t smem = 2 * (TileA::BYTES + TileB::BYTES);
+    // NC == 6 is the one-K-step variant: only stage 0 of B is ever touched (A keeps the two-stage offset layout)
+    const size_t smem = NC == 6 ? 2 * TileA::BYTES + TileB::BYTES : 2 * (TileA::BYTES + TileB::BYTES);
     static bool attr_done = false;   // per instantiation
     if (!attr_done && smem > 48 * 1024) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_group_kernel<T, TA, TB, BM, BN, D, NC>),
@@ -434,7 +435,8 @@ int launch(const GemmArgs& a, int ksplit, hipStream_t stream) {
     constexpr int BK = NC * Mma<T>::CH;
     using TileA = Tile<T, TA, BM, BK>;
     using TileB = Tile<T, TB, BN, BK>;
-    const size_t smem = 2 * (TileA::BYTES + TileB::BYTES);
+    // NC == 6 is the one-K-step variant: only stage 0 of B is ever touched (A keeps the two-stage offset layout)
+    const size_t smem = NC == 6 ? 2 * TileA::BYTES + TileB::BYTES : 2 * (TileA::BYTES + TileB::BYTES);
     static bool attr_done = false;   // per instantiation
     if (!attr_done && smem > 48 * 1024) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, TA, TB, BM, BN, D, NC>),
@@ -505,6 +507,10 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, bool& big, int&
     big = d->tile == 128 || (d->tile == 0 && tiles128 >= big_min);
     nc = big ? 2 : 4;
     ksplit = d->ksplit < 1 ? 1 : d->ksplit;
+    // weight gradients at 4 pairs x 48 tokens contract over exactly 192 rows: one 192-deep stage = ONE DMA round trip
+    // per workgroup, no partial tile through registers (the 128-deep stage needs a 128-step plus a masked 64-tail)
+    static const int one_step = [] { const char* e = getenv("UNIVL_GEMM_ONESTEP"); return e ? atoi(e) : 1; }();
+    if (one_step && !big && d->dtype == UNIVL_BF16 && d->trans_a && d->trans_b && d->K == 192 && ksplit == 1) nc = 6;
     const int BK = (d->dtype == UNIVL_BF16 ? 32 : 16) * nc;
     int klen = ((d->K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
     ksplit = (d->K + klen - 1) / klen;
@@ -539,6 +545,7 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
     }
     if (d->dtype == UNIVL_BF16) {
         if (big) return dispatch_trans<__bf16, 128, 128, 2, 2>(a, d->trans_a, d->trans_b, ksplit, stream);
+        if (nc == 6) return launch<__bf16, true, true, 64, 64, 2, 6>(a, ksplit, stream);
         return dispatch_trans<__bf16, 64, 64, 2, 4>(a, d->trans_a, d->trans_b, ksplit, stream);
     }
     if (big) return dispatch_trans<float, 128, 128, 2, 2>(a, d->trans_a, d->trans_b, ksplit, stream);
@@ -559,7 +566,7 @@ extern "C" int univl_gemm_group(const UnivlGemm* d, int n, hipStream_t stream) {
         static const long big_min = [] { const char* e = getenv("UNIVL_GEMM_BIG_MIN"); return e ? atol(e) : 256L; }();
         big_all = big_all && (d[i].tile == 128 || (d[i].tile == 0 && tiles128 >= big_min));
     }
-    int total = 0;
+    int total = 0, nc_all = 0;
     const int bm = big_all ? 128 : 64;
     for (int i = 0; i < UNIVL_GEMM_GROUP_MAX; ++i) {
         g.first[i] = total;
@@ -570,6 +577,7 @@ extern "C" int univl_gemm_group(const UnivlGemm* d, int n, hipStream_t stream) {
         bool big;
         const int rc = prepare(&di, g.p[i], ksplit, big, nc);
         if (rc != UNIVL_OK) return rc;
+        nc_all = (i == 0) ? nc : (nc_all == nc ? nc : -1);
         g.nx[i] = (di.N + bm - 1) / bm;
         g.nxy[i] = g.nx[i] * ((di.M + bm - 1) / bm);
         g.nz[i] = ksplit;
@@ -584,8 +592,10 @@ extern "C" int univl_gemm_group(const UnivlGemm* d, int n, hipStream_t stream) {
         if (ta && tb) return launch_group<T, true, true, BMN, BMN, 2, NCV>(g, stream);                       \
         return launch_group<T, true, false, BMN, BMN, 2, NCV>(g, stream);                                    \
     } while (0)
+    UNIVL_CHECK_ARG(nc_all > 0, UNIVL_EINVAL, "univl_gemm_group: members disagree on the K-step depth (mixed contraction lengths)");
     if (d[0].dtype == UNIVL_BF16) {
         if (big_all) UNIVL_GROUP_CASE(__bf16, 128, 2);
+        if (nc_all == 6) return launch_group<__bf16, true, true, 64, 64, 2, 6>(g, stream);
         UNIVL_GROUP_CASE(__bf16, 64, 4);
     }
     if (big_all) UNIVL_GROUP_CASE(float, 128, 2);
