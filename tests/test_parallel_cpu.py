@@ -35,8 +35,16 @@ def _worker(rank, world, port, q):
     red.reduce_ranges(issued[-1])
     red.join()
     assert issued == [[(300, 900)], [(0, 300), (900, 1000)]]
+    # token exchange of the sparse word-embedding gradient: every rank receives every rank's (ids, rows)
+    ids_all = torch.zeros(world, 3, dtype=torch.int64)
+    rows_all = torch.zeros(world, 3, 4)
+    red.gather(torch.arange(3) + 10 * rank, ids_all)
+    red.gather(torch.full((3, 4), float(rank + 1)), rows_all)
+    red.join()
+    assert torch.equal(ids_all, torch.stack([torch.arange(3) + 10 * r for r in range(world)]))
+    assert torch.equal(rows_all, torch.stack([torch.full((3, 4), float(r + 1)) for r in range(world)]))
     expect = torch.arange(1000, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
-    ok = torch.allclose(g, expect) and red.bytes_reduced == 4000 and not red.pending
+    ok = torch.allclose(g, expect) and red.bytes_reduced == 4000 + ids_all.numel() * 8 + rows_all.numel() * 4 and not red.pending
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
