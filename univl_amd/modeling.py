@@ -346,6 +346,11 @@ class _LossTensor(torch.Tensor):
     then be captured into a hipGraph together with the forward).  Anything else (`(loss / k).backward()`,
     `loss.mean()`, explicit gradients) takes the normal autograd route and ends in _StepLossFn.backward."""
 
+    def __float__(self):
+        # `total_loss += float(loss)` (main_task_retrieval.py:344) on a tensor that requires grad: read the detached value
+        # (same number, without torch's "converting a tensor with requires_grad=True to a scalar" warning every step)
+        return torch.Tensor.__float__(self.detach())
+
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
         ms = self.__dict__.get("_univl", None)
         if ms is not None and gradient is None and inputs is None and not create_graph and not ms[0]._implicit_dp:
