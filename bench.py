@@ -142,6 +142,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_base = cpu_baseline(args.batch)
 
+    from univl_amd import _lib as _ulib
+    if world == 1 and not os.path.exists(_ulib.LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc"):
+        from univl_amd import build as _ubuild          # harness convenience only; the product path never builds
+        _ubuild.build(verbose=False)
     from univl_amd import UniVL, BertAdam, clip_grad_norm_
     torch.manual_seed(0)
     tc = task_config(args, world)
