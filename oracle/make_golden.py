@@ -186,11 +186,84 @@ def dump_param_inventory():
     print("[golden] param_inventory.json written")
 
 
+# ------------------------------------------------------------------------------------------ beam search golden
+def _reference_decode_functions():
+    """The caption decoding helpers live in main_task_caption.py, which cannot be imported (it initialises NCCL at import
+    time).  Their definitions are taken out of the script's syntax tree and executed here, in this container only: the
+    reference's own code produces the golden hypotheses; nothing of it is stored in the repository."""
+    import ast
+    src = open(os.path.join(H.REFERENCE_ROOT, "main_task_caption.py")).read()
+    want = {"get_inst_idx_to_tensor_position_map", "collect_active_part", "collate_active_info", "beam_decode_step",
+            "collect_hypothesis_and_scores"}
+    tree = ast.parse(src)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert {n.name for n in body} == want
+    H._install_stubs()
+    from modules.beam import Beam
+    ns = {"torch": torch, "Beam": Beam}
+    exec(compile(ast.Module(body=body, type_ignores=[]), "main_task_caption.py[decode helpers]", "exec"), ns)
+    return ns, Beam
+
+
+def generate_beam(name="caption_small", n_inst=3, n_bm=5, max_len=5, bos=101):
+    """Runs the reference's caption decoding loop (main_task_caption.py:498-522) with the reference model on procedural
+    weights and stores hypotheses / scores for two EOS settings: unreachable, and the token instance 0's top beam emits at
+    its second step (so one instance stops early)."""
+    cfg, rows, dseed = case_config(name)
+    model = H.build_reference_model(_task_ns(cfg), vocab_size=cfg.vocab_size, zero_dropout=True)
+    load_procedural_into_reference(model, cfg, seed=0)
+    model.eval()
+    ns, Beam = _reference_decode_functions()
+    batch = O.synthetic_batch(cfg, n_inst, seed=dseed + 5)
+
+    class _Tok:                       # Constants.from_tokenizer reads tokenizer.vocab[...]
+        def __init__(self, eos):
+            self.vocab = {"[PAD]": 0, "[UNK]": 100, "[CLS]": bos, "[SEP]": eos}
+
+    def decode(eos, steps):
+        dev = torch.device("cpu")
+        with torch.no_grad():
+            seq, vis = model.get_sequence_visual_output(batch["input_ids"], batch["token_type_ids"], batch["attention_mask"],
+                                                        batch["video"], batch["video_mask"])
+            n, len_s, d_h = seq.size()
+            _, len_v, v_h = vis.size()
+            input_ids = batch["input_ids"].view(-1, batch["input_ids"].shape[-1])
+            input_mask = batch["attention_mask"].view(-1, batch["attention_mask"].shape[-1])
+            video_mask = batch["video_mask"].view(-1, batch["video_mask"].shape[-1])
+            tup = (seq.repeat(1, n_bm, 1).view(n * n_bm, len_s, d_h), vis.repeat(1, n_bm, 1).view(n * n_bm, len_v, v_h),
+                   input_ids.repeat(1, n_bm).view(n * n_bm, len_s), input_mask.repeat(1, n_bm).view(n * n_bm, len_s),
+                   video_mask.repeat(1, n_bm).view(n * n_bm, len_v))
+            beams = [Beam(n_bm, device=dev, tokenizer=_Tok(eos)) for _ in range(n)]
+            active = list(range(n))
+            pos = ns["get_inst_idx_to_tensor_position_map"](active)
+            for len_dec_seq in range(1, steps + 1):
+                active = ns["beam_decode_step"](model.decoder_caption, beams, len_dec_seq, pos, n_bm, dev, tup)
+                if not active:
+                    break
+                tup, pos = ns["collate_active_info"](tup, pos, active, n_bm, dev)
+            hyp, scores = ns["collect_hypothesis_and_scores"](beams, 1)
+        return [h[0] for h in hyp], [float(s[0]) for s in scores]
+
+    out = {}
+    hyp, sc = decode(-1, max_len)
+    short, _ = decode(-1, 2)
+    eos = short[0][1]
+    hyp2, sc2 = decode(eos, max_len)
+    pad = lambda hs: np.array([h + [-1] * (max_len - len(h)) for h in hs], dtype=np.int64)
+    out.update(n_inst=n_inst, n_bm=n_bm, max_len=max_len, bos=bos, eos2=eos, hyp=pad(hyp), scores=np.array(sc),
+               hyp2=pad(hyp2), scores2=np.array(sc2), data_seed=dseed + 5)
+    np.savez(os.path.join(GOLDEN_DIR, "beam_" + name + ".npz"), **out)
+    print("[golden] beam_%s.npz: hyp %s | eos=%d -> lengths %s" % (name, hyp, eos, [len(h) for h in hyp2]))
+
+
 if __name__ == "__main__":
     assert H.reference_available(), "reference not mounted; golden vectors can only be made in the build container"
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or list(CASES)
+    which = sys.argv[1:] or list(CASES) + ["beam"]
     for nm in which:
-        generate(nm)
+        if nm == "beam":
+            generate_beam()
+        else:
+            generate(nm)
     if not sys.argv[1:]:
         dump_param_inventory()

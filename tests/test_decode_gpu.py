@@ -76,3 +76,27 @@ def test_beam_search_matches_reference_procedure():
     assert hyp2 == ref2
     assert len(hyp2[0]) == 2 and hyp2[0][-1] == eos and any(len(h) == T for h in hyp2)
     assert max(abs(float(a) - b_) for a, b_ in zip(sc2, ref_sc2)) < 1e-3
+
+
+def test_beam_search_matches_reference_golden(golden_dir):
+    """The cached GPU decoder reproduces the hypotheses the reference's own decode loop produced (tests/golden/
+    beam_caption_small.npz, see oracle/make_golden.py::generate_beam)."""
+    import os
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "beam_caption_small.npz"))
+    cfg, rows, dseed = case_config("caption_small")
+    n, nb, T, bos = int(g["n_inst"]), int(g["n_bm"]), int(g["max_len"]), int(g["bos"])
+    model, P = build(cfg, torch.float32)
+    model.eval()
+    d = {k: v.to(DEV) for k, v in O.synthetic_batch(cfg, n, seed=int(g["data_seed"])).items()}
+    with torch.no_grad():
+        so, vo = model.get_sequence_visual_output(d["input_ids"], d["token_type_ids"], d["attention_mask"], d["video"], d["video_mask"])
+    bs = CaptionBeamSearch(model, n, cfg.max_words, cfg.max_frames, n_bm=nb, max_len=T)
+    am, vm = d["attention_mask"].view(n, -1), d["video_mask"].view(n, -1)
+    unpad = lambda a: [[int(t) for t in row if t >= 0] for row in a]
+    hyp, sc = bs(so, vo, am, vm, bos=bos, eos=-1)
+    assert hyp == unpad(g["hyp"])
+    assert float((sc.cpu() - torch.as_tensor(g["scores"], dtype=torch.float32)).abs().max()) < 1e-3
+    hyp2, sc2 = bs(so, vo, am, vm, bos=bos, eos=int(g["eos2"]))
+    assert hyp2 == unpad(g["hyp2"])
+    assert float((sc2.cpu() - torch.as_tensor(g["scores2"], dtype=torch.float32)).abs().max()) < 1e-3

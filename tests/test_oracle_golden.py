@@ -100,3 +100,28 @@ def test_param_inventory_matches_reference(golden_dir):
         assert [[n, list(s)] for n, s in shapes.items()] == rec["named_parameters"], name
         keys = set(shapes) | set(O.tied_aliases(cfg))
         assert keys == set(rec["state_dict_keys"]), name
+
+
+def _golden_hyps(a):
+    return [[int(t) for t in row if t >= 0] for row in a]
+
+
+def test_oracle_beam_search_matches_reference_decode_loop(golden_dir):
+    """oracle.beam_search_caption against hypotheses produced by the reference's OWN decode code (main_task_caption.py's
+    beam_decode_step / collate_active_info / collect_hypothesis_and_scores and modules/beam.py, executed by
+    oracle/make_golden.py::generate_beam on the reference model)."""
+    g = _load(golden_dir, "beam_caption_small")
+    cfg, rows, dseed = case_config("caption_small")
+    n, nb, T, bos = int(g["n_inst"]), int(g["n_bm"]), int(g["max_len"]), int(g["bos"])
+    P = O.procedural_params(cfg, 0)
+    b = O.synthetic_batch(cfg, n, seed=int(g["data_seed"]))
+    with torch.no_grad():
+        so, vo = O.get_sequence_visual_output(P, cfg, b["input_ids"], b["token_type_ids"], b["attention_mask"], b["video"],
+                                              b["video_mask"], training=False)
+        am, vm = b["attention_mask"].view(n, -1), b["video_mask"].view(n, -1)
+        hyp, sc = O.beam_search_caption(P, cfg, so, vo, am, vm, nb, T, bos, -1)
+        hyp2, sc2 = O.beam_search_caption(P, cfg, so, vo, am, vm, nb, T, bos, int(g["eos2"]))
+    assert hyp == _golden_hyps(g["hyp"]) and hyp2 == _golden_hyps(g["hyp2"])
+    assert [len(h) for h in hyp2][0] == 2 and max(len(h) for h in hyp2) == T          # instance 0 stopped at its EOS
+    np.testing.assert_allclose(sc, g["scores"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(sc2, g["scores2"], rtol=0, atol=2e-4)
