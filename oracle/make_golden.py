@@ -256,13 +256,34 @@ def generate_beam(name="caption_small", n_inst=3, n_bm=5, max_len=5, bos=101):
     print("[golden] beam_%s.npz: hyp %s | eos=%d -> lengths %s" % (name, hyp, eos, [len(h) for h in hyp2]))
 
 
+def generate_metrics():
+    """metrics.compute_metrics of the reference (metrics.py:8-20) on seeded similarity matrices incl. ties with the diagonal."""
+    H._install_stubs()
+    import importlib
+    ref_metrics = importlib.import_module("metrics")          # /root/reference/metrics.py
+    out = {}
+    for n in (7, 60, 333):
+        g = torch.Generator().manual_seed(n)
+        x = torch.randn(n, n, generator=g)
+        x[3, 5] = x[3, 3]
+        x[2, :] = 0.25
+        x[1, 1] = x[1].max() + 1
+        m = ref_metrics.compute_metrics(x.numpy())
+        out["x%d" % n] = x.numpy()
+        out["m%d" % n] = np.array([m["R1"], m["R5"], m["R10"], m["MR"]], dtype=np.float64)
+    np.savez(os.path.join(GOLDEN_DIR, "metrics.npz"), **out)
+    print("[golden] metrics.npz written")
+
+
 if __name__ == "__main__":
     assert H.reference_available(), "reference not mounted; golden vectors can only be made in the build container"
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or list(CASES) + ["beam"]
+    which = sys.argv[1:] or list(CASES) + ["beam", "metrics"]
     for nm in which:
         if nm == "beam":
             generate_beam()
+        elif nm == "metrics":
+            generate_metrics()
         else:
             generate(nm)
     if not sys.argv[1:]:

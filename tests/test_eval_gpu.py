@@ -95,3 +95,12 @@ def test_eval_retrieval_and_replicas(case):
     assert not errors, errors
     par = np.concatenate([results[0], results[1]], axis=0)
     assert float(np.abs(par - sim.cpu().numpy()).max()) < 1e-5
+
+
+def test_compute_metrics_matches_reference_golden(golden_dir):
+    """GPU rank counts vs values produced by the reference's own metrics.compute_metrics (tests/golden/metrics.npz)."""
+    import os
+    g = np.load(os.path.join(golden_dir, "metrics.npz"))
+    for n in (7, 60, 333):
+        m = M.compute_metrics(torch.as_tensor(g["x%d" % n]).to(DEV))
+        assert [m["R1"], m["R5"], m["R10"], float(m["MR"])] == list(g["m%d" % n])

@@ -125,3 +125,11 @@ def test_oracle_beam_search_matches_reference_decode_loop(golden_dir):
     assert [len(h) for h in hyp2][0] == 2 and max(len(h) for h in hyp2) == T          # instance 0 stopped at its EOS
     np.testing.assert_allclose(sc, g["scores"], rtol=0, atol=2e-4)
     np.testing.assert_allclose(sc2, g["scores2"], rtol=0, atol=2e-4)
+
+
+def test_oracle_metrics_match_reference(golden_dir):
+    """oracle.compute_metrics against values computed by the reference's metrics.compute_metrics (ties included)."""
+    g = _load(golden_dir, "metrics")
+    for n in (7, 60, 333):
+        m = O.compute_metrics(g["x%d" % n])
+        assert [m["R1"], m["R5"], m["R10"], float(m["MR"])] == list(g["m%d" % n])
