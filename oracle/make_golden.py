@@ -44,7 +44,19 @@ CASES = {
                             cross_num_hidden_layers=1, decoder_num_hidden_layers=1, stage_two=True,
                             do_pretrain=True, use_mil=True, task_type="retrieval",
                             max_words=16, max_frames=16), 2, 41),
+    # ---- BASELINE.json configurations at full depth (12 + 6 (+ 2 cross, + 3 decoder) layers)
+    # cfg3 (MSRVTT retrieval, global bs 128): 16 rows per GPU on 8 GPUs, 128 rows on one GPU
+    "joint_b16": (dict(batch_size=16), 16, 1316),
+    "joint_b128": (dict(batch_size=128), 128, 13128),
+    # FT-Align (--train_sim_after_cross) at 48x48: 16 (text, video) pairs x 96 tokens through the 2-layer cross encoder
+    "align_full": (dict(batch_size=4, train_sim_after_cross=True), 4, 2104),
+    # cfg4: caption finetune stage two, 128 x 96, 3 decoder layers, 4 rows per GPU
+    "caption_full": (dict(batch_size=4, stage_two=True, task_type="caption", max_words=128, max_frames=96), 4, 3104),
+    # cfg5: pretrain stage two, 2 videos x n_pair 3 = 6 rows, 48 x 64, five losses
+    "pretrain_full": (dict(batch_size=2, n_pair=3, stage_two=True, do_pretrain=True, use_mil=True,
+                           task_type="retrieval", max_words=48, max_frames=64), 2, 4106),
 }
+FULL_CASES = ["joint_b16", "joint_b128", "align_full", "caption_full", "pretrain_full"]
 
 
 def case_config(name):
@@ -94,6 +106,21 @@ def sample(t, n=4096):
     return f[idx].to(torch.float32).numpy().copy()
 
 
+def sample_exact(t, n):
+    """Strided subsample with exact integer indices (float32 linspace of `sample` rounds beyond 2^24 elements)."""
+    f = t.detach().reshape(-1)
+    if f.numel() <= n:
+        return f.to(torch.float32).numpy().copy()
+    idx = (torch.arange(n, dtype=torch.int64) * (f.numel() - 1)) // (n - 1)
+    return f[idx].to(torch.float32).numpy().copy()
+
+
+def _pad(a, n):
+    o = np.zeros(n, dtype=np.float32)
+    o[:a.size] = a
+    return o
+
+
 def generate(name):
     cfg, rows, dseed = case_config(name)
     model = H.build_reference_model(_task_ns(cfg), vocab_size=cfg.vocab_size, zero_dropout=True)
@@ -134,6 +161,12 @@ def generate(name):
         k = min(8, p.grad.numel())
         h[:k] = p.grad.reshape(-1)[:k]
         heads.append(h.numpy())
+    # strided samples of the gradients themselves: 256 elements of EVERY tensor, 4096 of the ten with the largest norm
+    gdict = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    out["grad_samples"] = np.stack([_pad(sample_exact(gdict[n], 256), 256) for n in names]).astype(np.float32)
+    top = sorted(range(len(names)), key=lambda i: -norms[i])[:10]
+    out["grad_top_index"] = np.array(top, dtype=np.int64)
+    out["grad_top_samples"] = np.stack([_pad(sample_exact(gdict[names[i]], 4096), 4096) for i in top]).astype(np.float32)
     out["grad_names"] = np.array(names)
     out["grad_norms"] = np.array(norms, dtype=np.float64)
     out["grad_sums"] = np.array(sums, dtype=np.float64)

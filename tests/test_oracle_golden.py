@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import univl_oracle as O
-from make_golden import CASES, case_config
+from make_golden import CASES, case_config, sample_exact
 
 ALL = list(CASES)
 
@@ -64,6 +64,15 @@ def test_oracle_matches_reference_golden(golden_dir, name):
         k = min(8, gr.numel())
         np.testing.assert_allclose(gr.reshape(-1)[:k].numpy(), g["grad_heads"][i][:k], rtol=2e-3, atol=2e-7,
                                    err_msg=n)
+        # strided sample of the gradient itself (256 elements of every tensor): relative error of the sample
+        rs = g["grad_samples"][i]
+        got = sample_exact(gr, 256)
+        d = float(np.linalg.norm(got - rs[:got.size]))
+        assert d <= 5e-4 * float(np.linalg.norm(rs)) + 1e-6 * ref + 1e-9, (n, d, float(np.linalg.norm(rs)))
+    for j, i in enumerate(g["grad_top_index"]):
+        rs = g["grad_top_samples"][j]
+        got = sample_exact(P[names[int(i)]].grad, 4096)
+        assert float(np.linalg.norm(got - rs[:got.size])) <= 5e-4 * float(np.linalg.norm(rs)), names[int(i)]
 
 
 @pytest.mark.parametrize("name", ["joint_small", "caption_small"])
