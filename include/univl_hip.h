@@ -8,9 +8,11 @@
  * Contract (SURVEY.md section 8b "C-ABI"):
  *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (PyTorch's caching
  *     allocator on the Python side).  The library never allocates, frees or synchronises on the hot path.
- *   - every call only ENQUEUES work on `stream` (a hipStream_t) of the CURRENT device and returns
- *     0 on success, <0 for an argument error (UNIVL_E*), >0 for a hipError_t; univl_last_error() describes it.
- *   - re-entrant; no global mutable state besides the thread-local error string.
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t) and returns 0 on success, <0 for an argument error (UNIVL_E*), >0 for a hipError_t; univl_last_error() describes it.
+ *   - the DEVICE is the one `stream` belongs to (hipStreamGetDevice), not the calling thread's current device: the
+ *     reference's evaluation fan-out calls the model from one thread per GPU (util.py:21-60) and autograd's backward
+ *     threads carry their own current device.  The null stream means the current device.
+ *   - re-entrant; no global mutable state besides the thread-local error string and per-device "large LDS enabled" flags.
  *   - dtype: UNIVL_F32 (parity mode, exact-fp32 MFMA) or UNIVL_BF16 (production: bf16 operands, fp32
  *     accumulate, fp32 LayerNorm/softmax/residual stream).
  *   - RNG for dropout is (seed, offset) supplied by the caller; offsets distinguish call sites.  The effective
@@ -39,6 +41,19 @@ int univl_version(void);
 int univl_struct_size(int which);
 /* number of CUs / name of the current device, for host-side launch heuristics; returns 0 or hipError_t */
 int univl_device_info(int* cu_count, char* name, int name_len);
+/* univl_init(device): optional, idempotent.  Checks that `device` exists and is a gfx950 part (the only code object in the
+ * library), returns 0 / UNIVL_EUNSUPPORTED / hipError_t.  Nothing needs to be initialised before the first call into the
+ * library; a host that wants the failure at start-up instead of at the first launch calls this once per GPU
+ * (where the reference calls torch.cuda.set_device, main_task_retrieval.py:121).  univl_destroy() releases what the
+ * library opened lazily (the RCCL handle of univl_allreduce_bucket); device memory is never owned by the library. */
+int univl_init(int device);
+int univl_destroy(void);
+/* Data-parallel gradient exchange for hosts that own an RCCL communicator themselves (the Python host goes through
+ * torch.distributed's "nccl" backend = RCCL, main_task_retrieval.py:23,197-198, instead): in-place all-reduce of
+ * buf[0..n) (dtype UNIVL_DT_F32 / UNIVL_DT_BF16) over `comm` (an ncclComm_t) on the side stream `side`,
+ * op = average if `average` else sum.  Only enqueues.  RCCL is resolved at first use (the copy already loaded into
+ * the process, else librccl.so); UNIVL_EUNSUPPORTED if it cannot be found, >0 = ncclResult_t + 1000. */
+int univl_allreduce_bucket(void* buf, size_t n, int dtype, int average, void* comm, hipStream_t side);
 
 /* ------------------------------------------------------------------------------------------------ GEMM
  * C[M,N] = epi( alpha * A_op[M,K] . B_op[N,K]^T ).   trans_x = 0: operand stored [rows][K] (row-major, ld);
@@ -282,6 +297,7 @@ typedef struct UnivlAdam {
     float b1, b2, eps;
     float warmup; int32_t t_total;   /* warmup_linear schedule (optimization.py:38-43), t_total -1: constant */
     float* seg_scalars;          /* scratch [nseg*2]                                                       */
+    int32_t schedule;            /* 0 warmup_linear, 1 warmup_cosine, 2 warmup_constant (optimization.py:26-50) */
 } UnivlAdam;
 int univl_bert_adam(const UnivlAdam* d, hipStream_t stream);
 /* *ctr += 1 (device word; used for per-replay dropout seeds) */

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import univl_oracle as O
-from make_golden import case_config
+from make_golden import case_config, sample_exact, FULL_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -22,7 +22,26 @@ if torch.cuda.is_available():
 
 DEV = "cuda"
 JOINT_CASES = ["joint_small", "joint_ones", "joint_full"]
-ALL_CASES = JOINT_CASES + ["align_small", "caption_small", "pretrain_small"]
+ALL_CASES = JOINT_CASES + ["align_small", "caption_small", "pretrain_small"] + FULL_CASES   # FULL: BASELINE cfg3/FT-Align/cfg4/cfg5
+
+# bf16 gates.  north_star: 1e-2 on outputs (similarity logits, decoder logits, loss) and on the relative gradient error;
+# hidden states carry bf16 operand noise that torch's own bf16 autocast of the REFERENCE shows too (measured the same way
+# by oracle/bf16_noise.py -> tests/golden/bf16_autocast_noise.json, quoted in DESIGN.md section 2).  Every measured error
+# is written to gpurun_out/parity_errors.json (copied to profiles/ per round).
+GATES = {
+    torch.float32: dict(hidden=1e-3, sim=1e-3, logits=1e-3, loss=1e-3, gnorm=1e-3, gsample=2e-3, gtop=2e-3),
+    torch.bfloat16: dict(hidden=5e-2, sim=1e-2, logits=1e-2, loss=1e-2, gnorm=1e-2, gsample=3e-2, gtop=2e-2),
+}
+_ERRORS = {}
+
+
+def _record(name, dtype, **kw):
+    import json
+    _ERRORS.setdefault(name, {})[str(dtype).replace("torch.", "")] = {k: float(v) for k, v in kw.items()}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_errors.json"), "w") as f:
+        json.dump(_ERRORS, f, indent=1, sort_keys=True)
 
 
 def task_ns(cfg, dtype):
@@ -79,6 +98,8 @@ def test_forward_backward_vs_reference_golden(golden_dir, name, dtype):
     model, P = build(cfg, dtype)
     batch = O.synthetic_batch(cfg, rows, seed=dseed)
     f32 = dtype == torch.float32
+    G = GATES[dtype]
+    err = {}
     # ---- eval surface: get_sequence_visual_output + get_similarity_logits (main_task_retrieval.py:398, 376)
     model.eval()
     with torch.no_grad():
@@ -91,26 +112,30 @@ def test_forward_backward_vs_reference_golden(golden_dir, name, dtype):
             logits = model.decoder_caption(seq, vis, b["input_ids"], b["attention_mask"], b["video_mask"],
                                            b["input_caption_ids"], b["decoder_mask"], shaped=False, get_logits=True)
             assert tuple(logits.shape[-1:]) == (cfg.vocab_size,)
-            assert float(np.abs(_sample(logits) - g["decoder_logits_sample"]).max()) < (1e-3 if f32 else 3e-2)
-    hid_tol = 1e-3 if f32 else 5e-2
-    assert max_abs(seq, g["sequence_output"]) < hid_tol
-    assert max_abs(vis, g["visual_output"]) < hid_tol
-    assert max_abs(sim, g["sim_matrix"]) < (1e-3 if f32 else 2e-2)
+            ref_l = g["decoder_logits_sample"]
+            err["logits"] = float(np.abs(_sample(logits) - ref_l).max()) / max(1.0, float(np.abs(ref_l).max()))
+    if "sequence_output" in g.files:
+        err["hidden"] = max(max_abs(seq, g["sequence_output"]), max_abs(vis, g["visual_output"]))
+    else:                                     # large cases store the strided 4096-sample only
+        err["hidden"] = max(float(np.abs(_sample(seq) - g["sequence_output_sample"]).max()),
+                            float(np.abs(_sample(vis) - g["visual_output_sample"]).max()))
+    err["sim"] = max_abs(sim, g["sim_matrix"]) / max(1.0, float(np.abs(g["sim_matrix"]).max()))
     # ---- training step: loss + every parameter gradient (main_task_retrieval.py:333-342)
     model.train()
     loss = call(model, batch)
     loss.backward()
-    assert abs(float(loss) - float(g["loss"])) < (1e-3 if f32 else 1e-2) * max(1.0, abs(float(g["loss"])))
+    err["loss"] = abs(float(loss) - float(g["loss"])) / max(1.0, abs(float(g["loss"])))
     names = [str(s) for s in g["grad_names"]]
     nograd = [str(s) for s in g["nograd_names"]]
     params = dict(model.named_parameters())
     for n in nograd:
         assert params[n].grad is None, n                      # dead poolers stay grad-less, as in the reference
-    worst = 0.0
     # absolute floor: bf16 operand rounding leaves noise proportional to the LARGEST gradients flowing through the
     # same kernels (a bias whose true gradient is ~0, e.g. key.bias, only sees that noise); fp32 mode: rounding only
     gmax = float(np.max(g["grad_norms"]))
     floor = (1e-6 if f32 else 2e-3) * max(gmax, 1.0 if f32 else gmax)
+    worst_norm = worst_s = 0.0
+    bad = []
     for i, n in enumerate(names):
         gr = params[n].grad
         assert gr is not None, n
@@ -118,15 +143,32 @@ def test_forward_backward_vs_reference_golden(golden_dir, name, dtype):
         got = float(gr.double().norm())
         # key.bias gradients are mathematically zero (softmax is invariant to a per-query shift): the reference
         # itself only holds rounding noise (~1e-10) there, hence the absolute floor.
-        rel = abs(got - ref) / (ref + 1e-12)
-        if ref > 1e-6:
-            worst = max(worst, rel)
-        assert abs(got - ref) < (1e-3 if f32 else 3e-2) * ref + floor, (n, got, ref)
-        k = min(8, gr.numel())
-        head_err = max_abs(gr.reshape(-1)[:k], g["grad_heads"][i][:k])
-        scale = max(float(np.abs(g["grad_heads"][i][:k]).max()), ref / (gr.numel() ** 0.5))
-        assert head_err < (2e-3 if f32 else 0.3) * scale + floor, (n, head_err, scale)
-    print(f"[{name} {dtype}] loss {float(loss):.6f} (ref {float(g['loss']):.6f}); worst grad-norm rel err {worst:.2e}")
+        significant = ref > 1e-3 * gmax
+        if significant:
+            worst_norm = max(worst_norm, abs(got - ref) / ref)
+        if not abs(got - ref) < G["gnorm"] * ref + floor:
+            bad.append((n, "norm", got, ref))
+        # 256-element strided sample of the gradient itself: relative error of the sample vector
+        rs = g["grad_samples"][i]
+        gs = sample_exact(gr.float().cpu(), 256)
+        d = float(np.linalg.norm(gs - rs[:gs.size]))
+        rn = float(np.linalg.norm(rs))
+        if significant and rn > 0:
+            worst_s = max(worst_s, d / rn)
+        if not d < G["gsample"] * rn + floor * (min(256, gr.numel()) / gr.numel()) ** 0.5 + 1e-9:
+            bad.append((n, "sample", d, rn))
+    worst_top = 0.0
+    for j, i in enumerate(g["grad_top_index"]):      # the ten largest gradients: 4096-element samples
+        rs = g["grad_top_samples"][j]
+        gs = sample_exact(params[names[int(i)]].grad.float().cpu(), 4096)
+        rel = float(np.linalg.norm(gs - rs[:gs.size])) / float(np.linalg.norm(rs))
+        worst_top = max(worst_top, rel)
+    err.update(gnorm=worst_norm, gsample=worst_s, gtop=worst_top)
+    _record(name, dtype, **err)
+    print(f"[parity {name} {dtype}] " + " ".join(f"{k}={v:.2e}" for k, v in sorted(err.items())))
+    assert not bad, bad[:5]
+    for k, v in err.items():
+        assert v < G[k], (name, k, v, G[k])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

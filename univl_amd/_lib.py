@@ -58,7 +58,7 @@ class Adam(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("p16", vp), ("segs", vp), ("nseg", i32),
                 ("chunk_seg", vp), ("chunk_off", vp), ("chunk_len", vp), ("nchunk", i32), ("sumsq", vp),
                 ("coef", vp), ("step", vp), ("b1", f32), ("b2", f32), ("eps", f32), ("warmup", f32),
-                ("t_total", i32), ("seg_scalars", vp)]
+                ("t_total", i32), ("seg_scalars", vp), ("schedule", i32)]
 
 
 _STRUCTS = [Gemm, LayerNorm, Attention, EmbedText, Pool, Seg, Adam]
@@ -120,11 +120,14 @@ def lib():
     L.univl_bump_counter.argtypes = [vp, vp]
     L.univl_probe_layouts.argtypes = [vp, i32, vp]
     L.univl_device_info.argtypes = [C.POINTER(i32), C.c_char_p, i32]
+    L.univl_init.argtypes = [i32]
+    L.univl_allreduce_bucket.argtypes = [vp, C.c_size_t, i32, i32, vp, vp]
     _lib = L
     return L
 
 
-EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_device_info", "univl_gemm", "univl_gemm_group",
+EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_device_info", "univl_init", "univl_destroy",
+            "univl_allreduce_bucket", "univl_gemm", "univl_gemm_group",
             "univl_layernorm_fwd", "univl_layernorm_bwd", "univl_attention_fwd", "univl_attention_bwd",
             "univl_embed_text_fwd", "univl_embed_text_bwd", "univl_embed_scatter", "univl_pool_fwd", "univl_pool_bwd",
             "univl_maxmargin_loss", "univl_crossen_loss", "univl_milnce_loss", "univl_rank_counts", "univl_gather_rows", "univl_log_softmax_rows", "univl_scale_by_device_scalar", "univl_pair_concat_fwd", "univl_pair_concat_bwd", "univl_postype_fwd", "univl_postype_bwd", "univl_tanh_fwd",

@@ -432,12 +432,8 @@ int check(const UnivlAttention* d, const char* who, bool bwd) {
 template <typename T, int MAXKT>
 int launch_fwd(const UnivlAttention* d, int Sk_pad, hipStream_t stream) {
     const size_t smem = (size_t)2 * Sk_pad * AttnCfg<T>::P * sizeof(T) + Sk_pad * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, MAXKT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    static bool attr_done[UNIVL_MAX_DEVICES] = {};
+    univl_allow_lds(attn_fwd_kernel<T, MAXKT>, 160 * 1024, attr_done);
     dim3 grid(d->B * d->H, (d->Sq + 63) / 64);
     hipLaunchKernelGGL((attn_fwd_kernel<T, MAXKT>), grid, dim3(256), smem, stream, *d, Sk_pad, 0.125f);
     UNIVL_LAUNCH_CHECK();
@@ -468,18 +464,12 @@ int dispatch_bwd(const UnivlAttention* d, hipStream_t stream) {
     constexpr int TR = (PIECES64 + 511) / 512;
     dim3 grid(d->B * d->H, nqb + nkb);
     if (small) {
-        static bool attr_small = false;
-        if (!attr_small) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<T, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_small = true;
-        }
+        static bool attr_small[UNIVL_MAX_DEVICES] = {};
+        univl_allow_lds(attn_bwd_kernel<T, TR>, 160 * 1024, attr_small);
         hipLaunchKernelGGL((attn_bwd_kernel<T, TR>), grid, dim3(256), smem, stream, *d, Sk_pad, Sq_pad, nqb, 0.125f);
     } else {
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_done = true;
-        }
+        static bool attr_done[UNIVL_MAX_DEVICES] = {};
+        univl_allow_lds(attn_bwd_kernel<T, 0>, 160 * 1024, attr_done);
         hipLaunchKernelGGL((attn_bwd_kernel<T, 0>), grid, dim3(256), smem, stream, *d, Sk_pad, Sq_pad, nqb, 0.125f);
     }
     UNIVL_LAUNCH_CHECK();
@@ -489,12 +479,14 @@ int dispatch_bwd(const UnivlAttention* d, hipStream_t stream) {
 }  // namespace
 
 extern "C" int univl_attention_fwd(const UnivlAttention* d, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     int rc = check(d, "univl_attention_fwd", false);
     if (rc) return rc;
     return d->dtype == UNIVL_DT_BF16 ? dispatch_fwd<__bf16>(d, stream) : dispatch_fwd<float>(d, stream);
 }
 
 extern "C" int univl_attention_bwd(const UnivlAttention* d, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     int rc = check(d, "univl_attention_bwd", true);
     if (rc) return rc;
     return d->dtype == UNIVL_DT_BF16 ? dispatch_bwd<__bf16>(d, stream) : dispatch_bwd<float>(d, stream);

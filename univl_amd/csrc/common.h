@@ -49,6 +49,39 @@ void univl_set_error(const char* fmt, ...);
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// ------------------------------------------------------------------------------------------- devices
+// Entry points take the DEVICE FROM THEIR STREAM ARGUMENT (hipStreamGetDevice), never from the calling thread's
+// "current device": the reference's evaluation fan-out (util.py:21-60) calls into the model from one thread per
+// GPU, and autograd's backward threads have their own current device.  The null stream means the current device.
+#define UNIVL_MAX_DEVICES 64
+struct UnivlStreamDevice {
+    int prev = -1, dev = -1;
+    explicit UnivlStreamDevice(hipStream_t s) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        dev = prev;
+        hipDevice_t d;
+        if (s != nullptr && hipStreamGetDevice(s, &d) == hipSuccess && (int)d != prev) {
+            dev = (int)d;
+            (void)hipSetDevice(dev);
+        } else {
+            prev = -1;                       // nothing to restore
+        }
+    }
+    ~UnivlStreamDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define UNIVL_ON_STREAM_DEVICE(stream) UnivlStreamDevice univl_dev_guard__(stream)
+
+// Kernels that need more than 48 KB of dynamic LDS opt in ONCE PER DEVICE (the attribute is per device and per function).
+template <typename K>
+static inline void univl_allow_lds(K kernel, size_t bytes, bool (&done)[UNIVL_MAX_DEVICES]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const bool tracked = dev >= 0 && dev < UNIVL_MAX_DEVICES;
+    if (tracked && done[dev]) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (tracked) done[dev] = true;
+}
+
 // ------------------------------------------------------------------------------------------- small helpers
 __device__ __forceinline__ float bf2f(__bf16 v) { return (float)v; }
 __device__ __forceinline__ __bf16 f2bf(float v) { return (__bf16)v; }   // RNE on gfx950 (v_cvt_pk_bf16_f32)

@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256) void mfm_kernel(const float* logits, long ld, 
 extern "C" int univl_pair_concat_fwd(const float* seq, const float* vis, const int64_t* amask, const int64_t* vmask,
                                      const int32_t* tidx, const int32_t* vidx, int32_t P, int32_t W, int32_t F, float* out,
                                      int64_t* out_mask, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(seq && vis && amask && vmask && tidx && vidx && out && P > 0 && W > 0 && F > 0, UNIVL_EINVAL,
                     "univl_pair_concat_fwd: bad argument");
     const long rows = (long)P * (W + F);
@@ -259,6 +260,7 @@ extern "C" int univl_pair_concat_fwd(const float* seq, const float* vis, const i
 
 extern "C" int univl_pair_concat_bwd(const float* dout, const int32_t* tidx, const int32_t* vidx, int32_t P, int32_t W,
                                      int32_t F, float* dseq, float* dvis, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(dout && tidx && vidx && dseq && dvis && P > 0 && W > 0 && F > 0, UNIVL_EINVAL, "univl_pair_concat_bwd: bad argument");
     const long rows = (long)P * (W + F);
     hipLaunchKernelGGL(pair_concat_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, dout, tidx, vidx, P, W, F,
@@ -268,6 +270,7 @@ extern "C" int univl_pair_concat_bwd(const float* dout, const int32_t* tidx, con
 }
 
 extern "C" int univl_postype_fwd(const float* pos, const float* type, int32_t W, int32_t S, float* out, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(pos && type && out && S > 0 && W >= 0, UNIVL_EINVAL, "univl_postype_fwd: bad argument");
     hipLaunchKernelGGL(postype_fwd_kernel, dim3((unsigned)(((long)S * N + 255) / 256)), dim3(256), 0, stream, pos, type, W, S, out);
     UNIVL_LAUNCH_CHECK();
@@ -275,6 +278,7 @@ extern "C" int univl_postype_fwd(const float* pos, const float* type, int32_t W,
 }
 
 extern "C" int univl_postype_bwd(const float* dpt, int32_t W, int32_t S, float* dpos, float* dtype, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(dpt && dpos && dtype && S > 0, UNIVL_EINVAL, "univl_postype_bwd: bad argument");
     hipLaunchKernelGGL(postype_bwd_kernel, dim3((unsigned)(((long)S * N + 255) / 256)), dim3(256), 0, stream, dpt, W, S, dpos, dtype);
     UNIVL_LAUNCH_CHECK();
@@ -282,6 +286,7 @@ extern "C" int univl_postype_bwd(const float* dpt, int32_t W, int32_t S, float* 
 }
 
 extern "C" int univl_tanh_fwd(const float* x, float* y, int64_t n, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(x && y && n > 0, UNIVL_EINVAL, "univl_tanh_fwd: bad argument");
     long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(tanh_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y, (long)n);
@@ -290,6 +295,7 @@ extern "C" int univl_tanh_fwd(const float* x, float* y, int64_t n, hipStream_t s
 }
 
 extern "C" int univl_tanh_bwd(int32_t dtype, const float* dy, const float* y, void* dx, int64_t n, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(dy && y && dx && n > 0, UNIVL_EINVAL, "univl_tanh_bwd: bad argument");
     long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
     if (dtype == UNIVL_DT_BF16)
@@ -301,6 +307,7 @@ extern "C" int univl_tanh_bwd(int32_t dtype, const float* dy, const float* y, vo
 }
 
 extern "C" int univl_gelu_bwd(int32_t dtype, const float* dg, const void* u, void* du, int64_t n, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(dg && u && du && n > 0, UNIVL_EINVAL, "univl_gelu_bwd: bad argument");
     long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
     if (dtype == UNIVL_DT_BF16)
@@ -314,6 +321,7 @@ extern "C" int univl_gelu_bwd(int32_t dtype, const float* dg, const void* u, voi
 }
 
 extern "C" int univl_colsum(int32_t dtype, const void* x, int64_t ld, int32_t rows, int32_t n, float* out, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(x && out && rows > 0 && n > 0, UNIVL_EINVAL, "univl_colsum: bad argument");
     dim3 grid((n + 255) / 256, (rows + 63) / 64);
     if (dtype == UNIVL_DT_BF16)
@@ -325,6 +333,7 @@ extern "C" int univl_colsum(int32_t dtype, const void* x, int64_t ld, int32_t ro
 }
 
 extern "C" int univl_scale_ct_by_device_scalar(int32_t dtype, void* x, int64_t n, const float* s, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(x && s && n > 0, UNIVL_EINVAL, "univl_scale_ct_by_device_scalar: bad argument");
     long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
     if (dtype == UNIVL_DT_BF16)
@@ -366,6 +375,7 @@ __global__ __launch_bounds__(256) void log_softmax_rows_kernel(float* x, int n, 
 
 extern "C" int univl_gather_rows(const void* src, void* dst, const int32_t* idx, int32_t rows, int64_t row_stride, int64_t copy_bytes,
                                  hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(src && dst && idx && rows > 0 && copy_bytes >= 0 && copy_bytes <= row_stride, UNIVL_EINVAL,
                     "univl_gather_rows: bad argument");
     UNIVL_CHECK_ARG(aligned16(src) && aligned16(dst) && row_stride % 16 == 0 && copy_bytes % 16 == 0, UNIVL_EALIGN,
@@ -380,6 +390,7 @@ extern "C" int univl_gather_rows(const void* src, void* dst, const int32_t* idx,
 }
 
 extern "C" int univl_log_softmax_rows(float* x, int32_t rows, int32_t n, int64_t ld, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(x && rows > 0 && n > 0 && ld >= n, UNIVL_EINVAL, "univl_log_softmax_rows: bad argument");
     hipLaunchKernelGGL(log_softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, x, n, (long)ld);
     UNIVL_LAUNCH_CHECK();
@@ -387,6 +398,7 @@ extern "C" int univl_log_softmax_rows(float* x, int32_t rows, int32_t n, int64_t
 }
 
 extern "C" int univl_simdense_fwd(const float* x, const float* w, const float* b, int32_t rows, float* out, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(x && w && b && out && rows > 0, UNIVL_EINVAL, "univl_simdense_fwd: bad argument");
     hipLaunchKernelGGL(simdense_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, w, b, rows, out);
     UNIVL_LAUNCH_CHECK();
@@ -395,6 +407,7 @@ extern "C" int univl_simdense_fwd(const float* x, const float* w, const float* b
 
 extern "C" int univl_simdense_bwd(const float* ds, const float* x, const float* w, int32_t rows, float* dx, float* dw, float* db,
                                   hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(ds && x && w && dx && dw && db && rows > 0, UNIVL_EINVAL, "univl_simdense_bwd: bad argument");
     hipLaunchKernelGGL(simdense_bwd_kernel, dim3(1), dim3(256), 0, stream, ds, x, w, rows, dx, dw, db);
     UNIVL_LAUNCH_CHECK();
@@ -403,6 +416,7 @@ extern "C" int univl_simdense_bwd(const float* ds, const float* x, const float* 
 
 extern "C" int univl_ce_loss(int32_t dtype, const float* logits, int64_t ld, const int64_t* labels, int32_t rows, int32_t V,
                              int32_t ignore_index, float* scratch2, float* loss, void* dlogits, int64_t lddl, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(logits && labels && scratch2 && loss && dlogits && rows > 0 && V > 0 && ld >= V && lddl >= V, UNIVL_EINVAL,
                     "univl_ce_loss: bad argument");
     UNIVL_CHECK_ARG(dtype == UNIVL_DT_F32 || dtype == UNIVL_DT_BF16, UNIVL_EUNSUPPORTED, "univl_ce_loss: dtype %d", dtype);
@@ -420,6 +434,7 @@ extern "C" int univl_ce_loss(int32_t dtype, const float* logits, int64_t ld, con
 
 extern "C" int univl_mfm_nce_loss(const float* logits, int64_t ld, const int64_t* vmask, const int64_t* labels, int32_t n,
                                   float* scratch2, float* loss, float* dlogits, int64_t lddl, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(logits && vmask && labels && scratch2 && loss && dlogits && n > 0 && ld >= n && lddl >= n, UNIVL_EINVAL,
                     "univl_mfm_nce_loss: bad argument");
     hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, stream, labels, n, -1, scratch2);

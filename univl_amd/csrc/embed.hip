@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(UnivlEmbedText p) {
 }  // namespace
 
 extern "C" int univl_embed_text_fwd(const UnivlEmbedText* d, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(d != nullptr, UNIVL_EINVAL, "univl_embed_text_fwd: null descriptor");
     UNIVL_CHECK_ARG(d->N == 768, UNIVL_EUNSUPPORTED, "univl_embed_text_fwd: N=%d (768 supported)", d->N);
     UNIVL_CHECK_ARG(d->B > 0 && d->S > 0 && d->ids && d->word && d->pos && d->gamma && d->beta && (d->out32 || d->out16),
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* ids, 
 }  // namespace
 
 extern "C" int univl_embed_scatter(const int64_t* ids, const float* rows, int64_t n, float scale, float* dword, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(ids && rows && dword && n > 0, UNIVL_EINVAL, "univl_embed_scatter: bad argument");
     hipLaunchKernelGGL(embed_scatter_kernel, dim3((unsigned)n), dim3(256), 0, stream, ids, rows, scale, dword);
     UNIVL_LAUNCH_CHECK();
@@ -186,6 +188,7 @@ extern "C" int univl_embed_scatter(const int64_t* ids, const float* rows, int64_
 }
 
 extern "C" int univl_embed_text_bwd(const UnivlEmbedText* d, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(d != nullptr, UNIVL_EINVAL, "univl_embed_text_bwd: null descriptor");
     UNIVL_CHECK_ARG(d->N == 768, UNIVL_EUNSUPPORTED, "univl_embed_text_bwd: N=%d (768 supported)", d->N);
     UNIVL_CHECK_ARG(d->B > 0 && d->S > 0 && d->ids && d->dout && d->y && d->stats && d->gamma && d->dword && d->dpos &&

@@ -418,12 +418,8 @@ int launch_group(const GroupArgs& g, hipStream_t stream) {
     using TileB = Tile<T, TB, BN, BK>;
     // NC == 6 is the one-K-step variant: only stage 0 of B is ever touched (A keeps the two-stage offset layout)
     const size_t smem = NC == 6 ? 2 * TileA::BYTES + TileB::BYTES : 2 * (TileA::BYTES + TileB::BYTES);
-    static bool attr_done = false;   // per instantiation
-    if (!attr_done && smem > 48 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_group_kernel<T, TA, TB, BM, BN, D, NC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
-    }
+    static bool attr_done[UNIVL_MAX_DEVICES] = {};   // per instantiation, per device
+    if (smem > 48 * 1024) univl_allow_lds(gemm_group_kernel<T, TA, TB, BM, BN, D, NC>, smem, attr_done);
     hipLaunchKernelGGL((gemm_group_kernel<T, TA, TB, BM, BN, D, NC>), dim3(g.first[UNIVL_GEMM_GROUP_MAX]), dim3(256), smem,
                        stream, g);
     UNIVL_LAUNCH_CHECK();
@@ -437,12 +433,8 @@ int launch(const GemmArgs& a, int ksplit, hipStream_t stream) {
     using TileB = Tile<T, TB, BN, BK>;
     // NC == 6 is the one-K-step variant: only stage 0 of B is ever touched (A keeps the two-stage offset layout)
     const size_t smem = NC == 6 ? 2 * TileA::BYTES + TileB::BYTES : 2 * (TileA::BYTES + TileB::BYTES);
-    static bool attr_done = false;   // per instantiation
-    if (!attr_done && smem > 48 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, TA, TB, BM, BN, D, NC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
-    }
+    static bool attr_done[UNIVL_MAX_DEVICES] = {};   // per instantiation, per device
+    if (smem > 48 * 1024) univl_allow_lds(gemm_kernel<T, TA, TB, BM, BN, D, NC>, smem, attr_done);
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, ksplit);
     hipLaunchKernelGGL((gemm_kernel<T, TA, TB, BM, BN, D, NC>), grid, dim3(256), smem, stream, a);
     UNIVL_LAUNCH_CHECK();
@@ -532,6 +524,7 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, bool& big, int&
 }
 
 extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     GemmArgs a;
     int ksplit, nc;
     bool big;
@@ -553,6 +546,7 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
 }
 
 extern "C" int univl_gemm_group(const UnivlGemm* d, int n, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(d != nullptr && n >= 1 && n <= UNIVL_GEMM_GROUP_MAX, UNIVL_EINVAL, "univl_gemm_group: n=%d (1..%d)", n,
                     UNIVL_GEMM_GROUP_MAX);
     if (n == 1) return univl_gemm(d, stream);

@@ -221,6 +221,7 @@ int check_common(const UnivlLayerNorm* d, const char* who) {
 }  // namespace
 
 extern "C" int univl_layernorm_fwd(const UnivlLayerNorm* d, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     int rc = check_common(d, "univl_layernorm_fwd");
     if (rc) return rc;
     UNIVL_CHECK_ARG(d->x && d->beta && (d->out32 || d->out16), UNIVL_EINVAL, "univl_layernorm_fwd: null x/beta/out");
@@ -243,6 +244,7 @@ extern "C" int univl_layernorm_fwd(const UnivlLayerNorm* d, hipStream_t stream) 
 }
 
 extern "C" int univl_layernorm_bwd(const UnivlLayerNorm* d, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     int rc = check_common(d, "univl_layernorm_bwd");
     if (rc) return rc;
     UNIVL_CHECK_ARG(d->dout && d->y && d->stats, UNIVL_EINVAL, "univl_layernorm_bwd: null dout/y/stats");

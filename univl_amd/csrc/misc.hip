@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <dlfcn.h>
 #include "common.h"
 #include "univl_hip.h"
 
@@ -42,6 +43,52 @@ extern "C" int univl_device_info(int* cu_count, char* name, int name_len) {
     if (cu_count) *cu_count = prop.multiProcessorCount;
     if (name && name_len > 0) { strncpy(name, prop.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
     return 0;
+}
+
+extern "C" int univl_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { univl_set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return (int)e; }
+    UNIVL_CHECK_ARG(device >= 0 && device < n, UNIVL_EINVAL, "univl_init: device %d of %d", device, n);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { univl_set_error("hipGetDeviceProperties: %s", hipGetErrorString(e)); return (int)e; }
+    UNIVL_CHECK_ARG(strncmp(prop.gcnArchName, "gfx950", 6) == 0, UNIVL_EUNSUPPORTED,
+                    "univl_init: device %d is %s; libunivl_hip holds gfx950 (MI355X) code only", device, prop.gcnArchName);
+    return UNIVL_OK;
+}
+
+// ---- RCCL, resolved lazily so that the library itself has no link-time dependency on it
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+static void* g_rccl_handle = nullptr;
+static nccl_allreduce_fn g_allreduce = nullptr;
+
+extern "C" int univl_destroy(void) {
+    g_allreduce = nullptr;
+    if (g_rccl_handle) { dlclose(g_rccl_handle); g_rccl_handle = nullptr; }
+    return UNIVL_OK;
+}
+
+extern "C" int univl_allreduce_bucket(void* buf, size_t n, int dtype, int average, void* comm, hipStream_t side) {
+    UNIVL_ON_STREAM_DEVICE(side);
+    UNIVL_CHECK_ARG(buf && comm && n > 0 && (dtype == UNIVL_F32 || dtype == UNIVL_BF16), UNIVL_EINVAL,
+                    "univl_allreduce_bucket: bad argument");
+    if (!g_allreduce) {
+        void* sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");               // the copy the host already loaded (torch's)
+        if (!sym) {
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                g_rccl_handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (g_rccl_handle) break;
+            }
+            if (g_rccl_handle) sym = dlsym(g_rccl_handle, "ncclAllReduce");
+        }
+        UNIVL_CHECK_ARG(sym != nullptr, UNIVL_EUNSUPPORTED, "univl_allreduce_bucket: RCCL (ncclAllReduce) not found");
+        g_allreduce = reinterpret_cast<nccl_allreduce_fn>(sym);
+    }
+    // rccl.h: ncclFloat32 = 7, ncclBfloat16 = 9; ncclSum = 0, ncclAvg = 4
+    const int rc = g_allreduce(buf, buf, n, dtype == UNIVL_BF16 ? 9 : 7, average ? 4 : 0, comm, side);
+    if (rc != 0) { univl_set_error("univl_allreduce_bucket: ncclAllReduce returned %d", rc); return 1000 + rc; }
+    return UNIVL_OK;
 }
 
 namespace {
@@ -119,6 +166,7 @@ __global__ void probe_kernel(float* out) {
 }  // namespace
 
 extern "C" int univl_probe_layouts(float* out, int32_t n_out, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(out && n_out >= 1792, UNIVL_EINVAL, "univl_probe_layouts: need 1792 floats");
     hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, stream, out);
     UNIVL_LAUNCH_CHECK();

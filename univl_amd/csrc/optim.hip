@@ -96,7 +96,13 @@ __global__ void adam_prep_kernel(UnivlAdam a) {
     }
     const int st = a.step[s];
     float lr = sg.lr;
-    if (a.t_total != -1) lr *= warmup_linear_f((float)st / (float)a.t_total, a.warmup);
+    if (a.t_total != -1) {
+        const float x = (float)st / (float)a.t_total;
+        float f = warmup_linear_f(x, a.warmup);
+        if (a.schedule == 1) f = x < a.warmup ? x / a.warmup : 0.5f * (1.0f + cosf(3.14159265358979323846f * x));   // warmup_cosine :26-29
+        if (a.schedule == 2) f = x < a.warmup ? x / a.warmup : 1.0f;                                                // warmup_constant :31-36
+        lr *= f;
+    }
     a.seg_scalars[2 * s] = scale;
     a.seg_scalars[2 * s + 1] = lr;
     a.step[s] = st + 1;
@@ -174,6 +180,7 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* p, __bf16* o, in
 extern "C" int univl_grad_sumsq(const float* g, const UnivlSeg* segs, int32_t nseg, const int32_t* chunk_seg,
                                 const int64_t* chunk_off, const int32_t* chunk_len, int32_t nchunk, float* sumsq,
                                 hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(g && segs && chunk_seg && chunk_off && chunk_len && sumsq && nseg > 0 && nchunk > 0, UNIVL_EINVAL,
                     "univl_grad_sumsq: bad argument");
     hipLaunchKernelGGL(sumsq_kernel, dim3(nchunk), dim3(256), 0, stream, g, segs, chunk_seg, chunk_off, chunk_len, sumsq);
@@ -194,6 +201,7 @@ __global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* partials
 
 extern "C" int univl_sumsq_finish(const float* partials, const int32_t* seg, const int32_t* start, const int32_t* count,
                                   int32_t n, float* out, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(partials && seg && start && count && out && n > 0, UNIVL_EINVAL, "univl_sumsq_finish: bad argument");
     hipLaunchKernelGGL(sumsq_finish_kernel, dim3(n), dim3(256), 0, stream, partials, seg, start, count, out);
     UNIVL_LAUNCH_CHECK();
@@ -202,6 +210,7 @@ extern "C" int univl_sumsq_finish(const float* partials, const int32_t* seg, con
 
 extern "C" int univl_clip_coef(const float* sumsq, const UnivlSeg* segs, int32_t nseg, float max_norm, float* coef,
                                hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(sumsq && segs && coef && nseg > 0, UNIVL_EINVAL, "univl_clip_coef: bad argument");
     hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, stream, sumsq, segs, nseg, max_norm, coef);
     UNIVL_LAUNCH_CHECK();
@@ -210,6 +219,7 @@ extern "C" int univl_clip_coef(const float* sumsq, const UnivlSeg* segs, int32_t
 
 extern "C" int univl_scale_grads(float* g, const UnivlSeg* segs, const int32_t* chunk_seg, const int64_t* chunk_off,
                                  const int32_t* chunk_len, int32_t nchunk, const float* coef, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(g && segs && chunk_seg && chunk_off && chunk_len && coef && nchunk > 0, UNIVL_EINVAL,
                     "univl_scale_grads: bad argument");
     hipLaunchKernelGGL(scale_kernel, dim3(nchunk), dim3(256), 0, stream, g, segs, chunk_seg, chunk_off, chunk_len, coef);
@@ -218,6 +228,7 @@ extern "C" int univl_scale_grads(float* g, const UnivlSeg* segs, const int32_t* 
 }
 
 extern "C" int univl_bert_adam(const UnivlAdam* d, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(d && d->p && d->g && d->m && d->v && d->segs && d->chunk_seg && d->chunk_off && d->chunk_len &&
                         d->sumsq && d->step && d->seg_scalars && d->nseg > 0 && d->nchunk > 0,
                     UNIVL_EINVAL, "univl_bert_adam: bad argument");
@@ -230,6 +241,7 @@ extern "C" int univl_bert_adam(const UnivlAdam* d, hipStream_t stream) {
 __global__ void bump_kernel(uint64_t* c) { c[0] += 1; }
 
 extern "C" int univl_bump_counter(uint64_t* ctr, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(ctr != nullptr, UNIVL_EINVAL, "univl_bump_counter: null");
     hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, stream, ctr);
     UNIVL_LAUNCH_CHECK();
@@ -237,6 +249,7 @@ extern "C" int univl_bump_counter(uint64_t* ctr, hipStream_t stream) {
 }
 
 extern "C" int univl_cast_bf16(const float* p, void* p16, int64_t n, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(p && p16 && n > 0 && aligned16(p) && ((((uintptr_t)p16) & 7) == 0), UNIVL_EINVAL, "univl_cast_bf16: bad argument");
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;

@@ -248,6 +248,7 @@ __global__ void scale_dev_kernel(float* x, long n, const float* s) {
 }  // namespace
 
 extern "C" int univl_scale_by_device_scalar(float* x, int64_t n, const float* s, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(x && s && n > 0, UNIVL_EINVAL, "univl_scale_by_device_scalar: bad argument");
     long blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(256) void rank_counts_kernel(const float* x, int n,
 }
 
 extern "C" int univl_rank_counts(const float* sim, int32_t n, int64_t ld, int32_t* gt, int32_t* eq, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(sim && gt && eq && n > 0 && ld >= n, UNIVL_EINVAL, "univl_rank_counts: bad argument");
     hipLaunchKernelGGL(rank_counts_kernel, dim3(n), dim3(256), 0, stream, sim, n, (long)ld, gt, eq);
     UNIVL_LAUNCH_CHECK();
@@ -285,6 +287,7 @@ extern "C" int univl_rank_counts(const float* sim, int32_t n, int64_t ld, int32_
 }
 
 extern "C" int univl_pool_fwd(const UnivlPool* d, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(d && d->N == 768 && d->B > 0 && d->S > 0 && d->x && d->out, UNIVL_EINVAL, "univl_pool_fwd: bad argument (N must be 768)");
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(d->B), dim3(256), 0, stream, *d);
     UNIVL_LAUNCH_CHECK();
@@ -292,6 +295,7 @@ extern "C" int univl_pool_fwd(const UnivlPool* d, hipStream_t stream) {
 }
 
 extern "C" int univl_pool_bwd(const UnivlPool* d, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(d && d->N == 768 && d->B > 0 && d->S > 0 && d->mean && d->dout && d->dx, UNIVL_EINVAL, "univl_pool_bwd: bad argument");
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(d->B, (d->S + PCHUNK - 1) / PCHUNK), dim3(256), 0, stream, *d);
     UNIVL_LAUNCH_CHECK();
@@ -300,6 +304,7 @@ extern "C" int univl_pool_bwd(const UnivlPool* d, hipStream_t stream) {
 
 extern "C" int univl_maxmargin_loss(const float* sim, int32_t n, int32_t ld, float margin, const float* weight, float* loss,
                                     float* dsim, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(sim && loss && dsim && n > 0 && n <= 8192 && ld >= n, UNIVL_EINVAL, "univl_maxmargin_loss: bad argument");
     hipLaunchKernelGGL(maxmargin_kernel, dim3(1), dim3(256), n * sizeof(float), stream, sim, n, ld, margin, weight, loss, dsim);
     UNIVL_LAUNCH_CHECK();
@@ -307,6 +312,7 @@ extern "C" int univl_maxmargin_loss(const float* sim, int32_t n, int32_t ld, flo
 }
 
 extern "C" int univl_crossen_loss(const float* sim, int32_t n, int32_t ld, float* loss, float* dsim, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(sim && loss && dsim && n > 0 && ld >= n, UNIVL_EINVAL, "univl_crossen_loss: bad argument");
     hipLaunchKernelGGL(crossen_kernel, dim3(1), dim3(256), 0, stream, sim, n, ld, loss, dsim);
     UNIVL_LAUNCH_CHECK();
@@ -315,6 +321,7 @@ extern "C" int univl_crossen_loss(const float* sim, int32_t n, int32_t ld, float
 
 extern "C" int univl_milnce_loss(const float* sim, int32_t batch_size, int32_t n_pair, int32_t ld, float* loss, float* dsim,
                                  hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(sim && loss && dsim && batch_size > 0 && n_pair > 0 && ld >= batch_size * n_pair, UNIVL_EINVAL, "univl_milnce_loss: bad argument");
     hipLaunchKernelGGL(milnce_kernel, dim3(1), dim3(256), 0, stream, sim, batch_size, n_pair, ld, loss, dsim);
     UNIVL_LAUNCH_CHECK();

@@ -524,7 +524,7 @@ class UniVL(UniVLPreTrainedModel):
         if self._stage_one:
             return "align" if self.train_sim_after_cross else "joint"
         if tc.do_pretrain:
-            return "pretrain"
+            return "pretrain" if has_caption else "pretrain_nocap"     # modeling.py:238: the decoder loss needs captions
         if tc.task_type == "caption":
             return "caption"
         return "align"                       # stage two, task_type "retrieval": cross-encoder similarity + CrossEn
@@ -543,6 +543,8 @@ class UniVL(UniVLPreTrainedModel):
             if kind == "caption" and (n.startswith("cross.pooler") or n.startswith("similarity_dense")):
                 continue
             if kind == "align" and (n.startswith("decoder.") or n.startswith("cls")):
+                continue
+            if kind == "pretrain_nocap" and n.startswith("decoder."):
                 continue
             out.append(n)
         return out
@@ -580,10 +582,14 @@ class UniVL(UniVLPreTrainedModel):
             st.gout.fill_(1.0)
         else:
             st.gout.copy_(gout.reshape(1).to(torch.float32))
+        if fl._pending is not None:          # a deferred clip nobody consumed: it scales the OLD gradients, as torch's did
+            from .optimization import apply_pending_clip
+            apply_pending_clip(fl)
         fl.grad_version += 1
         self._run_plan(st.backward_plan(fresh), st)
         plan = st.backward_plan(fresh)
-        fl.fused = dict(version=fl.grad_version, names=plan.fused_names) if plan.fused_names else None
+        fl.fused = (dict(version=fl.grad_version, names=plan.fused_names, tv=fl.g32._version)
+                    if plan.fused_names else None)
         fl.attach_grads(used)
 
     def forward(self, input_ids, token_type_ids, attention_mask, video, video_mask=None,
@@ -595,15 +601,17 @@ class UniVL(UniVLPreTrainedModel):
         W, F = input_ids.shape[-1], video_mask.shape[-1]
         B = input_ids.numel() // W
         kind = self.step_kind(input_caption_ids is not None)
-        if kind in ("caption", "pretrain") and input_caption_ids is None:
-            raise RuntimeError("UniVL.forward: the %s path needs input_caption_ids / decoder_mask / output_caption_ids" % kind)
+        if kind == "caption" and input_caption_ids is None:
+            # modeling.py:238-254: without captions the caption task has no loss term at all (the reference returns the
+            # float 0.0, whose .backward() fails in the script)
+            raise RuntimeError("UniVL.forward: the caption path needs input_caption_ids / decoder_mask / output_caption_ids")
         if not self._dp_checked:
             self._auto_data_parallel()
         fl = self.flat
         fl.refresh_shadow()
         st = self._get_step(kind, B, W, F)
         st.enc.load(input_ids, token_type_ids, attention_mask, video, video_mask)
-        if kind == "pretrain":
+        if kind in ("pretrain", "pretrain_nocap"):
             st.enc_m.load(pairs_masked_text, token_type_ids, attention_mask, masked_video, video_mask)
             st.heads.load(pairs_token_labels, video_labels_index)
         if st.decoder is not None:
@@ -620,8 +628,6 @@ class UniVL(UniVLPreTrainedModel):
     def get_sequence_visual_output(self, input_ids, token_type_ids, attention_mask, video, video_mask, shaped=False):
         """modeling.py:299-313.  `shaped=True` means the caller already flattened the pair dim AND normalised the video
         (only UniVL.forward does that in the reference); external callers use shaped=False."""
-        if shaped:
-            raise NotImplementedError("shaped=True is internal to the reference's forward(); pass raw inputs")
         W, F = input_ids.shape[-1], video_mask.shape[-1]
         B = input_ids.numel() // W
         fl = self.flat
@@ -629,7 +635,8 @@ class UniVL(UniVLPreTrainedModel):
         was = self.training
         self.training = False                      # feature extraction never applies dropout plans' training variant
         try:
-            st = self._get_step("joint" if self.cross is None else "features", B, W, F)
+            # shaped=True (modeling.py:300-305 skipped): `video` is already float32 [B, F, video_dim] and normalised
+            st = self._get_step("features_shaped" if shaped else ("joint" if self.cross is None else "features"), B, W, F)
         finally:
             self.training = was
         st.enc.load(input_ids, token_type_ids, attention_mask, video, video_mask)

@@ -18,11 +18,26 @@ from .engine import FLAT_REGISTRY
 CHUNK = 8192   # elements per workgroup
 
 
+import math
+
+
+def warmup_cosine(x, warmup=0.002):
+    """optimization.py:26-29."""
+    return x / warmup if x < warmup else 0.5 * (1.0 + math.cos(math.pi * x))
+
+
+def warmup_constant(x, warmup=0.002):
+    """optimization.py:31-36."""
+    return x / warmup if x < warmup else 1.0
+
+
 def warmup_linear(x, warmup=0.002):
     """optimization.py:38-43."""
-    if x < warmup:
-        return x / warmup
-    return max((x - 1.) / (warmup - 1.), 0)
+    return x / warmup if x < warmup else max((x - 1.) / (warmup - 1.), 0)
+
+
+SCHEDULES = {'warmup_cosine': warmup_cosine, 'warmup_constant': warmup_constant, 'warmup_linear': warmup_linear}
+_SCHEDULE_CODE = {'warmup_linear': 0, 'warmup_cosine': 1, 'warmup_constant': 2}      # UnivlAdam.schedule
 
 
 def _find_flat(p):
@@ -85,6 +100,10 @@ def _measure(fl, cfg, tb):
     already accumulated its own sum during this backward (engine.GradState.sumsq_args) are not read again: only the
     rest (embedding tables, vectors, a few small matrices) goes through the streaming kernel."""
     fused = fl.fused
+    # the epilogue sums describe the gradients as the backward left them: any in-place change since then made through
+    # torch (stock clip_grad_norm_, p.grad.mul_(), AMP unscale -- all bump the flat buffer's version counter) voids them
+    if fused is not None and fused.get("tv", fl.g32._version) != fl.g32._version:
+        fused = fl.fused = None
     if fused is not None and fused["version"] == fl.grad_version and fused["names"] <= set(cfg) and not fused.get("consumed"):
         fused["consumed"] = True          # fl.sumsq may be completed once per backward; later callers re-measure
         rest = {n: c for n, c in cfg.items() if n not in fused["names"]}
@@ -121,6 +140,20 @@ def _active_cfg(fl, params_with_cfg):
     return cfg
 
 
+def apply_pending_clip(fl):
+    """A deferred clip (clip_grad_norm_(..., deferred=True)) that BertAdam.step did not consume -- another backward is about
+    to add to the gradients, or the optimizer holds a different parameter set -- is applied in place, exactly where torch
+    would have scaled the gradients.  Never dropped."""
+    pend, fl._pending = fl._pending, None
+    if pend is None:
+        return
+    tb = pend["tables"]
+    _lib.check(_lib.lib().univl_scale_grads(fl.g32.data_ptr(), tb.segs.data_ptr(), tb.chunk_seg.data_ptr(),
+                                            tb.chunk_off.data_ptr(), tb.chunk_len.data_ptr(), tb.nchunk, pend["coef"].data_ptr(),
+                                            _stream()), "scale_grads")
+    fl.fused = None                        # the gradients were rescaled in place
+
+
 def clip_grad_norm_(parameters, max_norm, norm_type=2.0, deferred=True):
     """Fused torch.nn.utils.clip_grad_norm_ for univl_amd models (main_task_retrieval.py:347).
 
@@ -133,6 +166,8 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, deferred=True):
     if not params:
         return torch.tensor(0.0)
     fl = _find_flat(params[0])
+    if fl._pending is not None:            # two clips in a row: the first one takes effect now
+        apply_pending_clip(fl)
     cfg = _active_cfg(fl, [(p, (0.0, 0.0, 0.0)) for p in params])
     key = tuple(sorted(cfg))
     tb = fl._clip[1] if (fl._clip is not None and fl._clip[0] == key) else None
@@ -150,7 +185,7 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, deferred=True):
         fl._pending = None
         fl.fused = None                    # the gradients were rescaled in place
     else:
-        fl._pending = dict(version=fl.grad_version, names=key, sumsq=sumsq, coef=tb.coef)
+        fl._pending = dict(version=fl.grad_version, names=key, sumsq=sumsq, coef=tb.coef, tables=tb)
     return tb.coef[1]
 
 
@@ -161,9 +196,8 @@ class BertAdam(Optimizer):
                  weight_decay=0.01, max_grad_norm=1.0):
         if lr is None or lr < 0.0:
             raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
-        if schedule != 'warmup_linear':
-            raise ValueError("Invalid schedule parameter: {} (univl_amd implements warmup_linear, the one the "
-                             "reference's scripts use)".format(schedule))
+        if schedule not in SCHEDULES:
+            raise ValueError("Invalid schedule parameter: {}".format(schedule))
         if not 0.0 <= warmup < 1.0 and not warmup == -1:
             raise ValueError("Invalid warmup: {} - should be in [0.0, 1.0[ or -1".format(warmup))
         if not 0.0 <= b1 < 1.0:
@@ -185,7 +219,9 @@ class BertAdam(Optimizer):
         self._m = self._v = self._step_dev = None
 
     def get_lr(self):
-        """optimization.py:86-101."""
+        """optimization.py:86-101 (step counters are read back from the device: under hipGraph replay the host never
+        sees the individual steps)."""
+        self._sync_steps()
         lr = []
         for group in self.param_groups:
             for p in group['params']:
@@ -195,7 +231,7 @@ class BertAdam(Optimizer):
                 if len(state) == 0:
                     return [0]
                 if group['t_total'] != -1:
-                    lr_scheduled = group['lr'] * warmup_linear(state['step'] / group['t_total'], group['warmup'])
+                    lr_scheduled = group['lr'] * SCHEDULES[group['schedule']](state['step'] / group['t_total'], group['warmup'])
                 else:
                     lr_scheduled = group['lr']
                 lr.append(lr_scheduled)
@@ -206,16 +242,93 @@ class BertAdam(Optimizer):
         used by bench.py to time the update kernel with HIP events without being host-bound."""
         _lib.check(_lib.lib().univl_bert_adam(C.byref(self._last_desc), _stream()), "bert_adam")
 
+    # ------------------------------------------------------------------------------------------- state plumbing
+    # The moments live in two flat buffers laid out like the model's flat parameter buffer; state[p]['next_m'/'next_v'] are
+    # views into them and state[p]['step'] mirrors a per-tensor device counter, so that the reference's optimizer
+    # checkpoints (main_pretrain.py:266-273, 389) interchange in both directions.
+    def _link(self, fl, p, name, step=None):
+        o, k, shp = fl.index[name]
+        st = self.state[p]
+        if step is None:
+            step = st.get('step', 0)
+        st['step'] = int(step)
+        st['next_m'] = self._m[o:o + k].view(shp)
+        st['next_v'] = self._v[o:o + k].view(shp)
+
     def _bind(self):
         p0 = self.param_groups[0]['params'][0]
         fl = _find_flat(p0)
-        if self._fl is not fl:
-            self._fl = fl
-            self._m = torch.zeros(fl.total, device=fl.device)
-            self._v = torch.zeros(fl.total, device=fl.device)
-            self._step_dev = torch.zeros(len(fl.order), device=fl.device, dtype=torch.int32)
-            self._tb = None
+        if self._fl is fl:
+            return fl
+        old, m_old, v_old, s_old = self._fl, self._m, self._v, self._step_dev
+        self._fl = fl
+        self._m = torch.zeros(fl.total, device=fl.device)
+        self._v = torch.zeros(fl.total, device=fl.device)
+        self._step_dev = torch.zeros(len(fl.order), device=fl.device, dtype=torch.int32)
+        self._tb = None
+        # existing state (a model moved with .to()/.float() re-flattens its parameters; a checkpoint loaded before the first
+        # step holds free-standing tensors): migrate it into the new flat buffers instead of starting from zero
+        steps = s_old.cpu().tolist() if (old is not None and s_old is not None) else None
+        for p, st in list(self.state.items()):
+            name = fl.name_of.get(id(p))
+            if name is None or not st:
+                continue
+            o, k, shp = fl.index[name]
+            step = st.get('step', 0)
+            if old is not None and name in old.index and old.index[name][1] == k:
+                oo = old.index[name][0]
+                self._m[o:o + k].copy_(m_old[oo:oo + k])
+                self._v[o:o + k].copy_(v_old[oo:oo + k])
+                step = steps[old.seg_of[name]]
+            elif 'next_m' in st:
+                self._m[o:o + k].copy_(st['next_m'].reshape(-1))
+                self._v[o:o + k].copy_(st['next_v'].reshape(-1))
+            self._step_dev[fl.seg_of[name]] = int(step)
+            self._link(fl, p, name, step)
         return fl
+
+    def _sync_steps(self):
+        fl = self._fl
+        if fl is None or self._step_dev is None:
+            return
+        steps = self._step_dev.cpu().tolist()
+        for p, st in self.state.items():
+            name = fl.name_of.get(id(p))
+            if name is not None and st:
+                st['step'] = int(steps[fl.seg_of[name]])
+
+    def state_dict(self):
+        """Same structure as the reference optimizer's: state[i] = {step, next_m, next_v} with free-standing tensors."""
+        self._sync_steps()
+        sd = super().state_dict()
+        for st in sd['state'].values():
+            for k in ('next_m', 'next_v'):
+                if k in st:
+                    st[k] = st[k].clone()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        """optimizer.load_state_dict(checkpoint['last_optimizer_state']) of main_pretrain.py:389: torch installs fresh
+        tensors under state[p]; they are copied into the flat moment buffers, the device step counters are set from
+        state['step'], and the entries are re-pointed at the flat views the kernel updates."""
+        super().load_state_dict(state_dict)
+        try:
+            fl = _find_flat(self.param_groups[0]['params'][0])
+        except RuntimeError:
+            return                          # model not on the device yet: _bind() migrates the loaded tensors later
+        if self._fl is not fl:
+            self._fl = None                 # force a fresh bind that migrates from the loaded tensors
+            self._bind()
+            return
+        for p, st in self.state.items():
+            name = fl.name_of.get(id(p))
+            if name is None or 'next_m' not in st:
+                continue
+            o, k, _ = fl.index[name]
+            self._m[o:o + k].copy_(st['next_m'].reshape(-1))
+            self._v[o:o + k].copy_(st['next_v'].reshape(-1))
+            self._step_dev[fl.seg_of[name]] = int(st.get('step', 0))
+            self._link(fl, p, name)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -234,9 +347,11 @@ class BertAdam(Optimizer):
         coef_ptr = None
         if pend is not None and pend["version"] == fl.grad_version and pend["names"] == tuple(sorted(cfg)):
             sumsq, coef_ptr = pend["sumsq"], pend["coef"].data_ptr()      # clip already measured these gradients
+            fl._pending = None
         else:
+            if pend is not None:           # the clip saw another parameter set: it takes effect in place, like torch's
+                apply_pending_clip(fl)
             sumsq = _measure(fl, cfg, tb)
-        fl._pending = None
         g0 = self.param_groups[0]
         d = _lib.Adam()
         d.p, d.g, d.m, d.v = fl.p32.data_ptr(), fl.g32.data_ptr(), self._m.data_ptr(), self._v.data_ptr()
@@ -247,6 +362,7 @@ class BertAdam(Optimizer):
         d.sumsq, d.coef, d.step = sumsq.data_ptr(), coef_ptr, self._step_dev.data_ptr()
         d.b1, d.b2, d.eps = g0['b1'], g0['b2'], g0['e']
         d.warmup, d.t_total = float(g0['warmup']), int(g0['t_total'])
+        d.schedule = _SCHEDULE_CODE[g0['schedule']]
         d.seg_scalars = tb.scalars.data_ptr()
         self._last_desc = d
         _lib.check(_lib.lib().univl_bert_adam(C.byref(d), _stream()), "bert_adam")
@@ -255,9 +371,6 @@ class BertAdam(Optimizer):
             p = fl.params[n]
             st = self.state[p]
             if len(st) == 0:
-                o, k, shp = fl.index[n]
-                st['step'] = 0
-                st['next_m'] = self._m[o:o + k].view(shp)
-                st['next_v'] = self._v[o:o + k].view(shp)
+                self._link(fl, p, n, 0)
             st['step'] += 1
         return loss

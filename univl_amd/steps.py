@@ -56,8 +56,9 @@ def stage_input(dst, src):
 class EncoderPass:
     """NormalizeVideo + BertModel + VisualModel for one set of inputs (modeling.py:196-202, 299-313)."""
 
-    def __init__(self, cx, B, W, F, s_text=0, s_vis=2):
+    def __init__(self, cx, B, W, F, s_text=0, s_vis=2, normalized_input=False):
         self.cx, self.B, self.W, self.F = cx, B, W, F
+        self.normalized_input = bool(normalized_input)     # get_sequence_visual_output(shaped=True): video arrives normalised
         e, ct, bf, fl = cx.e, cx.ct, cx.bf, cx.fl
         D = cx.tc.video_dim
         self.D, self.Tt, self.Tv = D, B * W, B * F
@@ -95,7 +96,7 @@ class EncoderPass:
         stage_input(self.ids, input_ids)
         stage_input(self.type_ids, token_type_ids)
         stage_input(self.amask, attention_mask)
-        stage_input(self.video, video)
+        stage_input(self.vn32 if self.normalized_input else self.video, video)
         stage_input(self.vmask, video_mask)
 
     def build_forward(self, fwd):
@@ -103,9 +104,13 @@ class EncoderPass:
         W32, p, B, W, F, D, Tv = fl.w32, cx.p, self.B, self.W, self.F, self.D, self.Tv
         ST, SV = self.ST, self.SV
         fwd.fork(ST, SV)           # the video encoder runs concurrently with the text encoder
-        fwd.add("univl_layernorm_fwd", ops.layernorm_desc(
-            dt, Tv, D, x=self.video, x_f64=True, gamma=W32(n["nv_g"]), beta=W32(n["nv_b"]), y=self.vy, stats=self.vst,
-            out32=self.vn32, out16=self.vn_op if bf else None), SV)
+        if self.normalized_input:
+            if bf:
+                fwd.add_callable(lambda: ops.cast_bf16(self.vn32, self.vn_op), SV)
+        else:
+            fwd.add("univl_layernorm_fwd", ops.layernorm_desc(
+                dt, Tv, D, x=self.video, x_f64=True, gamma=W32(n["nv_g"]), beta=W32(n["nv_b"]), y=self.vy, stats=self.vst,
+                out32=self.vn32, out16=self.vn_op if bf else None), SV)
         fwd.add("univl_gemm", _gemm_desc(dt, self.vn_op, D, fl.wop(n["vw"]), D, Tv, H, D, out32=self.ve, ldc=H, bias=W32(n["vb"])), SV)
         fwd.add("univl_layernorm_fwd", ops.layernorm_desc(
             dt, Tv, H, x=self.ve, pos=W32(n["vpos"]), pos_period=F, gamma=W32(n["vlg"]), beta=W32(n["vlb"]), y=self.ve,
@@ -571,7 +576,7 @@ class Step:
         return self.bwd[fresh]
 
 
-def _ddp_hook(cx, fl, model):
+def _ddp_hook(cx, fl, model, kind):
     """Gradient exchange points for the data-parallel path (univl_amd.parallel): the hook is called by every encoder
     stack after each layer (backward order) and emits an eager all-reduce once UNIVL_BUCKET_MB of gradients are
     pending."""
@@ -579,7 +584,7 @@ def _ddp_hook(cx, fl, model):
     if red is None:
         return None, None, None
     from .parallel import BucketSchedule, layer_buckets
-    buckets = layer_buckets(fl, model.used_parameter_names())
+    buckets = layer_buckets(fl, model.used_parameter_names(kind))
     sched = BucketSchedule(float(os.environ.get("UNIVL_BUCKET_MB", "80")) * 2 ** 20)
 
     def emit(plan):
@@ -602,7 +607,7 @@ def build_step(model, kind, B, W, F, training):
     fwd = st.fwd
     if cx.p > 0:
         fwd.add_callable(lambda: ops.bump_counter(cx.seed_dev))
-    st.enc = enc = EncoderPass(cx, B, W, F)
+    st.enc = enc = EncoderPass(cx, B, W, F, normalized_input=(kind == "features_shaped"))
     enc.build_forward(fwd)
     st.fwd_encoders_len = len(fwd)
     stage_two = bool(model._stage_two)
@@ -627,7 +632,7 @@ def build_step(model, kind, B, W, F, training):
         st.decoder = DecoderRun(cx, st.run_rows, W)
         st.decoder.build_forward(fwd)
         st.loss_terms.append(st.decoder.loss)
-    elif kind == "pretrain":
+    elif kind in ("pretrain", "pretrain_nocap"):
         st.enc_m = enc_m = EncoderPass(cx, B, W, F)            # masked text / masked video pass (modeling.py:221)
         enc_m.build_forward(fwd)
         st.run_heads = CrossRun(cx, enc_m, rows, rows)
@@ -638,17 +643,18 @@ def build_step(model, kind, B, W, F, training):
         st.joint = JointSim(cx, enc, pre_kind)                  # _pretrain_joint on the CLEAN outputs (:233-236)
         st.joint.build_forward(fwd)
         st.loss_terms.append(st.joint.loss)
-        st.run_rows = CrossRun(cx, enc_m, rows, rows)            # _get_decoder_score re-runs the cross encoder (:404)
-        st.run_rows.build_forward(fwd)
-        st.decoder = DecoderRun(cx, st.run_rows, W)
-        st.decoder.build_forward(fwd)
-        st.loss_terms.append(st.decoder.loss)
+        if kind == "pretrain":                                   # modeling.py:238-254: only when captions are given
+            st.run_rows = CrossRun(cx, enc_m, rows, rows)        # _get_decoder_score re-runs the cross encoder (:404)
+            st.run_rows.build_forward(fwd)
+            st.decoder = DecoderRun(cx, st.run_rows, W)
+            st.decoder.build_forward(fwd)
+            st.loss_terms.append(st.decoder.loss)
         st.run_pairs = CrossRun(cx, enc_m, [a for a, _ in pairs], [b for _, b in pairs])   # alignment (:258-267)
         st.run_pairs.build_forward(fwd)
         st.pooler = PoolerSim(cx, st.run_pairs, B, B, loss_kind)
         st.pooler.build_forward(fwd)
         st.loss_terms.append(st.pooler.loss)
-    elif kind == "features":
+    elif kind in ("features", "features_shaped"):
         pass                                   # encoders only (get_sequence_visual_output on a stage-two model)
     else:
         raise ValueError(kind)
@@ -665,7 +671,14 @@ def build_step(model, kind, B, W, F, training):
         # norms of the averaged gradients) and only where every matrix has one writer per backward
         fuse = (cx.red is None and kind in ("joint", "align", "caption") and os.environ.get("UNIVL_FUSED_NORMS", "1") != "0")
         gs = GradState(fl, fresh, fuse_sumsq=fuse)
-        hook, buckets, sched = _ddp_hook(cx, fl, model)
+        hook, buckets, sched = _ddp_hook(cx, fl, model, kind)
+        # A layer reports its gradient slice to the exchange schedule only after its LAST writer in this backward: the
+        # cross stack runs up to three times (pair similarity, decoder rows, pretrain heads) and the text / video stacks
+        # twice on the pretrain path (masked pass, clean pass), every pass accumulating into the same slice.  An
+        # all-reduce issued after an earlier pass would race with the later read-modify-write weight gradients.
+        cross_runs = [r for r in (st.run_pairs, st.run_rows, st.run_heads) if r is not None]     # emission order below
+        last_cross = cross_runs[-1] if cross_runs else None
+        hook_for = lambda r: hook if r is last_cross else None
         if fuse:
             bwd.add_callable(fl.sumsq.zero_)
             bwd.add_callable(fl.partials.zero_)
@@ -682,17 +695,17 @@ def build_step(model, kind, B, W, F, training):
         g = st.gout
         if st.pooler is not None:
             st.pooler.build_backward(bwd, gs, g)
-            st.run_pairs.build_backward(bwd, gs, hook)
+            st.run_pairs.build_backward(bwd, gs, hook_for(st.run_pairs))
         if st.decoder is not None:
             st.decoder.build_backward(bwd, gs, g)
-            st.run_rows.build_backward(bwd, gs, hook)
+            st.run_rows.build_backward(bwd, gs, hook_for(st.run_rows))
         if st.heads is not None:
             st.heads.build_backward(bwd, gs, g)
-            st.run_heads.build_backward(bwd, gs, hook)
+            st.run_heads.build_backward(bwd, gs, hook_for(st.run_heads))
         if st.joint is not None:
             st.joint.build_backward(bwd, g)
         if st.enc_m is not None:
-            st.enc_m.build_backward(bwd, gs, hook)
+            st.enc_m.build_backward(bwd, gs, None)          # the clean pass below is the last writer of bert.* / visual.*
         enc.build_backward(bwd, gs, hook)
         if cx.red is not None:
             red, tail = cx.red, buckets["tail"]
