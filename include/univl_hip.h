@@ -300,6 +300,12 @@ typedef struct UnivlAdam {
     int32_t schedule;            /* 0 warmup_linear, 1 warmup_cosine, 2 warmup_constant (optimization.py:26-50) */
 } UnivlAdam;
 int univl_bert_adam(const UnivlAdam* d, hipStream_t stream);
+/* The same update over chunks [chunk_begin, chunk_begin + chunk_count) of the chunk table only; do_prep != 0 first runs the
+ * per-tensor scalar kernel (once per step, before the first range).  max_blocks > 0 caps the grid (the kernel then walks
+ * the range), which leaves compute units to kernels running concurrently on other streams: the pipelined training step
+ * applies the update layer by layer next to the following forward pass (univl_amd/graphed.py). */
+int univl_bert_adam_range(const UnivlAdam* d, int32_t chunk_begin, int32_t chunk_count, int32_t do_prep, int32_t max_blocks,
+                          hipStream_t stream);
 /* *ctr += 1 (device word; used for per-replay dropout seeds) */
 int univl_bump_counter(uint64_t* ctr, hipStream_t stream);
 /* p16 <- bf16(p) over n elements */

@@ -89,6 +89,7 @@ def _worker(rank, world, port, mode, q):
         for it in range(STEPS):
             losses.append(float(gs(*args, **kw)))
         assert gs.mode == "segmented"
+        gs.flush()                                  # the pipelined BertAdam update of the last iteration
     final = {n: model.flat.w32(n).detach().float().cpu().clone() for n in names}
     torch.cuda.synchronize()
     as_np = lambda d: None if d is None else {k: v.numpy() for k, v in d.items()}     # by value, not via shared memory
@@ -135,3 +136,130 @@ def test_stock_ddp_wrapper_and_graphed_data_parallel_two_ranks():
     for n in f0:
         assert float((gf0[n] - f0[n]).abs().max()) < 5e-5, n
         assert torch.allclose(gf0[n], gf1[n], rtol=0, atol=1e-6), n
+
+
+# ------------------------------------------------------------------------------------------------ RCCL on one GPU
+def _worker_nccl(port, q):
+    """World-size-1 process group on backend "nccl" (= RCCL): the reducer is forced active, so ReduceOp.AVG,
+    all_gather_into_tensor, the thread-local capture mode and the segmented hipGraphs run against the real library --
+    the branch `bench.py --gpus N` takes (main_task_retrieval.py:23,197-198)."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        from univl_amd import BertAdam, clip_grad_norm_
+        from univl_amd.graphed import GraphedTrainStep
+        out = {}
+
+        def train(dp, graphed):
+            model, args, kw = _model_and_batch(0, ROWS)
+            if dp:
+                model.enable_data_parallel(force=True)
+                assert model._reducer is not None and model._reducer._avg and model._reducer.world == 1
+            opt = BertAdam(model.parameters(), lr=1e-4, warmup=-1, t_total=-1, weight_decay=0.01, max_grad_norm=1.0)
+            losses = []
+            if graphed:
+                gs = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=1)
+                for _ in range(STEPS + 1):
+                    losses.append(float(gs(*args, **kw)))
+                gs.flush()
+                mode = gs.mode
+            else:
+                for _ in range(STEPS + 1):
+                    loss = model(*args, **kw)
+                    loss.backward()
+                    clip_grad_norm_(model.parameters(), 1.0)
+                    opt.step()
+                    opt.zero_grad()
+                    losses.append(float(loss))
+                mode = "eager"
+            red = model._reducer
+            names = _probe_names(model)
+            final = {n: model.flat.w32(n).detach().float().cpu().numpy().copy() for n in names}
+            return dict(losses=losses, final=final, mode=mode, calls=0 if red is None else red.calls,
+                        bytes=0 if red is None else red.bytes_reduced)
+
+        out["ref"] = train(False, False)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        out["backend"] = dist.get_backend()
+        out["eager"] = train(True, False)
+        out["graph"] = train(True, True)
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        q.put(("ok", out))
+    except Exception as ex:      # noqa: BLE001
+        import traceback
+        q.put(("error", "%s: %s\n%s" % (type(ex).__name__, ex, traceback.format_exc())))
+
+
+def test_reducer_on_rccl_world_size_one():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_nccl, args=(_free_port(), q))
+    p.start()
+    status, out = q.get(timeout=900)
+    p.join(timeout=120)
+    assert status == "ok", out
+    assert out["backend"] == "nccl"
+    ref = out["ref"]
+    for kind in ("eager", "graph"):
+        r = out[kind]
+        assert r["calls"] > 0 and r["bytes"] > 0, kind                 # collectives really went through RCCL
+        assert max(abs(a - b) for a, b in zip(r["losses"], ref["losses"])) < 2e-4, (kind, r["losses"], ref["losses"])
+        for n in ref["final"]:
+            assert float(abs(r["final"][n] - ref["final"][n]).max()) < 5e-5, (kind, n)
+    assert out["graph"]["mode"] == "segmented"
+
+
+def _worker_cabi(q):
+    """univl_allreduce_bucket (include/univl_hip.h) with a communicator the HOST created through RCCL's C API."""
+    try:
+        import ctypes as C
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        _setup_path()
+        from univl_amd import _lib
+        cands = [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so.1", "librccl.so.1"]
+        for c in cands:
+            try:
+                C.CDLL(c, mode=C.RTLD_GLOBAL)
+                break
+            except OSError:
+                continue
+        G = C.CDLL(None)                      # the process-global namespace: what dlsym(RTLD_DEFAULT) inside the library sees
+
+        class Uid(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        uid, comm = Uid(), C.c_void_p()
+        G.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+        assert G.ncclGetUniqueId(C.byref(uid)) == 0
+        assert G.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+        L = _lib.lib()
+        assert L.univl_init(0) == 0
+        x = torch.arange(1 << 20, device="cuda", dtype=torch.float32)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        for avg in (0, 1):
+            _lib.check(L.univl_allreduce_bucket(x.data_ptr(), x.numel(), _lib.DT_F32, avg, comm, C.c_void_p(side.cuda_stream)), "allreduce")
+        side.synchronize()
+        ok = bool(torch.equal(x.cpu(), torch.arange(1 << 20, dtype=torch.float32)))
+        G.ncclCommDestroy.argtypes = [C.c_void_p]
+        G.ncclCommDestroy(comm)
+        L.univl_destroy()
+        q.put(("ok", ok))
+    except Exception as ex:      # noqa: BLE001
+        import traceback
+        q.put(("error", "%s: %s\n%s" % (type(ex).__name__, ex, traceback.format_exc())))
+
+
+def test_allreduce_bucket_c_abi_with_host_owned_rccl_communicator():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_cabi, args=(q,))
+    p.start()
+    status, out = q.get(timeout=600)
+    p.join(timeout=60)
+    assert status == "ok", out
+    assert out is True

@@ -316,7 +316,8 @@ def test_dropout_training_runs_and_is_seeded():
 
 def _train(kind, case, steps=5, lr=1e-5):
     """`steps` optimizer steps on one fixed batch; returns the per-step losses, sampled final parameters and
-    bookkeeping of the gradient exchange.  kind: eager | graph | loopback_eager | loopback_graph."""
+    bookkeeping of the gradient exchange.  kind: eager | graph | graph_nopipe | loopback_eager | loopback_graph
+    (graph / loopback_graph: BertAdam pipelined with the next forward, univl_amd.graphed)."""
     from univl_amd.graphed import GraphedTrainStep
     cfg, rows, dseed = case_config(case)
     model, P = build(cfg, torch.float32)
@@ -332,11 +333,16 @@ def _train(kind, case, steps=5, lr=1e-5):
         kw.update(input_caption_ids=b["input_caption_ids"], decoder_mask=b["decoder_mask"],
                   output_caption_ids=b["output_caption_ids"])
     losses = []
-    if kind.endswith("graph"):
-        gs = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=1)
+    if "graph" in kind:
+        gs = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=1, pipeline_optimizer=not kind.endswith("nopipe"))
         for _ in range(steps):
             losses.append(float(gs(*args, **kw)))
         mode = gs.mode
+        assert gs.pipeline == (not kind.endswith("nopipe"))
+        if gs.pipeline:
+            assert opt.has_pending                 # the last update still rides with a forward that never came
+            gs.flush()
+            assert not opt.has_pending
     else:
         for _ in range(steps):
             loss = model(*args, **kw)
@@ -358,33 +364,37 @@ def _train(kind, case, steps=5, lr=1e-5):
     return losses, final, info
 
 
-@pytest.mark.parametrize("case", ["joint_full", "align_small"])
+@pytest.mark.parametrize("case", ["joint_full", "align_small", "caption_small", "pretrain_small"])
 def test_graphed_and_data_parallel_schedules_match_eager(case):
     """The hipGraph replays (whole-step graph; captured segments around host-issued gradient exchange points) and the
     data-parallel bucket schedule compute what the eager single-GPU loop computes.  Loopback reducer: identity
     exchanges with the RCCL path's stream/event choreography (univl_amd.parallel.BucketReducer)."""
     ref_l, ref_p, _ = _train("eager", case)
-    for kind in ("graph", "loopback_eager", "loopback_graph"):
+    sparse_word = case in ("joint_full", "align_small")     # the token gather is the word table's only gradient source
+    for kind in ("graph", "graph_nopipe", "loopback_eager", "loopback_graph"):
         l, p, info = _train(kind, case)
         # fp32 atomics (split-K, bias / LayerNorm gradients) make runs differ in the last bits only
         np.testing.assert_allclose(l, ref_l, rtol=2e-4, atol=2e-5, err_msg=kind)
         for n in ref_p:
             assert max_abs(p[n], ref_p[n]) < 2e-5, (kind, n)
-        if kind == "graph":
+        if kind in ("graph", "graph_nopipe"):
             assert info["mode"] == "whole"
         else:
             # every used gradient element is exchanged exactly once per step, in few large pieces
             per_step = info["bytes"] / 5
             covered = sum(e - s for cut in info["points"] for s, e in cut)
             # dense slices + the word-embedding gradient as (ids, rows) of the batch's tokens instead of 94 MB
-            assert info["sparse"] is not None and info["sparse"]["bytes"] < 4e6
-            assert per_step == covered * 4 + info["sparse"]["bytes"]
+            if sparse_word:
+                assert info["sparse"] is not None and info["sparse"]["bytes"] < 4e6
+                assert per_step == covered * 4 + info["sparse"]["bytes"]
+            else:                                    # tied decoder / MLM head: the table is exchanged densely
+                assert info["sparse"] is None and per_step == covered * 4
             flat_ranges = sorted(r for cut in info["points"] for r in cut)
             assert all(a[1] <= b[0] for a, b in zip(flat_ranges, flat_ranges[1:]))          # no overlap
             assert 1 <= len(info["points"]) <= 10
         if kind == "loopback_graph":
             assert info["mode"] == "segmented"
-            assert info["nseg"].count("eager") == len(info["points"]) + 2                  # exchanges + token gather + join
+            assert info["nseg"].count("eager") == len(info["points"]) + (2 if sparse_word else 1)   # exchanges (+ token gather) + join
             assert info["nseg"].count("graph") >= len(info["points"])
 
 
@@ -414,3 +424,109 @@ def test_unchanged_training_loop_switches_to_graph_replay():
     assert [s[0] for s in st.fwd._segments] == ["graph"]
     assert st_e.fwd._segments is None
     np.testing.assert_allclose(l_graph, l_eager, rtol=2e-4, atol=2e-5)
+
+
+def test_bert_adam_checkpoint_resume_and_state_dict_layout(tmp_path):
+    """optimizer.state_dict() -> torch.save -> load_state_dict on a fresh optimizer (main_pretrain.py:266-273, 389): the
+    resumed run continues exactly like the uninterrupted one (moments, per-parameter step counters, warmup schedule)."""
+    cfg, rows, dseed = case_config("joint_small")
+    batch = O.synthetic_batch(cfg, rows, seed=dseed)
+
+    def make():
+        model, _ = build(cfg, torch.float32)
+        model.train()
+        opt = BertAdam(model.parameters(), lr=1e-3, warmup=0.5, t_total=8, schedule="warmup_linear", weight_decay=0.01, max_grad_norm=1.0)
+        return model, opt
+
+    def one(model, opt):
+        loss = call(model, batch)
+        loss.backward()
+        clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad()
+        return float(loss)
+
+    m1, o1 = make()
+    cont = [one(m1, o1) for _ in range(5)]
+    m2, o2 = make()
+    first = [one(m2, o2) for _ in range(3)]
+    assert first == pytest.approx(cont[:3], rel=1e-5, abs=1e-6)
+    osd, msd = o2.state_dict(), m2.state_dict()
+    st0 = osd["state"][0]
+    assert set(st0) == {"step", "next_m", "next_v"} and st0["step"] == 3          # the reference's keys (optimization.py:124-129)
+    p0 = next(iter(m2.parameters()))
+    assert tuple(st0["next_m"].shape) == tuple(p0.shape)
+    torch.save(dict(opt=osd, model=msd), os.path.join(tmp_path, "ck.bin"))
+    ck = torch.load(os.path.join(tmp_path, "ck.bin"), map_location="cpu")
+    m3, o3 = make()
+    one(m3, o3)                                   # an optimizer that already owns flat moment buffers
+    m3.load_state_dict(ck["model"])
+    o3.load_state_dict(ck["opt"])
+    resumed = [one(m3, o3) for _ in range(2)]
+    assert resumed == pytest.approx(cont[3:], rel=2e-4, abs=2e-5), (resumed, cont)
+    assert o3.state_dict()["state"][0]["step"] == 5 and sorted(set(o3.get_lr())) == sorted(set(o1.get_lr()))
+    # loading before the first step (no flat buffers yet): the loaded tensors are migrated at the first step
+    m4, o4 = make()
+    m4.load_state_dict(ck["model"])
+    o4.load_state_dict(ck["opt"])
+    assert one(m4, o4) == pytest.approx(cont[3], rel=2e-4, abs=2e-5)
+
+
+@pytest.mark.parametrize("schedule", ["warmup_cosine", "warmup_constant", "warmup_linear"])
+def test_warmup_schedules_on_device(schedule):
+    """optimization.py:26-50: the per-step learning rate factor the update kernel computes equals the reference's
+    schedule function (its cosine form written with math.cos; the reference's torch.cos(float) cannot run)."""
+    from univl_amd.optimization import SCHEDULES
+    cfg, rows, dseed = case_config("joint_small")
+    model, _ = build(cfg, torch.float32)
+    model.train()
+    batch = O.synthetic_batch(cfg, rows, seed=dseed)
+    lr, T, wu = 1e-2, 6, 0.34
+    opt = BertAdam(model.parameters(), lr=lr, warmup=wu, t_total=T, schedule=schedule, weight_decay=0.0, max_grad_norm=-1)
+    n = "visual.encoder.layer.0.intermediate.dense.weight"
+    p = dict(model.named_parameters())[n]
+    for k in range(5):
+        call(model, batch).backward()
+        before = p.detach().clone()
+        g = p.grad.detach().clone()
+        st = opt.state.get(p, {})
+        m = st["next_m"].clone() if st else torch.zeros_like(p)
+        v = st["next_v"].clone() if st else torch.zeros_like(p)
+        opt.step()
+        opt.zero_grad()
+        m = 0.9 * m + 0.1 * g
+        v = 0.999 * v + 0.001 * g * g
+        want = before - lr * SCHEDULES[schedule](k / T, wu) * (m / (v.sqrt() + 1e-6))
+        assert max_abs(p, want) < 1e-6 + 1e-4 * float((want - before).abs().max()), (schedule, k)
+    assert opt.get_lr()[0] == pytest.approx(lr * SCHEDULES[schedule](5 / T, wu))
+
+
+def test_shaped_true_and_pretrain_without_captions():
+    """get_sequence_visual_output(shaped=True) (modeling.py:299-313: inputs already flattened, video already normalised)
+    and forward() on the pretrain path without captions (modeling.py:238: the decoder loss is skipped)."""
+    cfg, rows, dseed = case_config("pretrain_small")
+    model, P = build(cfg, torch.float32)
+    batch = O.synthetic_batch(cfg, rows, seed=dseed)
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    model.eval()
+    with torch.no_grad():
+        seq, vis = model.get_sequence_visual_output(b["input_ids"], b["token_type_ids"], b["attention_mask"], b["video"], b["video_mask"])
+        flat = lambda t: t.view(-1, t.shape[-1])
+        vnorm = O.normalize_video(batch["video"], P).to(DEV)           # modeling.py:88-92 on the CPU oracle
+        seq2, vis2 = model.get_sequence_visual_output(flat(b["input_ids"]), flat(b["token_type_ids"]), flat(b["attention_mask"]),
+                                                      vnorm.view(-1, cfg.max_frames, cfg.video_dim), flat(b["video_mask"]), shaped=True)
+    assert max_abs(seq, seq2) < 1e-4 and max_abs(vis, vis2) < 1e-4
+    model.train()
+    full = call(model, batch)
+    st = model._steps[("pretrain", rows * cfg.n_pair, cfg.max_words, cfg.max_frames, True)]
+    dec = float(st.decoder.loss)
+    full = float(full)
+    model.zero_grad(set_to_none=True)
+    nocap = model(b["input_ids"], b["token_type_ids"], b["attention_mask"], b["video"], b["video_mask"],
+                  pairs_masked_text=b["pairs_masked_text"], pairs_token_labels=b["pairs_token_labels"],
+                  masked_video=b["masked_video"], video_labels_index=b["video_labels_index"])
+    nocap.backward()
+    assert abs(float(nocap) - (full - dec)) < 1e-3 * max(1.0, abs(full))
+    params = dict(model.named_parameters())
+    assert all(p.grad is None for n, p in params.items() if n.startswith("decoder."))
+    assert params["cls.predictions.transform.dense.weight"].grad is not None

@@ -117,6 +117,7 @@ def lib():
     L.univl_clip_coef.argtypes = [vp, vp, i32, f32, vp, vp]
     L.univl_scale_grads.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
     L.univl_cast_bf16.argtypes = [vp, vp, i64, vp]
+    L.univl_bert_adam_range.argtypes = [vp, i32, i32, i32, i32, vp]
     L.univl_bump_counter.argtypes = [vp, vp]
     L.univl_probe_layouts.argtypes = [vp, i32, vp]
     L.univl_device_info.argtypes = [C.POINTER(i32), C.c_char_p, i32]
@@ -132,7 +133,7 @@ EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_dev
             "univl_embed_text_fwd", "univl_embed_text_bwd", "univl_embed_scatter", "univl_pool_fwd", "univl_pool_bwd",
             "univl_maxmargin_loss", "univl_crossen_loss", "univl_milnce_loss", "univl_rank_counts", "univl_gather_rows", "univl_log_softmax_rows", "univl_scale_by_device_scalar", "univl_pair_concat_fwd", "univl_pair_concat_bwd", "univl_postype_fwd", "univl_postype_bwd", "univl_tanh_fwd",
             "univl_tanh_bwd", "univl_gelu_bwd", "univl_colsum", "univl_scale_ct_by_device_scalar", "univl_simdense_fwd", "univl_simdense_bwd", "univl_ce_loss", "univl_mfm_nce_loss", "univl_grad_sumsq", "univl_sumsq_finish",
-            "univl_clip_coef", "univl_scale_grads", "univl_bert_adam", "univl_cast_bf16", "univl_bump_counter", "univl_probe_layouts"]
+            "univl_clip_coef", "univl_scale_grads", "univl_bert_adam", "univl_bert_adam_range", "univl_cast_bf16", "univl_bump_counter", "univl_probe_layouts"]
 
 
 def check(rc, what=""):

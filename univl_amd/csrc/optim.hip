@@ -108,10 +108,13 @@ __global__ void adam_prep_kernel(UnivlAdam a) {
     a.step[s] = st + 1;
 }
 
-__global__ __launch_bounds__(256) void adam_apply_kernel(UnivlAdam a) {
-    const int c = blockIdx.x, seg = a.chunk_seg[c];
+// chunks [c0, c1) of the chunk table; a grid smaller than the range walks it with stride gridDim.x (a throttled launch
+// that leaves CUs to concurrently running kernels: the pipelined step overlaps this update with the next forward)
+__global__ __launch_bounds__(256) void adam_apply_kernel(UnivlAdam a, int c0, int c1) {
+  for (int c = c0 + blockIdx.x; c < c1; c += gridDim.x) {
+    const int seg = a.chunk_seg[c];
     const UnivlSeg sg = a.segs[seg];
-    if (!sg.active) return;
+    if (!sg.active) continue;
     const float gs = a.seg_scalars[2 * seg], lr = a.seg_scalars[2 * seg + 1], wd = sg.weight_decay;
     const float b1 = a.b1, b2 = a.b2, eps = a.eps;
     const int64_t off = a.chunk_off[c];
@@ -162,6 +165,7 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(UnivlAdam a) {
         p[i] = pi; m[i] = mi; v[i] = vi;
         if (p16) p16[i] = (__bf16)pi;
     }
+  }
 }
 
 __global__ __launch_bounds__(256) void cast_kernel(const float* p, __bf16* o, int64_t n) {
@@ -233,7 +237,24 @@ extern "C" int univl_bert_adam(const UnivlAdam* d, hipStream_t stream) {
                         d->sumsq && d->step && d->seg_scalars && d->nseg > 0 && d->nchunk > 0,
                     UNIVL_EINVAL, "univl_bert_adam: bad argument");
     hipLaunchKernelGGL(adam_prep_kernel, dim3((d->nseg + 255) / 256), dim3(256), 0, stream, *d);
-    hipLaunchKernelGGL(adam_apply_kernel, dim3(d->nchunk), dim3(256), 0, stream, *d);
+    hipLaunchKernelGGL(adam_apply_kernel, dim3(d->nchunk), dim3(256), 0, stream, *d, 0, d->nchunk);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+extern "C" int univl_bert_adam_range(const UnivlAdam* d, int32_t chunk_begin, int32_t chunk_count, int32_t do_prep,
+                                     int32_t max_blocks, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    UNIVL_CHECK_ARG(d && d->p && d->g && d->m && d->v && d->segs && d->chunk_seg && d->chunk_off && d->chunk_len &&
+                        d->sumsq && d->step && d->seg_scalars && d->nseg > 0 && d->nchunk > 0,
+                    UNIVL_EINVAL, "univl_bert_adam_range: bad argument");
+    UNIVL_CHECK_ARG(chunk_begin >= 0 && chunk_count >= 0 && chunk_begin + chunk_count <= d->nchunk, UNIVL_EINVAL,
+                    "univl_bert_adam_range: chunks [%d, +%d) of %d", chunk_begin, chunk_count, d->nchunk);
+    if (do_prep) hipLaunchKernelGGL(adam_prep_kernel, dim3((d->nseg + 255) / 256), dim3(256), 0, stream, *d);
+    if (chunk_count > 0) {
+        const int grid = (max_blocks > 0 && max_blocks < chunk_count) ? max_blocks : chunk_count;
+        hipLaunchKernelGGL(adam_apply_kernel, dim3(grid), dim3(256), 0, stream, *d, chunk_begin, chunk_begin + chunk_count);
+    }
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }

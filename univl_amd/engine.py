@@ -194,12 +194,15 @@ class Plan:
     def __init__(self):
         self.ops = []
         self.keep = []
+        self.descs = {}              # op index -> the C descriptors of that launch (measurement / introspection)
+        self.external = {}           # key -> event recorded by somebody else (see wait_point)
         self._side = {}
         self._segments = None
 
     def add(self, fn_name, desc, stream=0):
         fn = getattr(_lib.lib(), fn_name)
         self.keep.append(desc)
+        self.descs[len(self.ops)] = [desc]
         self.ops.append(("call", fn, C.byref(desc), fn_name, stream))
 
     def add_gemm_group(self, descs, stream=0):
@@ -213,6 +216,7 @@ class Plan:
             chunk = descs[i:i + _lib.GEMM_GROUP_MAX]
             arr = (_lib.Gemm * len(chunk))(*chunk)
             self.keep.append(arr)
+            self.descs[len(self.ops)] = list(chunk)
             self.ops.append(("group", fn, (arr, len(chunk)), "univl_gemm_group", stream))
 
     def add_callable(self, f, stream=0, eager=False):
@@ -220,6 +224,13 @@ class Plan:
         treats it like any callable, run_graphed() replays the captured kernels on either side of it and calls it
         in between, on the calling stream."""
         self.ops.append(("eager" if eager else "py", f, None, getattr(f, "__name__", "callable"), stream))
+
+    def wait_point(self, key, stream=0):
+        """If an event is registered under `key` in self.external when the plan runs, `stream` waits for it; otherwise a
+        no-op.  The pipelined training step (univl_amd.graphed) applies the previous step's BertAdam update layer by layer
+        on its own stream and registers one event per layer; the forward plan waits for a layer's parameters only where it
+        first reads them."""
+        self.ops.append(("wait", key, None, "wait", stream))
 
     def fork(self, src, dst):
         """dst waits for all work enqueued on src so far."""
@@ -256,6 +267,10 @@ class Plan:
                 rc = a(b[0], b[1], h)
                 if rc != 0:
                     _lib.check(rc, name)
+            elif kind == "wait":
+                ev = self.external.get(a) if self.external else None
+                if ev is not None:
+                    self._stream(sidx, cur).wait_event(ev)
             elif kind == "eager":
                 for sd in self._side.values():             # host-driven exchange point: everything planned so far
                     if sd.device == cur.device:
@@ -320,6 +335,18 @@ class Plan:
                         cur.wait_stream(sd)
                 seg[2] = g
             seg[2].replay()
+
+    def launches(self, prefix):
+        """[(launch(stream_handle), [descriptors])] for every planned launch whose entry point starts with `prefix`, in plan
+        order -- bench.py replays one kernel family alone to time it with HIP events."""
+        out = []
+        for i, op in enumerate(self.ops):
+            kind, fn, arg, name, _ = op
+            if kind == "call" and name.startswith(prefix):
+                out.append((lambda h, fn=fn, arg=arg: fn(arg, h), self.descs[i]))
+            elif kind == "group" and name.startswith(prefix):
+                out.append((lambda h, fn=fn, arg=arg: fn(arg[0], arg[1], h), self.descs[i]))
+        return out
 
     @property
     def calls(self):
@@ -448,6 +475,7 @@ class EncoderStack:
             plan.add_callable(self.yarena.zero_, stream=sm)
         for l, ws in enumerate(self.layers):
             nm = self._names(l)
+            plan.wait_point(("layer", self.prefix, l), sm)
             wqkv, bqkv = fl.wop_fused(nm["qkv_w"]), fl.w32_fused(nm["qkv_b"])
             plan.add("univl_gemm", _gemm_desc(dt, x16, H, wqkv, H, T, 3 * H, H, out16=ws["qkv"], ldc=3 * H, bias=bqkv), sm)
             qkv = ws["qkv"]
@@ -597,6 +625,7 @@ class DecoderStack:
         for l, ws in enumerate(self.layers):
             nm = self._names(l)
             off = ws["off"]
+            plan.wait_point(("layer", "decoder", l), sm)
             plan.add("univl_gemm", _gemm_desc(dt, x16, H, fl.wop_fused(nm["s_qkv_w"]), H, Tq, 3 * H, H, out16=ws["qkv"], ldc=3 * H,
                                               bias=fl.w32_fused(nm["s_qkv_b"])), sm)
             qkv = ws["qkv"]

@@ -10,9 +10,23 @@ bottleneck (~10 us per ctypes call).  `GraphedTrainStep` captures the iteration 
     the all-reduces issued from the host between the replays (they run on RCCL's own stream and overlap the
     following segments), and clip + BertAdam are a last graph that is replayed after the reducer's join.
 
+Pipelined optimizer (pipeline_optimizer=True, the default).  At small per-GPU batch the forward/backward is a chain of
+short latency-bound kernels that leaves most of the HBM bandwidth idle, while the BertAdam update is one long HBM-bound
+stream (30 B per parameter) that needs nothing but bandwidth.  The global clip (main_task_retrieval.py:347) needs every
+gradient before any parameter may change, so the update cannot move INTO its own backward -- but it can ride next to the
+FOLLOWING forward: a replay applies the update of the previous iteration layer by layer on a second stream (embedding
+tables and vectors first, then the layers in the order the forward reads them, univl_bert_adam_range) while the forward
+runs, each layer's first kernel waiting only for that layer's parameters (engine.Plan.wait_point); backward, gradient
+exchange and the clip measurement follow as before.  Every iteration still performs exactly one forward, one backward
+and one BertAdam update, in the same arithmetic order: losses and parameters are the same as without pipelining
+(tests/test_model_gpu.py).  Between calls the parameters lag by the one pending update; `flush()` -- called
+automatically by state_dict(), eval(), the evaluation entry points and optimizer.state_dict() -- applies it.
+
 The first `warmup` calls run eagerly (they build the execution plans and the optimizer tables); the next call
 captures and runs; later calls only copy the new batch into the static input buffers and replay.
 """
+import os
+
 import torch
 
 from .optimization import clip_grad_norm_
@@ -20,52 +34,96 @@ from .steps import stage_input
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, max_grad_norm=1.0, warmup=3, persistent_inputs=False):
-        """persistent_inputs=True: the caller passes the SAME tensors every time and refills them in place (no
-        per-step copy into private static buffers)."""
+    def __init__(self, model, optimizer, max_grad_norm=1.0, warmup=3, persistent_inputs=True, pipeline_optimizer=True):
+        """persistent_inputs=True: the tensors of the first captured call ARE the static input buffers when they live on
+        the model's device (later calls may pass the same tensors refilled in place -- no copy -- or other tensors, e.g.
+        the loader's host batch, which are copied in)."""
         self.model, self.opt = model, optimizer
         self.max_grad_norm = max_grad_norm
         self.warmup = int(warmup)
         self.persistent = bool(persistent_inputs)
+        self.pipeline = bool(pipeline_optimizer) and os.environ.get("UNIVL_PIPELINE_OPT", "1") != "0"
+        self.adam_blocks = int(os.environ.get("UNIVL_ADAM_BLOCKS", "0"))      # grid cap of the overlapped update (0: none)
         self.params = [p for p in model.parameters()]
         self.calls = 0
         self.mode = None                 # None (not captured) | "whole" | "segmented"
         self._static_args, self._static_kw = None, None
         self._g_all = self._g_fwd = self._g_opt = None
+        self._side = None
         self.loss = None
 
     # ------------------------------------------------------------------------------------------------ pieces
-    def _clip_and_step(self):
+    def _clip_and_step(self, defer=False):
         if self.max_grad_norm is not None:
             clip_grad_norm_(self.params, self.max_grad_norm)
-        self.opt.step()
+        self.opt.step(defer=defer) if defer else self.opt.step()
 
-    def _eager(self, args, kw):
-        loss = self.model(*args, **kw)
+    def _eager(self, args, kw, defer=False):
+        self.model._in_pipelined_call = defer
+        try:
+            loss = self.model(*args, **kw)
+        finally:
+            self.model._in_pipelined_call = False
         loss.backward()
-        self._clip_and_step()
+        self._clip_and_step(defer)
+        if defer:
+            self.model._pending_update = self.opt
         self.opt.zero_grad()
         return loss
+
+    def _launch_pending_update(self):
+        """BertAdam of the PREVIOUS iteration, chunk group by chunk group on a second stream; one event per group for the
+        forward plan's wait points."""
+        cur = torch.cuda.current_stream()
+        side, events = self._side, self.model._param_events
+        events.clear()
+        side.wait_stream(cur)
+
+        def on_group(key):
+            ev = torch.cuda.Event()
+            ev.record(side)
+            events[key] = ev
+
+        with torch.cuda.stream(side):
+            groups = self.opt.chunk_groups()
+            self.opt.launch_deferred(groups=groups, on_group=on_group, max_blocks=self.adam_blocks)
+            on_group("all")
+
+    def _forward_pipelined(self, args, kw):
+        self._launch_pending_update()
+        self.model._in_pipelined_call = True
+        try:
+            return self.model(*args, **kw)
+        finally:
+            self.model._in_pipelined_call = False
+            self.model._param_events.clear()
+
+    def flush(self):
+        """Apply the pending BertAdam update of the last iteration (pipelined mode); no-op otherwise."""
+        self.opt.flush()
 
     def _stage(self, args, kw):
         """Bring the new batch into the static input buffers the graphs read from."""
         if self._static_args is None:
             dev = next(self.model.parameters()).device
-            hold = (lambda t: t) if self.persistent else (lambda t: t.to(dev, copy=True))
+            keep = lambda t: self.persistent and t.device == dev
+            hold = lambda t: t if keep(t) else t.to(dev, copy=True)
             self._static_args = [hold(a) if isinstance(a, torch.Tensor) else a for a in args]
             self._static_kw = {k: (hold(v) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
             return
         if len(args) != len(self._static_args) or set(kw) != set(self._static_kw):
             raise RuntimeError("GraphedTrainStep: the call signature changed after capture")
         pairs = list(zip(self._static_args, args)) + [(self._static_kw[k], kw[k]) for k in kw]
+        done = set()
         for st, new in pairs:
             if isinstance(st, torch.Tensor):
                 if not isinstance(new, torch.Tensor) or new.shape != st.shape or new.dtype != st.dtype:
                     raise RuntimeError("GraphedTrainStep: input shape/dtype changed after capture (%s -> %s); build a "
                                        "second GraphedTrainStep for the other batch shape" %
                                        (tuple(st.shape), tuple(getattr(new, "shape", ()))))
-                if new is not st:
-                    stage_input(st, new)           # host batches go through a pinned buffer (one async DMA)
+                if new is not st and (id(st), id(new)) not in done:
+                    done.add((id(st), id(new)))     # the same tensor passed under two names (masked_video=video) goes once
+                    stage_input(st, new)
             elif st is not new and st != new:
                 raise RuntimeError("GraphedTrainStep: a non-tensor argument changed after capture")
 
@@ -76,18 +134,31 @@ class GraphedTrainStep:
             return self._eager(args, kw)
         self._stage(args, kw)
         sa, sk = self._static_args, self._static_kw
+        if self.pipeline and self._side is None:          # created outside any capture
+            self._side = torch.cuda.Stream(device=next(self.model.parameters()).device)
+        if self.pipeline and not self.opt.has_pending:
+            # first pipelined call, or somebody flushed (evaluation, checkpoint): this iteration runs unpipelined up to its
+            # clip; its BertAdam update rides with the next forward
+            self.loss_eager = self._eager(sa, sk, defer=True)
+            return self.loss_eager
         if self.mode is None:
             torch.cuda.synchronize()
             if getattr(self.model, "_reducer", None) is None:
                 self._g_all = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._g_all):
-                    self.loss = self._eager(sa, sk)
+                    if self.pipeline:
+                        self.loss = self._forward_pipelined(sa, sk)
+                        self.loss.backward()
+                        self._clip_and_step(defer=True)
+                        self.opt.zero_grad()
+                    else:
+                        self.loss = self._eager(sa, sk)
                 self.mode = "whole"
             else:
                 self.model.graph_backward = True
                 self._g_fwd = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._g_fwd, capture_error_mode="thread_local"):
-                    self.loss = self.model(*sa, **sk)
+                    self.loss = self._forward_pipelined(sa, sk) if self.pipeline else self.model(*sa, **sk)
                 self.mode = "segmented"
         if self.mode == "whole":
             self._g_all.replay()
@@ -97,7 +168,7 @@ class GraphedTrainStep:
         if self._g_opt is None:
             self._g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_opt, capture_error_mode="thread_local"):
-                self._clip_and_step()
+                self._clip_and_step(defer=self.pipeline)
         self._g_opt.replay()
         self.opt.zero_grad()                 # host-side only: the next backward starts from beta = 0 again
         return self.loss

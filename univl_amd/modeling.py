@@ -410,6 +410,9 @@ class UniVL(UniVLPreTrainedModel):
 
         self._flat = None
         self._steps = {}
+        self._param_events = {}        # filled by a pipelined optimizer update in flight (univl_amd.graphed)
+        self._pending_update = None    # the optimizer holding a deferred update, if any
+        self._in_pipelined_call = False
         self._reducer = None
         self._dp_checked, self._implicit_dp = False, False
         self._seed_dev = None
@@ -463,6 +466,22 @@ class UniVL(UniVLPreTrainedModel):
         self._flat, self._steps = None, {}      # parameters were re-allocated (e.g. .to(device)): re-flatten lazily
         return r
 
+    def _flush_pending(self):
+        """A training step of univl_amd.graphed.GraphedTrainStep(pipeline_optimizer=True) leaves its BertAdam update to be
+        applied next to the following forward pass; everything else that reads the parameters applies it first."""
+        o = self._pending_update
+        if o is not None and not self._in_pipelined_call:
+            o.flush()
+
+    def state_dict(self, *a, **kw):
+        self._flush_pending()
+        return super().state_dict(*a, **kw)
+
+    def train(self, mode=True):
+        if not mode:
+            self._flush_pending()
+        return super().train(mode)
+
     def mark_params_dirty(self):
         """Tell the model its fp32 parameters were modified outside univl_amd.optimization.BertAdam (the bf16
         shadow the GEMMs read is refreshed before the next forward)."""
@@ -475,8 +494,10 @@ class UniVL(UniVLPreTrainedModel):
         return r
 
     def _replicate_for_data_parallel(self):
+        self._flush_pending()
         replica = super()._replicate_for_data_parallel()
         replica._flat, replica._steps, replica._reducer, replica._seed_dev = None, {}, None, None
+        replica._param_events, replica._pending_update, replica._in_pipelined_call = {}, None, False
         replica._used_names = {}
         replica._dp_checked, replica._implicit_dp, replica.graph_backward = True, False, False
         return replica
@@ -503,7 +524,7 @@ class UniVL(UniVLPreTrainedModel):
             self._steps = {}
         return self._flat
 
-    def enable_data_parallel(self, process_group=None, broadcast=True, loopback=False):
+    def enable_data_parallel(self, process_group=None, broadcast=True, loopback=False, force=False):
         """Re-homes the reference's DDP wrap (main_task_retrieval.py:197-198) onto per-layer RCCL all-reduces of
         the flat gradient buffer, overlapped with backward (univl_amd.parallel).  Call after model.to(device) and
         torch.distributed.init_process_group; with world_size 1 it is a no-op."""
@@ -512,7 +533,7 @@ class UniVL(UniVLPreTrainedModel):
         if broadcast:
             broadcast_parameters(fl.p32, 0, process_group)
             fl.shadow_valid = False
-        self._reducer = BucketReducer(fl.g32, process_group, loopback=loopback)
+        self._reducer = BucketReducer(fl.g32, process_group, loopback=loopback, force=force)
         if not self._reducer.active:
             self._reducer = None
         self._steps = {}
@@ -607,6 +628,7 @@ class UniVL(UniVLPreTrainedModel):
             raise RuntimeError("UniVL.forward: the caption path needs input_caption_ids / decoder_mask / output_caption_ids")
         if not self._dp_checked:
             self._auto_data_parallel()
+        self._flush_pending()
         fl = self.flat
         fl.refresh_shadow()
         st = self._get_step(kind, B, W, F)
@@ -630,6 +652,7 @@ class UniVL(UniVLPreTrainedModel):
         (only UniVL.forward does that in the reference); external callers use shaped=False."""
         W, F = input_ids.shape[-1], video_mask.shape[-1]
         B = input_ids.numel() // W
+        self._flush_pending()
         fl = self.flat
         fl.refresh_shadow()
         was = self.training
@@ -678,6 +701,7 @@ class UniVL(UniVLPreTrainedModel):
         from .engine import Plan
         Bt, W, _ = seq.shape
         Bv, F, _ = vis.shape
+        self._flush_pending()
         self.flat.refresh_shadow()
         out = torch.empty(Bt, Bv, device=seq.device)
         for lo in range(0, Bt, chunk_rows):
@@ -716,6 +740,7 @@ class UniVL(UniVLPreTrainedModel):
         F, Wd = visual_output.shape[1], input_caption_ids.shape[-1]
         if sequence_output.device.type != "cuda":
             raise RuntimeError("univl_amd.UniVL.decoder_caption needs HIP device tensors; no CPU fallback")
+        self._flush_pending()
         self.flat.refresh_shadow()
         key = ("caption_eval", B, W, F, Wd)
         ev = self._steps.get(key)

@@ -71,6 +71,7 @@ class _Tables:
                 c_len.append(min(CHUNK, numel - o))
         raw = bytes(segs)
         self.segs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.chunk_seg_host = c_seg
         self.chunk_seg = torch.tensor(c_seg, dtype=torch.int32, device=dev)
         self.chunk_off = torch.tensor(c_off, dtype=torch.int64, device=dev)
         self.chunk_len = torch.tensor(c_len, dtype=torch.int32, device=dev)
@@ -217,6 +218,8 @@ class BertAdam(Optimizer):
         self._fl = None
         self._tb = None
         self._m = self._v = self._step_dev = None
+        self._deferred = False          # step(defer=True) prepared an update that launch_deferred() / flush() still has to enqueue
+        self._last_desc = None
 
     def get_lr(self):
         """optimization.py:86-101 (step counters are read back from the device: under hipGraph replay the host never
@@ -299,6 +302,7 @@ class BertAdam(Optimizer):
 
     def state_dict(self):
         """Same structure as the reference optimizer's: state[i] = {step, next_m, next_v} with free-standing tensors."""
+        self.flush()
         self._sync_steps()
         sd = super().state_dict()
         for st in sd['state'].values():
@@ -330,9 +334,61 @@ class BertAdam(Optimizer):
             self._step_dev[fl.seg_of[name]] = int(st.get('step', 0))
             self._link(fl, p, name)
 
+    # --------------------------------------------------------------------------------------- deferred / layer-wise update
+    @property
+    def has_pending(self):
+        return self._deferred
+
+    def chunk_groups(self):
+        """[(key, first_chunk, n_chunks)] over the chunk table of the last step(), in the order a forward pass needs the
+        parameters: ("base") = embedding tables, every vector and the matrices outside the layer stacks (contiguous runs, so
+        possibly several entries), then ("layer", prefix, l) with the text / video stacks interleaved, the cross encoder and
+        the decoder after them."""
+        import re
+        fl, tb = self._fl, self._tb
+        runs = []
+        for c, s_ in enumerate(tb.chunk_seg_host):
+            name = fl.order[s_]
+            m = re.match(r"^(bert|visual|cross)\.encoder\.layer\.(\d+)\.", name) or re.match(r"^(decoder)\.decoder\.layer\.(\d+)\.", name)
+            key = ("layer", m.group(1), int(m.group(2))) if (m and not fl.is_atomic(name)) else "base"
+            if runs and runs[-1][0] == key and runs[-1][1] + runs[-1][2] == c:
+                runs[-1][2] += 1
+            else:
+                runs.append([key, c, 1])
+        stage = {"bert": 0, "visual": 0, "cross": 1, "decoder": 2}
+        base = [tuple(r) for r in runs if r[0] == "base"]
+        layers = sorted((tuple(r) for r in runs if r[0] != "base"), key=lambda r: (stage[r[0][1]], r[0][2], r[0][1]))
+        return base + layers
+
+    def launch_deferred(self, groups=None, on_group=None, max_blocks=0):
+        """Enqueue the update prepared by step(defer=True) on the current stream: in one launch (groups None) or one launch
+        per chunk group, calling on_group(key) after the last launch of each key."""
+        d = self._last_desc
+        if not self._deferred or d is None:
+            return
+        L, h = _lib.lib(), _stream()
+        if groups is None:
+            _lib.check(L.univl_bert_adam(C.byref(d), h), "bert_adam")
+        else:
+            for i, (key, c0, n) in enumerate(groups):
+                _lib.check(L.univl_bert_adam_range(C.byref(d), c0, n, 1 if i == 0 else 0, int(max_blocks), h), "bert_adam_range")
+                if on_group is not None and (i + 1 == len(groups) or groups[i + 1][0] != key):
+                    on_group(key)
+        self._deferred = False
+        self._fl.shadow_valid = True
+
+    def flush(self):
+        """Apply a deferred update now (checkpointing, evaluation, a forward outside the pipelined loop)."""
+        if self._deferred:
+            self.launch_deferred()
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, defer=False):
+        """defer=True prepares the update (descriptor, per-tensor scalars inputs) but leaves its launch to launch_deferred():
+        univl_amd.graphed.GraphedTrainStep overlaps it with the next forward pass."""
         loss = closure() if closure is not None else None
+        if self._deferred:
+            self.flush()
         fl = self._bind()
         pw = []
         for group in self.param_groups:
@@ -365,8 +421,11 @@ class BertAdam(Optimizer):
         d.schedule = _SCHEDULE_CODE[g0['schedule']]
         d.seg_scalars = tb.scalars.data_ptr()
         self._last_desc = d
-        _lib.check(_lib.lib().univl_bert_adam(C.byref(d), _stream()), "bert_adam")
-        fl.shadow_valid = True      # the step rewrote the bf16 shadow
+        if defer:
+            self._deferred = True
+        else:
+            _lib.check(_lib.lib().univl_bert_adam(C.byref(d), _stream()), "bert_adam")
+            fl.shadow_valid = True      # the step rewrote the bf16 shadow
         for n in cfg:
             p = fl.params[n]
             st = self.state[p]

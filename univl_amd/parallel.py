@@ -23,10 +23,13 @@ class BucketReducer:
     RCCL path (wait for the producer stream, run asynchronously, join before the optimizer) -- so that the bucket
     schedule, the exchange points and the hipGraph segmentation around them run without a second GPU."""
 
-    def __init__(self, flat_grad, process_group=None, loopback=False):
+    def __init__(self, flat_grad, process_group=None, loopback=False, force=False):
+        """force=True keeps a world-size-1 process group active: every collective of the N > 1 path is issued for real
+        (RCCL on one GPU), which is how the single-GPU box exercises the nccl branch (tests/test_ddp_gpu.py)."""
         self.g = flat_grad
         self.pg = process_group
         self.loopback = bool(loopback)
+        self.force = bool(force)
         self.world = dist.get_world_size(process_group) if (dist.is_initialized() and not loopback) else 1
         self.pending = []
         self.bytes_reduced = 0
@@ -37,7 +40,7 @@ class BucketReducer:
 
     @property
     def active(self):
-        return self.world > 1 or self.loopback
+        return self.world > 1 or self.loopback or (self.force and dist.is_initialized())
 
     def reduce_slice(self, start, end):
         """Launch the all-reduce of g[start:end]; returns immediately (the collective is stream-/thread-async)."""

@@ -560,6 +560,7 @@ class Step:
         self.calls = 0               # training forwards through this step (UniVL._run_plan: eager first, graphs later)
 
     def finish_forward(self):
+        self.fwd.wait_point("all")               # nothing after the forward may overtake an optimizer update in flight
         terms = self.loss_terms
         if len(terms) == 1:
             self.fwd.add_callable(lambda: self.loss.copy_(terms[0]))
@@ -605,6 +606,8 @@ def build_step(model, kind, B, W, F, training):
     st = Step(cx)
     st.kind, st.B, st.W, st.F = kind, B, W, F
     fwd = st.fwd
+    fwd.external = model._param_events          # events of an optimizer update still in flight (univl_amd.graphed)
+    fwd.wait_point("base")                      # embedding tables, every vector, the matrices outside the layer stacks
     if cx.p > 0:
         fwd.add_callable(lambda: ops.bump_counter(cx.seed_dev))
     st.enc = enc = EncoderPass(cx, B, W, F, normalized_input=(kind == "features_shaped"))
@@ -660,6 +663,8 @@ def build_step(model, kind, B, W, F, training):
         raise ValueError(kind)
     if st.loss_terms:
         st.finish_forward()
+    else:
+        fwd.wait_point("all")
 
     def build_bwd(fresh):
         bwd = Plan()
