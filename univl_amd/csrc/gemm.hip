@@ -166,7 +166,11 @@ template <typename T, bool TR, int ROWS, int BK> struct Tile {
     }
 };
 
-template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC>
+// BURST = 0: two LDS stages, tile t+1 streams in while tile t is multiplied (one wait + barrier per K step).
+// BURST = n: up to n stages, ALL of the workgroup's K steps are issued before the first wait and multiplied after ONE
+// barrier.  At M <= a few hundred rows the K loop is a chain of dependent DMA round trips, not MFMA work: a workgroup
+// whose whole contraction slice (<= n x BK) fits the 160 KB LDS pays one round trip instead of K / BK of them.
+template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC, int BURST = 0>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const int by, const int bz, const int nz) {
     constexpr int CH = Mma<T>::CH;
     constexpr int BK = NC * CH;          // contraction depth of one LDS stage (NC chunks of CH)
@@ -180,6 +184,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* sA = smem_raw;
     unsigned char* sB = sA + 2 * TileA::BYTES;
+    constexpr int STAGE = TileA::BYTES + TileB::BYTES;       // BURST layout: stage s = [A_s | B_s] at smem_raw + s * STAGE
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -233,6 +238,21 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         TileA::load_tail(ta, pa, stepA * nfull, p.lda, krem, tid);
         TileB::load_tail(tb, pb, stepB * nfull, p.ldb, krem, tid);
     }
+    if constexpr (BURST > 0) {
+        for (int t = 0; t < nfull; ++t) {
+            TileA::issue(pa, smem_raw + t * STAGE, tid);
+            TileB::issue(pb, smem_raw + t * STAGE + TileA::BYTES, tid);
+            TileA::advance(pa, stepA);
+            TileB::advance(pb, stepB);
+        }
+        if (krem > 0) {
+            TileA::store_tail(ta, smem_raw + nfull * STAGE, krem, tid);
+            TileB::store_tail(tb, smem_raw + nfull * STAGE + TileA::BYTES, krem, tid);
+        }
+        __syncthreads();                                     // carries the vmcnt(0) for every DMA issued above
+        const int nst = nfull + (krem > 0 ? 1 : 0);
+        for (int t = 0; t < nst; ++t) compute(smem_raw + t * STAGE, smem_raw + t * STAGE + TileA::BYTES);
+    } else {
     if (nfull > 0) {
         // double-buffered LDS-DMA pipeline: tile t+1 streams into the other stage while tile t is multiplied; the
         // __syncthreads() at the end of a step carries the vmcnt(0) that makes tile t+1 visible and releases stage t.
@@ -260,6 +280,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         TileB::store_tail(tb, cB, krem, tid);
         __syncthreads();
         compute(cA, cB);
+    }
     }
 
     // ------------------------------------------------------------------------------------------ epilogue
@@ -382,6 +403,26 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     gemm_tile<T, TA, TB, BM, BN, D, NC>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z);
+}
+
+template <typename T, bool TA, bool TB, int BM, int BN, int NC, int BURST>
+__global__ __launch_bounds__(256) void gemm_burst_kernel(GemmArgs p) {
+    gemm_tile<T, TA, TB, BM, BN, 2, NC, BURST>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z);
+}
+
+template <typename T, bool TA, bool TB, int BM, int BN, int NC, int BURST>
+int launch_burst(const GemmArgs& a, int ksplit, hipStream_t stream) {
+    constexpr int BK = NC * Mma<T>::CH;
+    using TileA = Tile<T, TA, BM, BK>;
+    using TileB = Tile<T, TB, BN, BK>;
+    const int nst = (a.ksplit_len + BK - 1) / BK;                      // stages this launch really needs (<= BURST)
+    const size_t smem = (size_t)nst * (TileA::BYTES + TileB::BYTES);
+    static bool attr_done[UNIVL_MAX_DEVICES] = {};
+    univl_allow_lds(gemm_burst_kernel<T, TA, TB, BM, BN, NC, BURST>, (size_t)BURST * (TileA::BYTES + TileB::BYTES), attr_done);
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, ksplit);
+    hipLaunchKernelGGL((gemm_burst_kernel<T, TA, TB, BM, BN, NC, BURST>), grid, dim3(256), smem, stream, a);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
 }
 
 // Up to UNIVL_GEMM_GROUP_MAX independent problems of the same operand layout in ONE launch (the four weight-gradient
@@ -539,6 +580,14 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
     if (d->dtype == UNIVL_BF16) {
         if (big) return dispatch_trans<__bf16, 128, 128, 2, 2>(a, d->trans_a, d->trans_b, ksplit, stream);
         if (nc == 6) return launch<__bf16, true, true, 64, 64, 2, 6>(a, ksplit, stream);
+        // small-M forward / dgrad products whose contraction slice (the host's split-K choice) is at most 6 x 128 deep:
+        // the whole slice in one LDS-DMA burst, half-width tiles (64x32 forward, 32x64 dgrad) so that twice as many
+        // compute units share the operand traffic (UNIVL_GEMM_BURST=0: the two-stage kernel, for A/B runs)
+        static const int burst = [] { const char* e = getenv("UNIVL_GEMM_BURST"); return e ? atoi(e) : 0; }();
+        if (burst && d->tile == 0 && !d->trans_a && a.ksplit_len <= 6 * 128 && !d->sumsq) {
+            if (!d->trans_b) return launch_burst<__bf16, false, false, 64, 32, 4, 6>(a, ksplit, stream);
+            return launch_burst<__bf16, false, true, 32, 64, 4, 6>(a, ksplit, stream);
+        }
         return dispatch_trans<__bf16, 64, 64, 2, 4>(a, d->trans_a, d->trans_b, ksplit, stream);
     }
     if (big) return dispatch_trans<float, 128, 128, 2, 2>(a, d->trans_a, d->trans_b, ksplit, stream);
