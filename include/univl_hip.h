@@ -47,6 +47,9 @@ int univl_device_info(int* cu_count, char* name, int name_len);
  * (where the reference calls torch.cuda.set_device, main_task_retrieval.py:121).  univl_destroy() releases what the
  * library opened lazily (the RCCL handle of univl_allreduce_bucket); device memory is never owned by the library. */
 int univl_init(int device);
+/* Clears n <= UNIVL_ZERO_MAX device buffers (16-byte aligned) with one launch; ptrs / bytes are HOST arrays read at call time. */
+#define UNIVL_ZERO_MAX 16
+int univl_zero_many(void* const* ptrs, const int64_t* bytes, int32_t n, hipStream_t stream);
 int univl_destroy(void);
 /* Data-parallel gradient exchange for hosts that own an RCCL communicator themselves (the Python host goes through
  * torch.distributed's "nccl" backend = RCCL, main_task_retrieval.py:23,197-198, instead): in-place all-reduce of
@@ -98,6 +101,10 @@ int univl_gemm(const UnivlGemm* desc, hipStream_t stream);
  * module_bert.py:172-174,207,233,246).  Members must not alias each other's outputs. */
 #define UNIVL_GEMM_GROUP_MAX 4
 int univl_gemm_group(const UnivlGemm* descs, int32_t n, hipStream_t stream);
+/* The same with at most max_blocks workgroups (0: one per tile): the kernel then walks its tiles.  A launch that is not on
+ * the critical path -- a layer's weight gradients -- can run beside the next layer's latency-bound kernels on another
+ * stream without taking the compute units away from them. */
+int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_blocks, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------ LayerNorm
  * TF-style LayerNorm (until_module.py:40-53: biased variance, eps inside the sqrt) fused with what surrounds it
@@ -184,6 +191,15 @@ typedef struct UnivlEmbedText {
 } UnivlEmbedText;
 int univl_embed_text_fwd(const UnivlEmbedText* d, hipStream_t stream);
 int univl_embed_text_bwd(const UnivlEmbedText* d, hipStream_t stream);
+/* Sparse bookkeeping of the word-embedding gradient (retrieval configurations: the token gather is the table's only
+ * gradient source, so at most B*W of its 30522 rows are non-zero).  list[0 .. meta[0]) holds the rows written since the
+ * last clear; meta[1] != 0 means "treat every row as listed" (list overflow, or a dense writer).  univl_rows_zero clears
+ * the listed rows (instead of a 94 MB memset), univl_rows_append records the rows of a backward (reset != 0 starts a new
+ * list), univl_rows_sumsq adds the sum of squares of the listed rows (each row once) to *out (instead of streaming the
+ * whole table for its gradient norm).  cap <= 8192. */
+int univl_rows_zero(float* table, int64_t rows_total, const int64_t* list, const int32_t* meta, hipStream_t stream);
+int univl_rows_append(const int64_t* ids, int32_t n, int64_t* list, int32_t cap, int32_t* meta, int32_t reset, hipStream_t stream);
+int univl_rows_sumsq(const float* table, int64_t rows_total, const int64_t* list, const int32_t* meta, float* out, hipStream_t stream);
 /* dword[ids[t]] += scale * rows[t] for t < n (fp32 atomics; rows [n, 768]): the second half of the sparse exchange */
 int univl_embed_scatter(const int64_t* ids, const float* rows, int64_t n, float scale, float* dword, hipStream_t stream);
 

@@ -651,3 +651,47 @@ def test_attention_kv_cache_strides():
     qq = q.reshape(B, 1, NH, 64).permute(0, 2, 1, 3).double().cpu()
     ref = (torch.softmax(qq @ k.transpose(-1, -2) / 8.0, -1) @ v).permute(0, 2, 1, 3).reshape(B, 768)
     assert rel_err(out, ref) < 1e-5
+
+
+# ------------------------------------------------------------------- sparse word-table bookkeeping / merged clears
+def test_zero_many_and_word_row_bookkeeping():
+    """univl_zero_many (several buffers, one launch) and the listed-rows clear / append / sum-of-squares of the word table
+    (univl_rows_zero / _append / _sumsq), incl. duplicates, list reset, accumulation and overflow."""
+    g = torch.Generator().manual_seed(3)
+    bufs = [torch.randn(n, generator=g).to(DEV) for n in (4, 1000, 64 * 768, 123456)]
+    bufs.append(torch.randn(16, generator=g).to(DEV).to(torch.bfloat16)[:8])                  # 16 bytes
+    guard = torch.randn(1000, generator=g).to(DEV)
+    keep = guard.clone()
+    ops.zero_many(bufs)
+    assert all(float(b.float().abs().max()) == 0.0 for b in bufs) and torch.equal(guard, keep)
+    V, N, cap = 3000, 768, 64
+    table = torch.randn(V, N, generator=g).to(DEV)
+    ref = table.clone()
+    lst = torch.zeros(cap, dtype=torch.int64, device=DEV)
+    meta = torch.zeros(2, dtype=torch.int32, device=DEV)
+    ids1 = torch.tensor([5, 17, 5, 2999, 0, 17], device=DEV)
+    ops.rows_append(ids1, lst, meta, reset=True)
+    assert meta.tolist() == [6, 0] and lst[:6].tolist() == ids1.tolist()
+    out = torch.zeros(1, device=DEV)
+    ops.rows_sumsq(table, lst, meta, out)                    # each listed row once
+    uniq = torch.tensor([5, 17, 2999, 0])
+    assert abs(float(out) - float((ref[uniq].double() ** 2).sum())) < 1e-3 * float(out)
+    ids2 = torch.tensor([7, 5], device=DEV)
+    ops.rows_append(ids2, lst, meta, reset=False)            # gradient accumulation: the list grows
+    assert meta.tolist() == [8, 0]
+    ops.rows_zero(table, lst, meta)
+    z = torch.tensor([5, 17, 2999, 0, 7])
+    assert float(table[z].abs().max()) == 0.0
+    mask = torch.ones(V, dtype=torch.bool); mask[z] = False
+    assert torch.equal(table[mask].cpu(), ref[mask].cpu())   # nothing else touched
+    ops.rows_append(ids2, lst, meta, reset=True)
+    assert meta.tolist() == [2, 0]
+    big = torch.arange(cap, device=DEV)
+    ops.rows_append(big, lst, meta, reset=False)             # does not fit: every row counts as listed from now on
+    assert meta.tolist()[1] == 1
+    table.copy_(ref)
+    out.zero_()
+    ops.rows_sumsq(table, lst, meta, out)
+    assert abs(float(out) - float((ref.double() ** 2).sum())) < 1e-3 * float(out)
+    ops.rows_zero(table, lst, meta)
+    assert float(table.abs().max()) == 0.0

@@ -30,8 +30,26 @@ ALL_CASES = JOINT_CASES + ["align_small", "caption_small", "pretrain_small"] + F
 # is written to gpurun_out/parity_errors.json (copied to profiles/ per round).
 GATES = {
     torch.float32: dict(hidden=1e-3, sim=1e-3, logits=1e-3, loss=1e-3, gnorm=1e-3, gsample=2e-3, gtop=2e-3),
-    torch.bfloat16: dict(hidden=5e-2, sim=1e-2, logits=1e-2, loss=1e-2, gnorm=1e-2, gsample=3e-2, gtop=2e-2),
+    torch.bfloat16: dict(hidden=5e-2, sim=1e-2, logits=1e-2, loss=1e-2, gnorm=1e-2, gsample=5e-2, gtop=2e-2),
 }
+# Per-tensor GRADIENT gates of the branches whose losses amplify operand rounding (measured: profiles/r02_parity_errors.json;
+# the reference under torch's own bf16 autocast, measured the same way: tests/golden/bf16_autocast_noise.json -- e.g. FT-Align
+# 48x48: worst tensor 0.57 relative, median 0.10; norms 5.8e-2).  Every gate here is within 1.5x of what the reference's own
+# bf16 run shows for that branch; outputs (sim / logits / loss) stay at 1e-2 everywhere.
+BF16_GRAD_GATES = {
+    "align": dict(gnorm=8e-2, gsample=0.6, gtop=0.25),         # all B^2 pairs through the cross encoder, margin loss on differences
+    "caption": dict(gnorm=1e-2, gsample=6e-2, gtop=4e-2),      # 30522-way softmax gradient through the tied table
+    "pretrain": dict(gnorm=2.5e-2, gsample=0.2, gtop=3e-2),    # five losses incl. the FT-Align term
+}
+
+
+def gates_for(name, dtype):
+    g = dict(GATES[dtype])
+    if dtype == torch.bfloat16:
+        g.update(BF16_GRAD_GATES.get(name.split("_")[0], {}))
+    return g
+
+
 _ERRORS = {}
 
 
@@ -98,7 +116,7 @@ def test_forward_backward_vs_reference_golden(golden_dir, name, dtype):
     model, P = build(cfg, dtype)
     batch = O.synthetic_batch(cfg, rows, seed=dseed)
     f32 = dtype == torch.float32
-    G = GATES[dtype]
+    G = gates_for(name, dtype)
     err = {}
     # ---- eval surface: get_sequence_visual_output + get_similarity_logits (main_task_retrieval.py:398, 376)
     model.eval()
@@ -493,12 +511,13 @@ def test_warmup_schedules_on_device(schedule):
         m = st["next_m"].clone() if st else torch.zeros_like(p)
         v = st["next_v"].clone() if st else torch.zeros_like(p)
         opt.step()
-        opt.zero_grad()
         m = 0.9 * m + 0.1 * g
         v = 0.999 * v + 0.001 * g * g
         want = before - lr * SCHEDULES[schedule](k / T, wu) * (m / (v.sqrt() + 1e-6))
         assert max_abs(p, want) < 1e-6 + 1e-4 * float((want - before).abs().max()), (schedule, k)
-    assert opt.get_lr()[0] == pytest.approx(lr * SCHEDULES[schedule](5 / T, wu))
+        # get_lr() reports the rate of the NEXT step for parameters that hold a gradient (optimization.py:86-101)
+        assert sorted(set(opt.get_lr()))[0] == pytest.approx(lr * SCHEDULES[schedule]((k + 1) / T, wu))
+        opt.zero_grad()
 
 
 def test_shaped_true_and_pretrain_without_captions():
@@ -530,3 +549,39 @@ def test_shaped_true_and_pretrain_without_captions():
     params = dict(model.named_parameters())
     assert all(p.grad is None for n, p in params.items() if n.startswith("decoder."))
     assert params["cls.predictions.transform.dense.weight"].grad is not None
+
+
+def test_sparse_word_table_bookkeeping_matches_dense_clear(monkeypatch):
+    """Retrieval configurations clear only the word-table rows the previous backward wrote and take the table's gradient
+    norm from those rows (engine.FlatParams.word_rows): same gradients, clip norm and parameters as the dense 94 MB clear +
+    streaming norm (UNIVL_SPARSE_ROWS=0), over changing batches, gradient accumulation and a foreign dense write."""
+    cfg, rows, dseed = case_config("joint_small")
+    batches = [O.synthetic_batch(cfg, rows, seed=dseed + k) for k in range(4)]
+    wname = "bert.embeddings.word_embeddings.weight"
+
+    def run(sparse):
+        monkeypatch.setenv("UNIVL_SPARSE_ROWS", "1" if sparse else "0")
+        model, _ = build(cfg, torch.float32)
+        model.train()
+        opt = BertAdam(model.parameters(), lr=1e-4, warmup=-1, t_total=-1, weight_decay=0.01, max_grad_norm=1.0)
+        trace = []
+        for k, b in enumerate(batches):
+            call(model, b).backward()
+            if k == 1:                                   # gradient accumulation: a second backward before the step
+                call(model, batches[0]).backward()
+            if k == 2:                                   # somebody edits the table gradient through torch
+                dict(model.named_parameters())[wname].grad[123].add_(1.0)
+            gw = dict(model.named_parameters())[wname].grad
+            total = clip_grad_norm_(model.parameters(), 1.0)
+            trace.append((float(total), float(gw.double().norm()), int((gw.abs().sum(1) > 0).sum())))
+            opt.step()
+            opt.zero_grad()
+        fl = model.flat
+        assert (getattr(fl, "_word_rows", None) is not None) == sparse
+        return trace, fl.w32(wname).detach().cpu().clone()
+
+    t1, w1 = run(True)
+    t0, w0 = run(False)
+    for a, b in zip(t1, t0):
+        assert a[0] == pytest.approx(b[0], rel=1e-5) and a[1] == pytest.approx(b[1], rel=1e-5) and a[2] == b[2], (t1, t0)
+    assert max_abs(w1, w0) < 1e-7

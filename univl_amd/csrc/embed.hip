@@ -187,6 +187,90 @@ extern "C" int univl_embed_scatter(const int64_t* ids, const float* rows, int64_
     return UNIVL_OK;
 }
 
+// ---------------------------------------------------------------------------------- sparse bookkeeping of the word table
+// In the retrieval configurations the token gather is the ONLY source of the 30522 x 768 word-embedding gradient: at most
+// B*W of its rows are non-zero.  Instead of clearing 94 MB before every backward and streaming 94 MB again for its norm,
+// the rows written by the previous backward(s) are kept in a device list:  list[0 .. meta[0])  (meta[1] != 0: the list
+// overflowed or somebody wrote the table densely -> every row is treated as listed).
+namespace {
+constexpr int ROWS_GRID = 8192;
+
+__global__ __launch_bounds__(256) void rows_zero_kernel(float* table, long rows_total, const int64_t* list, const int* meta) {
+    const int n = meta[0], over = meta[1];
+    if (!over && (int)blockIdx.x >= n) return;
+    for (long r = over ? blockIdx.x : list[blockIdx.x]; r < rows_total; r += ROWS_GRID) {
+        float4* p = reinterpret_cast<float4*>(table + r * N);
+        for (int c = threadIdx.x; c < N / 4; c += 256) p[c] = float4{0.f, 0.f, 0.f, 0.f};
+        if (!over) break;
+    }
+}
+
+__global__ __launch_bounds__(256) void rows_append_kernel(const int64_t* ids, int n, int64_t* list, int cap, int* meta, int reset) {
+    __shared__ int base, over;
+    if (threadIdx.x == 0) {
+        const int cur = reset ? 0 : meta[0];
+        int ov = reset ? 0 : meta[1];
+        if (cur + n > cap) ov = 1;
+        base = cur; over = ov;
+        meta[1] = ov;
+        meta[0] = ov ? cur : cur + n;
+    }
+    __syncthreads();
+    if (!over) for (int i = threadIdx.x; i < n; i += 256) list[base + i] = ids[i];
+}
+
+__global__ __launch_bounds__(256) void rows_sumsq_kernel(const float* table, long rows_total, const int64_t* list, const int* meta,
+                                                         float* out) {
+    __shared__ float red[4];
+    const int n = meta[0], over = meta[1];
+    if (!over && (int)blockIdx.x >= n) return;
+    float acc = 0.f;
+    if (over) {
+        for (long r = blockIdx.x; r < rows_total; r += ROWS_GRID) {
+            const float4* p = reinterpret_cast<const float4*>(table + r * N);
+            for (int c = threadIdx.x; c < N / 4; c += 256) { const float4 v = p[c]; acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
+        }
+    } else {
+        const int64_t r = list[blockIdx.x];
+        int dup = 0;                                   // a row listed twice is counted by its first occurrence only
+        for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) dup |= (list[j] == r) ? 1 : 0;
+        if (__syncthreads_or(dup)) return;
+        const float4* p = reinterpret_cast<const float4*>(table + r * N);
+        for (int c = threadIdx.x; c < N / 4; c += 256) { const float4 v = p[c]; acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+}  // namespace
+
+extern "C" int univl_rows_zero(float* table, int64_t rows_total, const int64_t* list, const int32_t* meta, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    UNIVL_CHECK_ARG(table && list && meta && rows_total > 0 && aligned16(table), UNIVL_EINVAL, "univl_rows_zero: bad argument");
+    hipLaunchKernelGGL(rows_zero_kernel, dim3(ROWS_GRID), dim3(256), 0, stream, table, (long)rows_total, list, meta);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+extern "C" int univl_rows_append(const int64_t* ids, int32_t n, int64_t* list, int32_t cap, int32_t* meta, int32_t reset,
+                                 hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    UNIVL_CHECK_ARG(ids && list && meta && n > 0 && cap > 0 && cap <= ROWS_GRID, UNIVL_EINVAL, "univl_rows_append: bad argument (cap <= %d)", ROWS_GRID);
+    hipLaunchKernelGGL(rows_append_kernel, dim3(1), dim3(256), 0, stream, ids, n, list, cap, meta, reset);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+extern "C" int univl_rows_sumsq(const float* table, int64_t rows_total, const int64_t* list, const int32_t* meta, float* out,
+                                hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    UNIVL_CHECK_ARG(table && list && meta && out && rows_total > 0 && aligned16(table), UNIVL_EINVAL, "univl_rows_sumsq: bad argument");
+    hipLaunchKernelGGL(rows_sumsq_kernel, dim3(ROWS_GRID), dim3(256), 0, stream, table, (long)rows_total, list, meta, out);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
 extern "C" int univl_embed_text_bwd(const UnivlEmbedText* d, hipStream_t stream) {
     UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(d != nullptr, UNIVL_EINVAL, "univl_embed_text_bwd: null descriptor");

@@ -434,9 +434,13 @@ struct GroupArgs {
     int nx[UNIVL_GEMM_GROUP_MAX], nxy[UNIVL_GEMM_GROUP_MAX], nz[UNIVL_GEMM_GROUP_MAX];
 };
 
+// A grid smaller than the number of tiles walks them with stride gridDim.x: the "background" form of the layer's
+// weight-gradient launch (engine.EncoderStack, UNIVL_WGRAD_BLOCKS) occupies only that many workgroups while the next
+// layer's latency-bound dgrad chain runs beside it on another stream.
 template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC>
 __global__ __launch_bounds__(256, 2) void gemm_group_kernel(GroupArgs g) {
-    const int w = blockIdx.x;
+  const int total = g.first[UNIVL_GEMM_GROUP_MAX];
+  for (int w = blockIdx.x; w < total; w += gridDim.x) {
     int idx = 0;
 #pragma unroll
     for (int i = 1; i < UNIVL_GEMM_GROUP_MAX; ++i) idx += (w >= g.first[i]) ? 1 : 0;
@@ -450,10 +454,12 @@ __global__ __launch_bounds__(256, 2) void gemm_group_kernel(GroupArgs g) {
     const int bz = local / nxy, rem = local - bz * nxy;
     const int by = rem / nx, bx = rem - by * nx;
     gemm_tile<T, TA, TB, BM, BN, D, NC>(p, bx, by, bz, nz);
+    if (gridDim.x < total) __syncthreads();           // the next tile's DMA reuses the LDS stages
+  }
 }
 
 template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC>
-int launch_group(const GroupArgs& g, hipStream_t stream) {
+int launch_group(const GroupArgs& g, int max_blocks, hipStream_t stream) {
     constexpr int BK = NC * Mma<T>::CH;
     using TileA = Tile<T, TA, BM, BK>;
     using TileB = Tile<T, TB, BN, BK>;
@@ -461,8 +467,9 @@ int launch_group(const GroupArgs& g, hipStream_t stream) {
     const size_t smem = NC == 6 ? 2 * TileA::BYTES + TileB::BYTES : 2 * (TileA::BYTES + TileB::BYTES);
     static bool attr_done[UNIVL_MAX_DEVICES] = {};   // per instantiation, per device
     if (smem > 48 * 1024) univl_allow_lds(gemm_group_kernel<T, TA, TB, BM, BN, D, NC>, smem, attr_done);
-    hipLaunchKernelGGL((gemm_group_kernel<T, TA, TB, BM, BN, D, NC>), dim3(g.first[UNIVL_GEMM_GROUP_MAX]), dim3(256), smem,
-                       stream, g);
+    const int total = g.first[UNIVL_GEMM_GROUP_MAX];
+    const int grid = (max_blocks > 0 && max_blocks < total) ? max_blocks : total;
+    hipLaunchKernelGGL((gemm_group_kernel<T, TA, TB, BM, BN, D, NC>), dim3(grid), dim3(256), smem, stream, g);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
@@ -595,10 +602,14 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
 }
 
 extern "C" int univl_gemm_group(const UnivlGemm* d, int n, hipStream_t stream) {
+    return univl_gemm_group_limited(d, n, 0, stream);
+}
+
+extern "C" int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_blocks, hipStream_t stream) {
     UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(d != nullptr && n >= 1 && n <= UNIVL_GEMM_GROUP_MAX, UNIVL_EINVAL, "univl_gemm_group: n=%d (1..%d)", n,
                     UNIVL_GEMM_GROUP_MAX);
-    if (n == 1) return univl_gemm(d, stream);
+    if (n == 1 && max_blocks <= 0) return univl_gemm(d, stream);
     GroupArgs g;
     bool big_all = true;
     // the group runs one kernel instantiation: the 128x128 tile only if every member would pick it
@@ -630,15 +641,15 @@ extern "C" int univl_gemm_group(const UnivlGemm* d, int n, hipStream_t stream) {
     const bool ta = d[0].trans_a, tb = d[0].trans_b;
 #define UNIVL_GROUP_CASE(T, BMN, NCV)                                                                        \
     do {                                                                                                     \
-        if (!ta && !tb) return launch_group<T, false, false, BMN, BMN, 2, NCV>(g, stream);                   \
-        if (!ta && tb) return launch_group<T, false, true, BMN, BMN, 2, NCV>(g, stream);                     \
-        if (ta && tb) return launch_group<T, true, true, BMN, BMN, 2, NCV>(g, stream);                       \
-        return launch_group<T, true, false, BMN, BMN, 2, NCV>(g, stream);                                    \
+        if (!ta && !tb) return launch_group<T, false, false, BMN, BMN, 2, NCV>(g, max_blocks, stream);       \
+        if (!ta && tb) return launch_group<T, false, true, BMN, BMN, 2, NCV>(g, max_blocks, stream);         \
+        if (ta && tb) return launch_group<T, true, true, BMN, BMN, 2, NCV>(g, max_blocks, stream);           \
+        return launch_group<T, true, false, BMN, BMN, 2, NCV>(g, max_blocks, stream);                        \
     } while (0)
     UNIVL_CHECK_ARG(nc_all > 0, UNIVL_EINVAL, "univl_gemm_group: members disagree on the K-step depth (mixed contraction lengths)");
     if (d[0].dtype == UNIVL_BF16) {
         if (big_all) UNIVL_GROUP_CASE(__bf16, 128, 2);
-        if (nc_all == 6) return launch_group<__bf16, true, true, 64, 64, 2, 6>(g, stream);
+        if (nc_all == 6) return launch_group<__bf16, true, true, 64, 64, 2, 6>(g, max_blocks, stream);
         UNIVL_GROUP_CASE(__bf16, 64, 4);
     }
     if (big_all) UNIVL_GROUP_CASE(float, 128, 2);

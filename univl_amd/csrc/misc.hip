@@ -45,6 +45,36 @@ extern "C" int univl_device_info(int* cu_count, char* name, int name_len) {
     return 0;
 }
 
+// ---- several buffers cleared by ONE launch (a backward starts by zeroing ~8 accumulation buffers: one graph node, not 8)
+namespace {
+struct ZeroList { unsigned char* ptr[UNIVL_ZERO_MAX]; long bytes[UNIVL_ZERO_MAX]; };
+__global__ __launch_bounds__(256) void zero_many_kernel(ZeroList z) {
+    unsigned char* p = z.ptr[blockIdx.y];
+    const long n16 = z.bytes[blockIdx.y] >> 4;
+    u32x4_t* q = reinterpret_cast<u32x4_t*>(p);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) q[i] = u32x4_t{0u, 0u, 0u, 0u};
+    if (blockIdx.x == 0) for (long i = (n16 << 4) + threadIdx.x; i < z.bytes[blockIdx.y]; i += 256) p[i] = 0;
+}
+}  // namespace
+
+extern "C" int univl_zero_many(void* const* ptrs, const int64_t* bytes, int32_t n, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    UNIVL_CHECK_ARG(ptrs && bytes && n >= 1 && n <= UNIVL_ZERO_MAX, UNIVL_EINVAL, "univl_zero_many: n=%d (1..%d)", n, UNIVL_ZERO_MAX);
+    ZeroList z;
+    long most = 0;
+    for (int i = 0; i < n; ++i) {
+        UNIVL_CHECK_ARG(ptrs[i] && bytes[i] > 0 && aligned16(ptrs[i]), UNIVL_EALIGN, "univl_zero_many: buffer %d must be non-empty and 16-byte aligned", i);
+        z.ptr[i] = static_cast<unsigned char*>(ptrs[i]);
+        z.bytes[i] = bytes[i];
+        most = bytes[i] > most ? bytes[i] : most;
+    }
+    long gx = (most / 16 + 2047) / 2048;                       // ~8 x 16 B per thread for the largest buffer
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    hipLaunchKernelGGL(zero_many_kernel, dim3((unsigned)gx, n), dim3(256), 0, stream, z);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
 extern "C" int univl_init(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

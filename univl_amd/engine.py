@@ -81,6 +81,24 @@ class FlatParams:
     def is_atomic(self, name):
         return self.index[name][0] < self.v_end
 
+    WORD = "bert.embeddings.word_embeddings.weight"
+    WORD_ROWS_CAP = 8192
+
+    def word_rows(self):
+        """(list, meta) device buffers of the sparse word-table bookkeeping (univl_rows_zero / _append / _sumsq): the table
+        rows written by the backward passes since the last clear."""
+        if getattr(self, "_word_rows", None) is None:
+            self._word_rows = (torch.zeros(self.WORD_ROWS_CAP, dtype=torch.int64, device=self.device),
+                               torch.zeros(2, dtype=torch.int32, device=self.device))
+            self.word_rows_version = -1
+        return self._word_rows
+
+    def v_region_without_word_table(self):
+        """Slices of g32 covering the atomic region except the word-embedding table."""
+        o, k, _ = self.index[self.WORD]
+        end = o + (k + _ALIGN - 1) // _ALIGN * _ALIGN
+        return [t for t in (self.g32[:o], self.g32[end:self.v_end]) if t.numel() > 0]
+
     # ---- views
     def w32(self, name):
         o, k, shp = self.index[name]
@@ -205,9 +223,10 @@ class Plan:
         self.descs[len(self.ops)] = [desc]
         self.ops.append(("call", fn, C.byref(desc), fn_name, stream))
 
-    def add_gemm_group(self, descs, stream=0):
-        """Independent GEMMs with the same operand layouts as ONE launch (univl_gemm_group), in chunks of GEMM_GROUP_MAX."""
-        fn = _lib.lib().univl_gemm_group
+    def add_gemm_group(self, descs, stream=0, max_blocks=0):
+        """Independent GEMMs with the same operand layouts as ONE launch (univl_gemm_group), in chunks of GEMM_GROUP_MAX.
+        max_blocks > 0: at most that many workgroups (the kernel walks its tiles)."""
+        fn = _lib.lib().univl_gemm_group_limited
         if os.environ.get("UNIVL_GROUP_WGRAD", "1") == "0":           # A/B switch: one launch per member
             for d in descs:
                 self.add("univl_gemm", d, stream)
@@ -217,7 +236,13 @@ class Plan:
             arr = (_lib.Gemm * len(chunk))(*chunk)
             self.keep.append(arr)
             self.descs[len(self.ops)] = list(chunk)
-            self.ops.append(("group", fn, (arr, len(chunk)), "univl_gemm_group", stream))
+            self.ops.append(("group", fn, (arr, len(chunk), int(max_blocks)), "univl_gemm_group", stream))
+
+    def add_zeros(self, tensors, stream=0):
+        """Clear several buffers with one launch (univl_zero_many)."""
+        ts = [t for t in tensors if t is not None and t.numel() > 0]
+        if ts:
+            self.add_callable(lambda: ops.zero_many(ts), stream)
 
     def add_callable(self, f, stream=0, eager=False):
         """eager=True marks host-driven work that must never be captured into a hipGraph (RCCL collectives): run()
@@ -231,6 +256,11 @@ class Plan:
         on its own stream and registers one event per layer; the forward plan waits for a layer's parameters only where it
         first reads them."""
         self.ops.append(("wait", key, None, "wait", stream))
+
+    def record(self, key, stream=0):
+        """Mark the work enqueued on `stream` so far; a later wait_point(key, other_stream) waits for exactly that much
+        (fork / join always wait for everything enqueued on the source up to the moment of the wait)."""
+        self.ops.append(("record", key, None, "record", stream))
 
     def fork(self, src, dst):
         """dst waits for all work enqueued on src so far."""
@@ -250,7 +280,7 @@ class Plan:
         return st
 
     def _run_ops(self, ops_, cur):
-        handles = {}
+        handles, events = {}, {}
         for op in ops_:
             kind, a, b, name, sidx = op
             if kind == "call":
@@ -264,11 +294,17 @@ class Plan:
                 h = handles.get(sidx)
                 if h is None:
                     h = handles[sidx] = C.c_void_p(self._stream(sidx, cur).cuda_stream)
-                rc = a(b[0], b[1], h)
+                rc = a(b[0], b[1], b[2], h)
                 if rc != 0:
                     _lib.check(rc, name)
+            elif kind == "record":
+                ev = torch.cuda.Event()
+                ev.record(self._stream(sidx, cur))
+                events[a] = ev
             elif kind == "wait":
-                ev = self.external.get(a) if self.external else None
+                ev = events.get(a)
+                if ev is None and self.external:
+                    ev = self.external.get(a)
                 if ev is not None:
                     self._stream(sidx, cur).wait_event(ev)
             elif kind == "eager":
@@ -345,7 +381,7 @@ class Plan:
             if kind == "call" and name.startswith(prefix):
                 out.append((lambda h, fn=fn, arg=arg: fn(arg, h), self.descs[i]))
             elif kind == "group" and name.startswith(prefix):
-                out.append((lambda h, fn=fn, arg=arg: fn(arg[0], arg[1], h), self.descs[i]))
+                out.append((lambda h, fn=fn, arg=arg: fn(arg[0], arg[1], arg[2], h), self.descs[i]))
         return out
 
     @property
@@ -399,9 +435,15 @@ class EncoderStack:
 
     H, NH, I = 768, 12, 3072
 
-    def __init__(self, flat, prefix, n_layers, B, S, key_mask, p_drop, seed_dev, sites, splitk=True, s_main=0, s_side=1):
+    def __init__(self, flat, prefix, n_layers, B, S, key_mask, p_drop, seed_dev, sites, splitk=True, s_main=0, s_side=1,
+                 s_wgrad=None):
+        """s_wgrad: stream index for "background" weight gradients (None: they run in the chain).  With it, a layer's
+        grouped weight-gradient launch is capped at UNIVL_WGRAD_BLOCKS workgroups and runs on that stream beside the
+        NEXT layer's dgrad chain; the four operands it reads live in two alternating scratch sets."""
         self.flat, self.prefix, self.L, self.B, self.S = flat, prefix, n_layers, B, S
         self.sm, self.ss = s_main, s_side
+        self.wg_blocks = int(os.environ.get("UNIVL_WGRAD_BLOCKS", "0"))
+        self.sw = s_wgrad if (s_wgrad is not None and self.wg_blocks > 0 and n_layers > 1) else None
         self.T = B * S
         self.key_mask = key_mask            # int64 [B,S] device tensor (static buffer)
         self.p = float(p_drop)
@@ -425,11 +467,12 @@ class EncoderStack:
             self.layers.append(ws)
         # backward scratch shared by all layers
         self.gbuf = e(T, H)
-        self.dxd = e(T, H, dtype=ct)       # grad wrt FFN2 output (operand of its wgrad / dgrad)
-        self.dxd2 = e(T, H, dtype=ct)      # grad wrt attention-output projection (separate: wgrads run concurrently)
-        self.du = e(T, I, dtype=ct)
         self.dctx = e(T, H, dtype=ct)
-        self.dqkv = e(T, 3 * H, dtype=ct)
+        # operands of the weight-gradient GEMMs: dxd = grad wrt the FFN2 output, dxd2 = grad wrt the attention-output
+        # projection (separate buffers: the four wgrads of a layer are one grouped launch), du, dqkv.  Two sets when the
+        # weight gradients of layer l run while layer l-1's chain already produces its own.
+        self.scr = [dict(dxd=e(T, H, dtype=ct), dxd2=e(T, H, dtype=ct), du=e(T, I, dtype=ct), dqkv=e(T, 3 * H, dtype=ct))
+                    for _ in range(2 if self.sw is not None else 1)]
         # split-K for the N=768 products when the grid would not fill the chip: ~3 K-steps of 128 per workgroup
         self.tiles = ((T + 63) // 64) * (H // 64)
         self.splitk = splitk and self.tiles < 128
@@ -467,11 +510,12 @@ class EncoderStack:
         return ws["o32"], ws["o16"]
 
     # ------------------------------------------------------------------------------------------ forward
-    def build_forward(self, plan, x32, x16, training):
+    def build_forward(self, plan, x32, x16, training, zero_arena=True):
+        """zero_arena=False: the caller clears self.yarena (split-K accumulation targets) together with its other buffers."""
         fl, dt, T, H, I, S, B = self.flat, self.flat.dt, self.T, self.H, self.I, self.S, self.B
         sm = self.sm
         p = self.p if training else 0.0
-        if self.ks_h > 1:
+        if self.ks_h > 1 and zero_arena:
             plan.add_callable(self.yarena.zero_, stream=sm)
         for l, ws in enumerate(self.layers):
             nm = self._names(l)
@@ -505,7 +549,7 @@ class EncoderStack:
             pass
         return self.bwd_out
 
-    def backward_layers(self, plan, gin, x0_32, x0_16, gs, training, layer_hook=None):
+    def backward_layers(self, plan, gin, x0_32, x0_16, gs, training, layer_hook=None, zero_arena=True):
         """Generator form: emits one layer per next() (last layer first) so that a caller can interleave two stacks in
         plan order; self.bwd_out holds the gradient wrt the stack input once exhausted.
         gin: fp32 [T,H] gradient wrt the last layer's output.  `gs` (GradState) decides beta = 0 / 1 per
@@ -516,36 +560,41 @@ class EncoderStack:
         fl, dt, T, H, I, S, B = self.flat, self.flat.dt, self.T, self.H, self.I, self.S, self.B
         sm = self.sm
         p = self.p if training else 0.0
-        if self.ks_h > 1:
+        if self.ks_h > 1 and zero_arena:
             plan.add_callable(self.garena.zero_, stream=sm)
+        sw = self.sw
         for l in range(self.L - 1, -1, -1):
             ws, nm = self.layers[l], self._names(l)
             xin32, xin16 = (x0_32, x0_16) if l == 0 else (self.layers[l - 1]["o32"], self.layers[l - 1]["o16"])
+            sc = self.scr[l % len(self.scr)]
+            s_dxd, s_dxd2, s_du, s_dqkv = sc["dxd"], sc["dxd2"], sc["du"], sc["dqkv"]
+            if sw is not None and l + 2 < self.L:
+                plan.wait_point(("wgrad", self.prefix, id(self), l + 2), sm)     # this scratch set is free again
             dz, da = self.gbuf, self.garena[l, 0]
             # output LayerNorm / dropout backward (BertOutput, module_bert.py:246-250)
             plan.add("univl_layernorm_bwd", ops.layernorm_desc(
-                dt, T, H, gamma=fl.w32(nm["ln2_g"]), y=ws["y2"], stats=ws["st2"], dout=gin, dx32=dz, dxd16=self.dxd,
+                dt, T, H, gamma=fl.w32(nm["ln2_g"]), y=ws["y2"], stats=ws["st2"], dout=gin, dx32=dz, dxd16=s_dxd,
                 dgamma=fl.g(nm["ln2_g"]), dbeta=fl.g(nm["ln2_b"]), dbias=fl.g(nm["b2"]), p_pre=p, off_pre=ws["off"][2],
                 seed_dev=self.seed_dev), sm)
-            wgrads = [_gemm_desc(dt, self.dxd, H, ws["f"], I, H, I, T, trans_a=1, trans_b=1,
+            wgrads = [_gemm_desc(dt, s_dxd, H, ws["f"], I, H, I, T, trans_a=1, trans_b=1,
                                  out32=fl.g(nm["w2"]), ldc=I, accumulate=gs.acc(nm["w2"]), **gs.sumsq_args(nm["w2"], H, I))]
-            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, fl.wop(nm["w2"]), I, T, I, H, trans_b=1, out16=self.du,
+            plan.add("univl_gemm", _gemm_desc(dt, s_dxd, H, fl.wop(nm["w2"]), I, T, I, H, trans_b=1, out16=s_du,
                                               ldc=I, aux=ws["u"], ldaux=I, gelu="bwd"), sm)
-            wgrads.append(_gemm_desc(dt, self.du, I, ws["a16"], H, I, H, T, trans_a=1, trans_b=1,
+            wgrads.append(_gemm_desc(dt, s_du, I, ws["a16"], H, I, H, T, trans_a=1, trans_b=1,
                                      out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=fl.g(nm["b1"]),
                                      **gs.sumsq_args(nm["w1"], I, H)))
-            plan.add("univl_gemm", _gemm_desc(dt, self.du, I, fl.wop(nm["w1"]), H, T, H, I, trans_b=1, out32=da, ldc=H,
+            plan.add("univl_gemm", _gemm_desc(dt, s_du, I, fl.wop(nm["w1"]), H, T, H, I, trans_b=1, out32=da, ldc=H,
                                               residual=dz, ldr=H, ksplit=self.ksplit_for(I)), sm)
             # attention-output LayerNorm / dropout backward (BertSelfOutput, module_bert.py:207-211)
             dy = self.gbuf
             plan.add("univl_layernorm_bwd", ops.layernorm_desc(
-                dt, T, H, gamma=fl.w32(nm["ln1_g"]), y=ws["y1"], stats=ws["st1"], dout=da, dx32=dy, dxd16=self.dxd2,
+                dt, T, H, gamma=fl.w32(nm["ln1_g"]), y=ws["y1"], stats=ws["st1"], dout=da, dx32=dy, dxd16=s_dxd2,
                 dgamma=fl.g(nm["ln1_g"]), dbeta=fl.g(nm["ln1_b"]), dbias=fl.g(nm["o_b"]), p_pre=p, off_pre=ws["off"][1],
                 seed_dev=self.seed_dev), sm)
-            wgrads.append(_gemm_desc(dt, self.dxd2, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
+            wgrads.append(_gemm_desc(dt, s_dxd2, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
                                      out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"]), **gs.sumsq_args(nm["o_w"], H, H)))
-            plan.add("univl_gemm", _gemm_desc(dt, self.dxd2, H, fl.wop(nm["o_w"]), H, T, H, H, trans_b=1, out16=self.dctx, ldc=H), sm)
-            qkv, dqkv = ws["qkv"], self.dqkv
+            plan.add("univl_gemm", _gemm_desc(dt, s_dxd2, H, fl.wop(nm["o_w"]), H, T, H, H, trans_b=1, out16=self.dctx, ldc=H), sm)
+            qkv, dqkv = ws["qkv"], s_dqkv
             plan.add("univl_attention_bwd", ops.attention_desc(
                 dt, B, self.NH, S, S, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx"], H, ws["lse"],
                 key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev, dout=self.dctx, lddo=H,
@@ -558,12 +607,19 @@ class EncoderStack:
                                               out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ksplit_for(3 * H)), sm)
             # the layer's four weight-gradient GEMMs only consume tensors the chain above produced (dxd, du, dxd2, dqkv
             # are distinct buffers): one grouped launch, after which the scratch may be reused by the next layer
-            plan.add_gemm_group(wgrads, sm)
+            if sw is None:
+                plan.add_gemm_group(wgrads, sm)
+            else:                                       # beside the next layer's chain, on at most wg_blocks workgroups
+                plan.fork(sm, sw)
+                plan.add_gemm_group(wgrads, sw, max_blocks=self.wg_blocks)
+                plan.record(("wgrad", self.prefix, id(self), l), sw)
             gin = dx
             if layer_hook is not None:
                 layer_hook(plan, self.prefix, l, sm)
             self.bwd_out = gin
             yield l
+        if sw is not None:
+            plan.join(sw, sm)                           # whatever follows on the chain's stream sees every weight gradient
         self.bwd_out = gin
 
 

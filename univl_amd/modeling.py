@@ -606,11 +606,18 @@ class UniVL(UniVLPreTrainedModel):
         if fl._pending is not None:          # a deferred clip nobody consumed: it scales the OLD gradients, as torch's did
             from .optimization import apply_pending_clip
             apply_pending_clip(fl)
+        if getattr(fl, "_word_rows", None) is not None and fl.g32._version != getattr(fl, "_g32_tv", fl.g32._version):
+            fl._word_rows[1][1] = 1          # the gradients were edited through torch since the last backward: rows unknown
         fl.grad_version += 1
         self._run_plan(st.backward_plan(fresh), st)
         plan = st.backward_plan(fresh)
         fl.fused = (dict(version=fl.grad_version, names=plan.fused_names, tv=fl.g32._version)
                     if plan.fused_names else None)
+        fl._g32_tv = fl.g32._version
+        if getattr(plan, "rows_mode", False):
+            fl.word_rows_version = fl.grad_version            # the row list describes exactly these gradients
+        elif getattr(fl, "_word_rows", None) is not None:
+            fl._word_rows[1][1] = 1                            # a dense writer ran: every row counts as listed from now on
         fl.attach_grads(used)
 
     def forward(self, input_ids, token_type_ids, attention_mask, video, video_mask=None,

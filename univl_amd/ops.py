@@ -213,6 +213,29 @@ def scale_by_device_scalar(x, s):
     _lib.check(_lib.lib().univl_scale_by_device_scalar(_p(x), x.numel(), _p(s), _stream()), "scale_by_device_scalar")
 
 
+def zero_many(tensors):
+    """One launch that clears up to 16 device buffers."""
+    import ctypes as C
+    L = _lib.lib()
+    for i in range(0, len(tensors), 16):
+        ts = tensors[i:i + 16]
+        ptrs = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        sizes = (C.c_int64 * len(ts))(*[t.numel() * t.element_size() for t in ts])
+        _lib.check(L.univl_zero_many(ptrs, sizes, len(ts), _stream()), "zero_many")
+
+
+def rows_zero(table, lst, meta):
+    _lib.check(_lib.lib().univl_rows_zero(_p(table), table.shape[0], _p(lst), _p(meta), _stream()), "rows_zero")
+
+
+def rows_append(ids, lst, meta, reset):
+    _lib.check(_lib.lib().univl_rows_append(_p(ids), ids.numel(), _p(lst), lst.numel(), _p(meta), int(bool(reset)), _stream()), "rows_append")
+
+
+def rows_sumsq(table, lst, meta, out):
+    _lib.check(_lib.lib().univl_rows_sumsq(_p(table), table.shape[0], _p(lst), _p(meta), _p(out), _stream()), "rows_sumsq")
+
+
 def embed_scatter(ids, rows, scale, dword):
     _require_gpu(ids, rows, dword)
     _lib.check(_lib.lib().univl_embed_scatter(_p(ids), _p(rows), ids.numel(), float(scale), _p(dword), _stream()), "embed_scatter")

@@ -108,12 +108,20 @@ def _measure(fl, cfg, tb):
     if fused is not None and fused["version"] == fl.grad_version and fused["names"] <= set(cfg) and not fused.get("consumed"):
         fused["consumed"] = True          # fl.sumsq may be completed once per backward; later callers re-measure
         rest = {n: c for n, c in cfg.items() if n not in fused["names"]}
+        rows = getattr(fl, "_word_rows", None)
+        sparse_table = (rows is not None and getattr(fl, "word_rows_version", -1) == fl.grad_version and fl.WORD in rest)
+        if sparse_table:                  # only the listed rows of the word table are non-zero: no 94 MB read for its norm
+            rest = {n: c for n, c in rest.items() if n != fl.WORD}
         key = tuple(sorted(rest))
         tr = fl._rest[1] if (getattr(fl, "_rest", None) is not None and fl._rest[0] == key) else None
         if tr is None:
             tr = _Tables(fl, rest)
             fl._rest = (key, tr)
         _sumsq(fl, tr, out=fl.sumsq, zero=False)       # the backward zeroed fl.sumsq before its GEMMs added to it
+        if sparse_table:
+            from . import ops
+            seg = fl.seg_of[fl.WORD]
+            ops.rows_sumsq(fl.g(fl.WORD), rows[0], rows[1], fl.sumsq[seg:seg + 1])
         return fl.sumsq
     _sumsq(fl, tb)
     return tb.sumsq
@@ -136,6 +144,8 @@ def _active_cfg(fl, params_with_cfg):
             if gr.data_ptr() != gv.data_ptr():
                 gv.copy_(gr)               # a foreign gradient tensor: bring it into the flat buffer
                 fl.fused = None            # ... whose norm nobody has measured
+                if n == fl.WORD and getattr(fl, "_word_rows", None) is not None:
+                    fl._word_rows[1][1] = 1                 # ... and whose non-zero rows nobody listed
             p.grad = gv
         cfg[n] = (lr, wd, mgn, 1)
     return cfg

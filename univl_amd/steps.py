@@ -77,9 +77,9 @@ class EncoderPass:
         self.dvnorm = e(self.Tv, D)            # grad wrt the normalised video (accumulated: encoder + MFM loss)
         m = cx.model
         self.text = EncoderStack(fl, "bert", m.bert_config.num_hidden_layers, B, W, self.amask, cx.p, cx.seed_dev, cx.sites,
-                                 s_main=s_text, s_side=s_text)
+                                 s_main=s_text, s_side=s_text, s_wgrad=s_text + 4)
         self.vis = EncoderStack(fl, "visual", m.visual_config.num_hidden_layers, B, F, self.vmask, cx.p, cx.seed_dev, cx.sites,
-                                s_main=s_vis, s_side=s_vis)
+                                s_main=s_vis, s_side=s_vis, s_wgrad=s_vis + 4)
         self.off_t, self.off_v = cx.sites.next(), cx.sites.next()
         self.seq_out, self.seq_out16 = self.text.output()
         self.vis_out, self.vis_out16 = self.vis.output()
@@ -103,6 +103,7 @@ class EncoderPass:
         cx, n, fl, dt, bf = self.cx, self.N, self.cx.fl, self.cx.dt, self.cx.bf
         W32, p, B, W, F, D, Tv = fl.w32, cx.p, self.B, self.W, self.F, self.D, self.Tv
         ST, SV = self.ST, self.SV
+        fwd.add_zeros([st.yarena for st in (self.text, self.vis) if st.ks_h > 1], ST)      # split-K accumulation targets
         fwd.fork(ST, SV)           # the video encoder runs concurrently with the text encoder
         if self.normalized_input:
             if bf:
@@ -120,14 +121,13 @@ class EncoderPass:
             dt, B, W, self.ids, W32(n["bw"]), W32(n["bp"]), W32(n["blg"]), W32(n["blb"]), type_ids=self.type_ids,
             type_emb=W32(n["bt"]), y=self.te, stats=self.test, out32=self.t0_32, out16=self.t0_16 if bf else None, p_post=p,
             seed=cx.seed, off_post=self.off_t, seed_dev=cx.seed_dev), ST)
-        self.vis.build_forward(fwd, self.v0_32, self.v0_16, cx.training)
-        self.text.build_forward(fwd, self.t0_32, self.t0_16, cx.training)
+        self.vis.build_forward(fwd, self.v0_32, self.v0_16, cx.training, zero_arena=False)
+        self.text.build_forward(fwd, self.t0_32, self.t0_16, cx.training, zero_arena=False)
         fwd.join(SV, ST)
 
-    def zero_grads(self, bwd):
-        bwd.add_callable(self.dseq.zero_)
-        bwd.add_callable(self.dvis.zero_)
-        bwd.add_callable(self.dvnorm.zero_)
+    def zero_list(self):
+        """Accumulation buffers a backward clears before anything adds into them."""
+        return [self.dseq, self.dvis, self.dvnorm] + [st.garena for st in (self.text, self.vis) if st.ks_h > 1]
 
     def build_backward(self, bwd, gs, hook=None):
         """Consumes self.dseq / self.dvis (+ whatever was accumulated into self.dvnorm)."""
@@ -138,8 +138,8 @@ class EncoderPass:
         # The two stacks are independent until the join below and run on two streams; they are emitted INTERLEAVED
         # (text layers : video layers in the ratio of their depths) so that plan order follows time order -- gradient
         # exchange points and hipGraph segment cuts (Plan.run_graphed) then fall between layers of both stacks.
-        gv = self.vis.backward_layers(bwd, self.dvis, self.v0_32, self.v0_16, gs, cx.training, layer_hook=hook)
-        gt = self.text.backward_layers(bwd, self.dseq, self.t0_32, self.t0_16, gs, cx.training, layer_hook=hook)
+        gv = self.vis.backward_layers(bwd, self.dvis, self.v0_32, self.v0_16, gs, cx.training, layer_hook=hook, zero_arena=False)
+        gt = self.text.backward_layers(bwd, self.dseq, self.t0_32, self.t0_16, gs, cx.training, layer_hook=hook, zero_arena=False)
         ratio = max(1, int(round(self.text.L / max(1, self.vis.L))))
         done_t = done_v = False
         while not (done_t and done_v):
@@ -177,6 +177,10 @@ class EncoderPass:
             type_emb=W32(n["bt"]), y=self.te, stats=self.test, p_post=p, seed=cx.seed, off_post=self.off_t,
             seed_dev=cx.seed_dev, dout=dxt, dword=G(n["bw"]), dpos=G(n["bp"]), dtype_emb=G(n["bt"]), dgamma=G(n["blg"]),
             dbeta=G(n["blb"]), drows=self.drows if sparse else None), ST)
+        rows = getattr(self, "word_rows", None)
+        if rows is not None and not sparse:            # remember which table rows this backward wrote (engine.FlatParams.word_rows)
+            lst, meta, reset = rows
+            bwd.add_callable(lambda: ops.rows_append(self.ids.view(-1), lst, meta, reset), ST)
 
 
 class SimLoss:
@@ -284,9 +288,8 @@ class CrossRun:
             seed_dev=cx.seed_dev), sm)
         self.stack.build_forward(fwd, self.c0_32, self.c0_16, cx.training)
 
-    def zero_grads(self, bwd):
-        bwd.add_callable(self.dcross.zero_, self.sm)
-        bwd.add_callable(self.dpostype.zero_, self.sm)
+    def zero_list(self):
+        return [self.dcross, self.dpostype]
 
     def build_backward(self, bwd, gs, hook=None):
         """Consumes self.dcross (accumulated by the consumers); adds into enc.dseq / enc.dvis."""
@@ -684,19 +687,32 @@ def build_step(model, kind, B, W, F, training):
         cross_runs = [r for r in (st.run_pairs, st.run_rows, st.run_heads) if r is not None]     # emission order below
         last_cross = cross_runs[-1] if cross_runs else None
         hook_for = lambda r: hook if r is last_cross else None
-        if fuse:
-            bwd.add_callable(fl.sumsq.zero_)
-            bwd.add_callable(fl.partials.zero_)
-        if fresh:
-            bwd.add_callable(fl.g32[:fl.v_end].zero_)
-        enc.zero_grads(bwd)
+        # Everything a backward clears before its kernels add into it goes into ONE launch.  Retrieval configurations
+        # (the token gather is the word table's only gradient source): the 94 MB table is not cleared as a whole, only the
+        # rows the previous backward wrote (engine.FlatParams.word_rows).
+        world = 1 if cx.red is None else max(1, cx.red.world)
+        rows_mode = (kind in ("joint", "align") and os.environ.get("UNIVL_SPARSE_ROWS", "1") != "0"
+                     and (cx.red is None or sparse)        # a dense all-reduce of the table fills rows nobody listed
+                     and enc.Tt * (world if sparse else 1) <= fl.WORD_ROWS_CAP)
+        zeros = [fl.sumsq, fl.partials] if fuse else []
+        enc.word_rows = None
+        if rows_mode:
+            lst, meta = fl.word_rows()
+            enc.word_rows = (lst, meta, fresh)
+            if fresh:
+                zeros += fl.v_region_without_word_table()
+                bwd.add_callable(lambda: ops.rows_zero(fl.g(fl.WORD), lst, meta))
+        elif fresh:
+            zeros.append(fl.g32[:fl.v_end])
+        zeros += enc.zero_list()
         if st.enc_m is not None:
-            st.enc_m.zero_grads(bwd)
+            zeros += st.enc_m.zero_list()
         for r in (st.run_pairs, st.run_rows):
             if r is not None:
-                r.zero_grads(bwd)
+                zeros += r.zero_list()
         if st.run_heads is not None:
-            bwd.add_callable(st.run_heads.dpostype.zero_)
+            zeros.append(st.run_heads.dpostype)
+        bwd.add_zeros(zeros)
         g = st.gout
         if st.pooler is not None:
             st.pooler.build_backward(bwd, gs, g)
@@ -734,9 +750,12 @@ def build_step(model, kind, B, W, F, training):
             bwd.add_callable(red.join, eager=True)
             if sparse:                                     # rebuild the dense table gradient: mean over ranks
                 bwd.add_callable(lambda: ops.embed_scatter(ids_all.view(-1), rows_all.view(-1, H), 1.0 / world, fl.g(wname)))
+                if rows_mode:
+                    bwd.add_callable(lambda: ops.rows_append(ids_all.view(-1), lst, meta, fresh))
             st.exchange_points = list(sched[0].cuts)
         gs.finish(bwd)
         bwd.fused_names = frozenset(gs.covered)
+        bwd.rows_mode = rows_mode
         return bwd
 
     st._build_bwd = build_bwd
