@@ -44,8 +44,8 @@ def get_args():
     ap.add_argument("--batch", type=int, default=4, help="pairs per GPU per step (configs[1]: bs=4)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="keep BertAdam at the end of its own step instead of overlapping it with the next forward")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="overlap BertAdam of step t with the forward of step t+1 (univl_amd.graphed; measured slower, off by default)")
     ap.add_argument("--host-inputs", action="store_true",
                     help="time the MAIN loop with the batch handed over as pageable HOST tensors every step")
     ap.add_argument("--loopback", action="store_true",
@@ -259,7 +259,7 @@ def main():
     gstep, mode = None, ("per-plan graphs (UniVL._run_plan)" if model.auto_graph else "eager")
     if not args.no_graph:
         from univl_amd.graphed import GraphedTrainStep
-        gstep = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=0, pipeline_optimizer=not args.no_pipeline)
+        gstep = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=0, pipeline_optimizer=args.pipeline)
         ok = 1
         try:
             a, kw = call_args(inputs)
@@ -274,7 +274,7 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = int(flag)
         if ok:
-            mode = gstep.mode
+            mode = "hipGraph"
         else:
             gstep = None
             model.graph_backward = False
@@ -397,7 +397,8 @@ def main():
                                         "encoder (12 L) + 6-layer visual encoder, max_words=48, max_frames=48, bs=%d per GPU, "
                                         "fwd+bwd+clip+BertAdam, dropout %.2f, random-init weights" % (args.batch, args.dropout),
                                per_gpu_batch=args.batch, global_batch=args.batch * world, max_words=48, max_frames=48,
-                               parallelism="dp%d" % world, hip_graph=gstep is not None, graph_mode=mode,
+                               parallelism="dp%d" % world, hip_graph=gstep is not None,
+                               graph_mode=(gstep.mode if gstep is not None else mode),
                                optimizer_pipelined=bool(gstep is not None and gstep.pipeline),
                                host_inputs=bool(args.host_inputs), exchange=exchange, params=n_params,
                                last_loss=round(last, 6)),

@@ -85,7 +85,7 @@ def _worker(rank, world, port, mode, q):
     else:                                           # explicit API + hipGraph replay with real collectives in between
         from univl_amd.graphed import GraphedTrainStep
         model.enable_data_parallel()
-        gs = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=1)
+        gs = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=1, pipeline_optimizer=True)
         for it in range(STEPS):
             losses.append(float(gs(*args, **kw)))
         assert gs.mode == "segmented"
@@ -161,7 +161,7 @@ def _worker_nccl(port, q):
             opt = BertAdam(model.parameters(), lr=1e-4, warmup=-1, t_total=-1, weight_decay=0.01, max_grad_norm=1.0)
             losses = []
             if graphed:
-                gs = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=1)
+                gs = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=1, pipeline_optimizer=True)
                 for _ in range(STEPS + 1):
                     losses.append(float(gs(*args, **kw)))
                 gs.flush()

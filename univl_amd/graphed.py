@@ -10,7 +10,8 @@ bottleneck (~10 us per ctypes call).  `GraphedTrainStep` captures the iteration 
     the all-reduces issued from the host between the replays (they run on RCCL's own stream and overlap the
     following segments), and clip + BertAdam are a last graph that is replayed after the reducer's join.
 
-Pipelined optimizer (pipeline_optimizer=True, the default).  At small per-GPU batch the forward/backward is a chain of
+Pipelined optimizer (pipeline_optimizer=True; OFF by default -- measured slower on MI355X, see the end of this paragraph).
+At small per-GPU batch the forward/backward is a chain of
 short latency-bound kernels that leaves most of the HBM bandwidth idle, while the BertAdam update is one long HBM-bound
 stream (30 B per parameter) that needs nothing but bandwidth.  The global clip (main_task_retrieval.py:347) needs every
 gradient before any parameter may change, so the update cannot move INTO its own backward -- but it can ride next to the
@@ -21,6 +22,10 @@ exchange and the clip measurement follow as before.  Every iteration still perfo
 and one BertAdam update, in the same arithmetic order: losses and parameters are the same as without pipelining
 (tests/test_model_gpu.py).  Between calls the parameters lag by the one pending update; `flush()` -- called
 automatically by state_dict(), eval(), the evaluation entry points and optimizer.state_dict() -- applies it.
+Measured (profiles/README.md, round 2): 3.38 ms per step pipelined against 3.16 ms sequential at 4 pairs per GPU, 3.25 ms
+with the update capped at 256 workgroups: the forward is a chain of kernels bound by memory ROUND TRIPS, and a concurrent
+stream that saturates HBM multiplies exactly those latencies -- what the overlap hides of the update it loses again in a
+slower forward.  Kept as a tested option, not the default.
 
 The first `warmup` calls run eagerly (they build the execution plans and the optimizer tables); the next call
 captures and runs; later calls only copy the new batch into the static input buffers and replay.
@@ -34,7 +39,7 @@ from .steps import stage_input
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, max_grad_norm=1.0, warmup=3, persistent_inputs=True, pipeline_optimizer=True):
+    def __init__(self, model, optimizer, max_grad_norm=1.0, warmup=3, persistent_inputs=True, pipeline_optimizer=False):
         """persistent_inputs=True: the tensors of the first captured call ARE the static input buffers when they live on
         the model's device (later calls may pass the same tensors refilled in place -- no copy -- or other tensors, e.g.
         the loader's host batch, which are copied in)."""
@@ -42,7 +47,7 @@ class GraphedTrainStep:
         self.max_grad_norm = max_grad_norm
         self.warmup = int(warmup)
         self.persistent = bool(persistent_inputs)
-        self.pipeline = bool(pipeline_optimizer) and os.environ.get("UNIVL_PIPELINE_OPT", "1") != "0"
+        self.pipeline = bool(pipeline_optimizer) or os.environ.get("UNIVL_PIPELINE_OPT", "0") == "1"
         self.adam_blocks = int(os.environ.get("UNIVL_ADAM_BLOCKS", "0"))      # grid cap of the overlapped update (0: none)
         self.params = [p for p in model.parameters()]
         self.calls = 0
