@@ -12,6 +12,7 @@
 //
 // Work decomposition: the host splits every tensor into chunks of <= CHUNK elements (chunk_seg/off/len arrays);
 // one workgroup per chunk, so no chunk straddles two tensors and per-tensor scalars are workgroup-uniform.
+#include <stdlib.h>
 #include "common.h"
 #include "univl_hip.h"
 
@@ -109,7 +110,22 @@ __global__ void adam_prep_kernel(UnivlAdam a) {
 }
 
 // chunks [c0, c1) of the chunk table; a grid smaller than the range walks it with stride gridDim.x (a throttled launch
-// that leaves CUs to concurrently running kernels: the pipelined step overlaps this update with the next forward)
+// that leaves CUs to concurrently running kernels: the pipelined step overlaps this update with the next forward).
+// NT: the fp32 streams (p, g, m, v: 28 of the 30 bytes per parameter, touched exactly once per step) go through
+// non-temporal loads / stores so that they do not push the bf16 shadow -- the only thing the next forward reads -- out of
+// the caches (UNIVL_ADAM_NT, A/B in profiles/README.md).
+template <bool NT> __device__ __forceinline__ f32x4_t ld4(const float* p, int i) {
+    const f32x4_t* q = reinterpret_cast<const f32x4_t*>(p) + i;
+    if (NT) return __builtin_nontemporal_load(q);
+    return *q;
+}
+template <bool NT> __device__ __forceinline__ void st4(float* p, int i, f32x4_t v) {
+    f32x4_t* q = reinterpret_cast<f32x4_t*>(p) + i;
+    if (NT) __builtin_nontemporal_store(v, q);
+    else *q = v;
+}
+
+template <bool NT>
 __global__ __launch_bounds__(256) void adam_apply_kernel(UnivlAdam a, int c0, int c1) {
   for (int c = c0 + blockIdx.x; c < c1; c += gridDim.x) {
     const int seg = a.chunk_seg[c];
@@ -122,23 +138,21 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(UnivlAdam a, int c0, in
     float* p = a.p + off; const float* g = a.g + off; float* m = a.m + off; float* v = a.v + off;
     __bf16* p16 = a.p16 ? reinterpret_cast<__bf16*>(a.p16) + off : nullptr;
     const int nv = ((off & 3) == 0) ? len / 4 : 0;
-    auto update = [&](int i, float4 pp, const float4 gg, float4 mm, float4 vv) {
-        float* pe = reinterpret_cast<float*>(&pp); const float* ge = reinterpret_cast<const float*>(&gg);
-        float* me = reinterpret_cast<float*>(&mm); float* ve = reinterpret_cast<float*>(&vv);
+    auto update = [&](int i, f32x4_t pp, const f32x4_t gg, f32x4_t mm, f32x4_t vv) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float gr = ge[e] * gs;
-            me[e] = me[e] * b1 + (1.0f - b1) * gr;
-            ve[e] = ve[e] * b2 + (1.0f - b2) * gr * gr;
-            const float upd = me[e] / (sqrtf(ve[e]) + eps) + wd * pe[e];
-            pe[e] -= lr * upd;
+            const float gr = gg[e] * gs;
+            mm[e] = mm[e] * b1 + (1.0f - b1) * gr;
+            vv[e] = vv[e] * b2 + (1.0f - b2) * gr * gr;
+            const float upd = mm[e] / (sqrtf(vv[e]) + eps) + wd * pp[e];
+            pp[e] -= lr * upd;
         }
-        reinterpret_cast<float4*>(p)[i] = pp;
-        reinterpret_cast<float4*>(m)[i] = mm;
-        reinterpret_cast<float4*>(v)[i] = vv;
+        st4<NT>(p, i, pp);
+        st4<NT>(m, i, mm);
+        st4<NT>(v, i, vv);
         if (p16) {
             bf16x4_t w;
-            w[0] = (__bf16)pe[0]; w[1] = (__bf16)pe[1]; w[2] = (__bf16)pe[2]; w[3] = (__bf16)pe[3];
+            w[0] = (__bf16)pp[0]; w[1] = (__bf16)pp[1]; w[2] = (__bf16)pp[2]; w[3] = (__bf16)pp[3];
             reinterpret_cast<bf16x4_t*>(p16)[i] = w;
         }
     };
@@ -146,16 +160,14 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(UnivlAdam a, int c0, in
     // two vectors per thread per trip: all eight 16-byte loads are issued before the first store (p, m, v are read and
     // written through the same pointers, so the compiler cannot hoist the next trip's loads above this trip's stores)
     for (; i + 256 < nv; i += 512) {
-        const float4 p0 = reinterpret_cast<const float4*>(p)[i], p1 = reinterpret_cast<const float4*>(p)[i + 256];
-        const float4 g0 = reinterpret_cast<const float4*>(g)[i], g1 = reinterpret_cast<const float4*>(g)[i + 256];
-        const float4 m0 = reinterpret_cast<const float4*>(m)[i], m1 = reinterpret_cast<const float4*>(m)[i + 256];
-        const float4 v0 = reinterpret_cast<const float4*>(v)[i], v1 = reinterpret_cast<const float4*>(v)[i + 256];
+        const f32x4_t p0 = ld4<NT>(p, i), p1 = ld4<NT>(p, i + 256);
+        const f32x4_t g0 = ld4<NT>(g, i), g1 = ld4<NT>(g, i + 256);
+        const f32x4_t m0 = ld4<NT>(m, i), m1 = ld4<NT>(m, i + 256);
+        const f32x4_t v0 = ld4<NT>(v, i), v1 = ld4<NT>(v, i + 256);
         update(i, p0, g0, m0, v0);
         update(i + 256, p1, g1, m1, v1);
     }
-    for (; i < nv; i += 256)
-        update(i, reinterpret_cast<const float4*>(p)[i], reinterpret_cast<const float4*>(g)[i],
-               reinterpret_cast<const float4*>(m)[i], reinterpret_cast<const float4*>(v)[i]);
+    for (; i < nv; i += 256) update(i, ld4<NT>(p, i), ld4<NT>(g, i), ld4<NT>(m, i), ld4<NT>(v, i));
     for (int i = nv * 4 + threadIdx.x; i < len; i += 256) {
         const float gr = g[i] * gs;
         const float mi = m[i] * b1 + (1.0f - b1) * gr;
@@ -166,6 +178,11 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(UnivlAdam a, int c0, in
         if (p16) p16[i] = (__bf16)pi;
     }
   }
+}
+
+static inline bool adam_nt() {
+    static const int v = [] { const char* e = getenv("UNIVL_ADAM_NT"); return e ? atoi(e) : 0; }();
+    return v != 0;
 }
 
 __global__ __launch_bounds__(256) void cast_kernel(const float* p, __bf16* o, int64_t n) {
@@ -237,7 +254,8 @@ extern "C" int univl_bert_adam(const UnivlAdam* d, hipStream_t stream) {
                         d->sumsq && d->step && d->seg_scalars && d->nseg > 0 && d->nchunk > 0,
                     UNIVL_EINVAL, "univl_bert_adam: bad argument");
     hipLaunchKernelGGL(adam_prep_kernel, dim3((d->nseg + 255) / 256), dim3(256), 0, stream, *d);
-    hipLaunchKernelGGL(adam_apply_kernel, dim3(d->nchunk), dim3(256), 0, stream, *d, 0, d->nchunk);
+    if (adam_nt()) hipLaunchKernelGGL(adam_apply_kernel<true>, dim3(d->nchunk), dim3(256), 0, stream, *d, 0, d->nchunk);
+    else hipLaunchKernelGGL(adam_apply_kernel<false>, dim3(d->nchunk), dim3(256), 0, stream, *d, 0, d->nchunk);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
@@ -253,7 +271,8 @@ extern "C" int univl_bert_adam_range(const UnivlAdam* d, int32_t chunk_begin, in
     if (do_prep) hipLaunchKernelGGL(adam_prep_kernel, dim3((d->nseg + 255) / 256), dim3(256), 0, stream, *d);
     if (chunk_count > 0) {
         const int grid = (max_blocks > 0 && max_blocks < chunk_count) ? max_blocks : chunk_count;
-        hipLaunchKernelGGL(adam_apply_kernel, dim3(grid), dim3(256), 0, stream, *d, chunk_begin, chunk_begin + chunk_count);
+        if (adam_nt()) hipLaunchKernelGGL(adam_apply_kernel<true>, dim3(grid), dim3(256), 0, stream, *d, chunk_begin, chunk_begin + chunk_count);
+        else hipLaunchKernelGGL(adam_apply_kernel<false>, dim3(grid), dim3(256), 0, stream, *d, chunk_begin, chunk_begin + chunk_count);
     }
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;

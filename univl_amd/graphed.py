@@ -27,6 +27,13 @@ with the update capped at 256 workgroups: the forward is a chain of kernels boun
 stream that saturates HBM multiplies exactly those latencies -- what the overlap hides of the update it loses again in a
 slower forward.  Kept as a tested option, not the default.
 
+Early loss read-back (async_loss=True, default).  The reference's loop reads `float(loss)` every iteration
+(main_task_retrieval.py:344).  On a single captured graph that read waits for the WHOLE iteration, and the next replay is
+only launched afterwards: ~0.1 ms of idle GPU per iteration at 4 pairs per GPU.  The iteration is therefore captured as two
+graphs -- forward, and backward + clip + BertAdam -- both launched back to back; the loss is copied to pinned host memory on
+a copy stream right after the forward graph, and float(loss) waits for that copy only.  The host gets every iteration's loss
+before it continues, exactly as before, while the GPU is already running the backward and finds the next iteration queued.
+
 The first `warmup` calls run eagerly (they build the execution plans and the optimizer tables); the next call
 captures and runs; later calls only copy the new batch into the static input buffers and replay.
 """
@@ -39,7 +46,7 @@ from .steps import stage_input
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, max_grad_norm=1.0, warmup=3, persistent_inputs=True, pipeline_optimizer=False):
+    def __init__(self, model, optimizer, max_grad_norm=1.0, warmup=3, persistent_inputs=True, pipeline_optimizer=False, async_loss=True):
         """persistent_inputs=True: the tensors of the first captured call ARE the static input buffers when they live on
         the model's device (later calls may pass the same tensors refilled in place -- no copy -- or other tensors, e.g.
         the loader's host batch, which are copied in)."""
@@ -49,6 +56,9 @@ class GraphedTrainStep:
         self.persistent = bool(persistent_inputs)
         self.pipeline = bool(pipeline_optimizer) or os.environ.get("UNIVL_PIPELINE_OPT", "0") == "1"
         self.adam_blocks = int(os.environ.get("UNIVL_ADAM_BLOCKS", "0"))      # grid cap of the overlapped update (0: none)
+        self.async_loss = bool(async_loss) and os.environ.get("UNIVL_ASYNC_LOSS", "1") != "0"
+        self._copy_stream = self._loss_host = self._loss_ev = None
+        self._g_rest = None
         self.params = [p for p in model.parameters()]
         self.calls = 0
         self.mode = None                 # None (not captured) | "whole" | "segmented"
@@ -107,6 +117,20 @@ class GraphedTrainStep:
         """Apply the pending BertAdam update of the last iteration (pipelined mode); no-op otherwise."""
         self.opt.flush()
 
+    def _read_back_loss(self):
+        """Copy self.loss to pinned host memory on the copy stream, behind everything enqueued so far (= the forward)."""
+        cur = torch.cuda.current_stream()
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=cur.device)
+            self._loss_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+            self._loss_ev = torch.cuda.Event()
+        cs = self._copy_stream
+        cs.wait_stream(cur)
+        with torch.cuda.stream(cs):
+            self._loss_host.copy_(self.loss.detach().reshape(1), non_blocking=True)
+            self._loss_ev.record(cs)
+        self.loss.__dict__["_async"] = (self._loss_host, self._loss_ev)
+
     def _stage(self, args, kw):
         """Bring the new batch into the static input buffers the graphs read from."""
         if self._static_args is None:
@@ -146,9 +170,23 @@ class GraphedTrainStep:
             # clip; its BertAdam update rides with the next forward
             self.loss_eager = self._eager(sa, sk, defer=True)
             return self.loss_eager
+        if self._loss_ev is not None:
+            torch.cuda.current_stream().wait_event(self._loss_ev)     # the previous loss copy reads what this replay overwrites
         if self.mode is None:
             torch.cuda.synchronize()
-            if getattr(self.model, "_reducer", None) is None:
+            if getattr(self.model, "_reducer", None) is None and self.async_loss:
+                # two graphs from one memory pool: forward | backward + clip + BertAdam
+                self._g_fwd, self._g_rest = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._g_fwd):
+                    self.loss = self._forward_pipelined(sa, sk) if self.pipeline else self.model(*sa, **sk)
+                with torch.cuda.graph(self._g_rest, pool=self._g_fwd.pool()):
+                    self.loss.backward()
+                    self._clip_and_step(defer=self.pipeline)
+                    if self.pipeline:
+                        self.model._pending_update = self.opt
+                    self.opt.zero_grad()
+                self.mode = "whole"
+            elif getattr(self.model, "_reducer", None) is None:
                 self._g_all = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._g_all):
                     if self.pipeline:
@@ -166,9 +204,16 @@ class GraphedTrainStep:
                     self.loss = self._forward_pipelined(sa, sk) if self.pipeline else self.model(*sa, **sk)
                 self.mode = "segmented"
         if self.mode == "whole":
-            self._g_all.replay()
+            if self._g_rest is not None:
+                self._g_fwd.replay()
+                self._read_back_loss()
+                self._g_rest.replay()
+            else:
+                self._g_all.replay()
             return self.loss
         self._g_fwd.replay()
+        if self.async_loss:
+            self._read_back_loss()
         self.loss.backward()                 # captured segments + host-issued all-reduces + join (Plan.run_graphed)
         if self._g_opt is None:
             self._g_opt = torch.cuda.CUDAGraph()

@@ -349,7 +349,14 @@ class _LossTensor(torch.Tensor):
     def __float__(self):
         # `total_loss += float(loss)` (main_task_retrieval.py:344) on a tensor that requires grad: read the detached value
         # (same number, without torch's "converting a tensor with requires_grad=True to a scalar" warning every step)
+        a = self.__dict__.get("_async")
+        if a is not None:                  # univl_amd.graphed: the value was copied to pinned memory right after the forward;
+            a[1].synchronize()             # waiting for THAT copy does not wait for the backward / optimizer behind it
+            return float(a[0][0])
         return torch.Tensor.__float__(self.detach())
+
+    def item(self):
+        return float(self)
 
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
         ms = self.__dict__.get("_univl", None)
