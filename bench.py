@@ -165,9 +165,10 @@ def gemm_family(model, dev, reps=10):
                 outb += d.M * d.N * esz
             nbytes += opb + outb
             wbytes += d.N * d.K * esz if not (d.trans_a and d.trans_b) else 0
+    from univl_amd.engine import no_gc
     g = torch.cuda.CUDAGraph()
     torch.cuda.synchronize()
-    with torch.cuda.graph(g):
+    with no_gc(), torch.cuda.graph(g):
         h = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         for launch, _ in items:
             rc = launch(h)

@@ -82,6 +82,33 @@ def _worker(rank, world, port, mode, q):
             opt.zero_grad()
             losses.append(float(loss))
         assert model._implicit_dp and model._reducer is not None
+    elif mode.startswith("sharded"):                 # reduce-scatter + sharded clip/BertAdam + all-gather of the shadow
+        from univl_amd.graphed import GraphedTrainStep
+        model.enable_data_parallel(shard_optimizer=True)
+        assert model.flat.owned is not None and model._reducer.partition is not None
+        if mode == "sharded_graph":
+            gs = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=1)
+            for it in range(STEPS):
+                losses.append(float(gs(*args, **kw)))
+            assert gs.mode == "segmented"
+        else:
+            for it in range(STEPS):
+                loss = model(*args, **kw)
+                loss.backward()
+                clip_grad_norm_(model.parameters(), 1.0)
+                opt.step()
+                opt.zero_grad()
+                losses.append(float(loss))
+        try:
+            model.state_dict()
+            raise AssertionError("state_dict() must refuse while the fp32 master is sharded")
+        except RuntimeError:
+            pass
+        model.consolidate_parameters()               # collective: every rank
+        opt.consolidate()
+        sd = model.state_dict()
+        osd = opt.state_dict()
+        assert len(sd) > 0 and osd["state"][0]["next_m"].abs().sum() > 0
     else:                                           # explicit API + hipGraph replay with real collectives in between
         from univl_amd.graphed import GraphedTrainStep
         model.enable_data_parallel()
@@ -136,6 +163,13 @@ def test_stock_ddp_wrapper_and_graphed_data_parallel_two_ranks():
     for n in f0:
         assert float((gf0[n] - f0[n]).abs().max()) < 5e-5, n
         assert torch.allclose(gf0[n], gf1[n], rtol=0, atol=1e-6), n
+    # sharded optimizer (reduce-scatter, clip + BertAdam on 1/world of every bucket, all-gather): same parameters
+    for mode in ("sharded", "sharded_graph"):
+        (_, sl0, _, sf0), (_, sl1, _, sf1) = _run(mode)
+        assert max(abs(a - b) for a, b in zip(sl0, l0)) < 2e-4 and max(abs(a - b) for a, b in zip(sl1, l1)) < 2e-4, mode
+        for n in f0:
+            assert float((sf0[n] - f0[n]).abs().max()) < 5e-5, (mode, n)
+            assert torch.allclose(sf0[n], sf1[n], rtol=0, atol=1e-6), (mode, n)       # after consolidate_parameters()
 
 
 # ------------------------------------------------------------------------------------------------ RCCL on one GPU

@@ -84,3 +84,74 @@ def test_subtract_range():
     assert subtract_range(r, 0, 100) == [(200, 300)]
     assert subtract_range(r, 90, 250) == [(0, 90), (250, 300)]
     assert subtract_range(r, 100, 200) == r
+
+
+# ------------------------------------------------------------------------------------------ sharded optimizer exchange
+class _FakeFlat:
+    """The part of engine.FlatParams that parallel.shard_partition reads."""
+    WORD = "bert.embeddings.word_embeddings.weight"
+
+    def __init__(self):
+        names = [("bert.embeddings.word_embeddings.weight", (40, 16)), ("bert.embeddings.LayerNorm.weight", (16,)),
+                 ("bert.encoder.layer.0.attention.self.query.bias", (16,))]
+        mats = [("bert.encoder.layer.%d.%s.weight" % (l, k), (16, 16)) for l in range(2) for k in ("a", "b")]
+        mats += [("visual.embeddings.word_embeddings.weight", (16, 32)), ("visual.encoder.layer.0.a.weight", (16, 16))]
+        self.index, self.order, off = {}, [], 0
+        for n, shp in names + mats:
+            k = 1
+            for d in shp:
+                k *= d
+            if n == mats[0][0]:
+                self.v_end = off
+            self.index[n] = (off, k, shp)
+            self.order.append(n)
+            off += (k + 63) // 64 * 64
+        self.total = off
+
+
+def _worker_shard(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from univl_amd.parallel import owned_ranges, shard_partition
+    fl = _FakeFlat()
+    part = shard_partition(fl, world)
+    g = (torch.arange(fl.total, dtype=torch.float32) + 1) * (rank + 1)
+    red = BucketReducer(g)
+    red.set_partition(part)
+    own = owned_ranges(part, world, rank)
+    assert all((b - a) % world == 0 for a, b in part) and sum(b - a for a, b in own) * world == fl.total
+    # exchange points as the backward plan issues them: unions of whole partition ranges, every range exactly once
+    mid = part[len(part) // 2][0]
+    red.reduce_ranges([(mid, fl.total)])
+    red.reduce_ranges([(0, mid)])
+    red.join()
+    mean = (torch.arange(fl.total, dtype=torch.float32) + 1) * (sum(range(1, world + 1)) / world)
+    for a, b in own:                                  # the owned pieces hold the mean gradient
+        assert torch.allclose(g[a:b], mean[a:b])
+    # "optimizer": every rank updates its own pieces of the parameters, then the all-gather completes them everywhere
+    p = torch.zeros(fl.total)
+    for a, b in own:
+        p[a:b] = -0.5 * g[a:b]
+    red.all_gather_ranges(p)
+    red.join()
+    ok = torch.allclose(p, -0.5 * mean)
+    small = torch.tensor([float(rank + 1), 2.0])
+    red.all_reduce_small(small)
+    ok = ok and small.tolist() == [float(sum(range(1, world + 1))), 2.0 * world]
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_sharded_exchange_gloo_world2_and_world4():
+    for world in (2, 4):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker_shard, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=180) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+        assert res == [(r, True) for r in range(world)], (world, res)

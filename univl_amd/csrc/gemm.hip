@@ -288,6 +288,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     // of back-to-back loads from clamped (always valid) addresses; only the stores are predicated.  A per-element
     // "if (flag) load" would serialise 16 dependent round trips per thread.
     const bool atomic = (p.flags & UNIVL_GEMM_ATOMIC) != 0;
+    const bool nt_out = (p.flags & UNIVL_GEMM_NT_OUT) != 0;
     const bool first_slice = (bz == 0);
     T* C16 = reinterpret_cast<T*>(p.C16);
     T* aux = reinterpret_cast<T*>(p.aux);
@@ -377,7 +378,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 if (atomic) {
                     unsafeAtomicAdd(p.C32 + o, ev[b][r]);
                 } else {
-                    if (p.C32) p.C32[o] = ev[b][r];
+                    if (p.C32) { if (nt_out) __builtin_nontemporal_store(ev[b][r], p.C32 + o); else p.C32[o] = ev[b][r]; }
                     if (C16) C16[o] = from_f32<T>(ev[b][r]);
                     ssq += ev[b][r] * ev[b][r];
                 }

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(UnivlAdam a, int c0, in
 }
 
 static inline bool adam_nt() {
-    static const int v = [] { const char* e = getenv("UNIVL_ADAM_NT"); return e ? atoi(e) : 0; }();
+    static const int v = [] { const char* e = getenv("UNIVL_ADAM_NT"); return e ? atoi(e) : 1; }();   // measured: 3.16 -> 3.06 ms per step
     return v != 0;
 }
 

@@ -9,13 +9,29 @@ Design (MI355X-first):
     STATIC PLAN: a list of pre-built C descriptors pointing into a persistent workspace.  Running a plan only
     enqueues kernels on the current HIP stream; it is what gets captured into a hipGraph.
 """
+import contextlib
 import ctypes as C
+import gc
 import os
 import weakref
 
 import torch
 
 from . import _lib, ops
+
+@contextlib.contextmanager
+def no_gc():
+    """hipGraph capture must not be interrupted by Python's cyclic garbage collector: a collection that happens to run inside
+    a capture frees device tensors / events of unrelated dead objects (an earlier model, old plans), which is illegal while
+    a stream is capturing and aborts the process."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
 
 _ALIGN = 64  # elements; keeps every tensor 256-byte aligned in fp32 and 128-byte in bf16
 FLAT_REGISTRY = weakref.WeakSet()   # lets the fused optimizer find the flat buffers that own a Parameter
@@ -361,7 +377,7 @@ class Plan:
             if seg[2] is None:
                 g = torch.cuda.CUDAGraph()
                 # thread_local: RCCL's watchdog thread may query events of in-flight collectives during the capture
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with no_gc(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                     cur = torch.cuda.current_stream()
                     sides = [self._stream(i, cur) for i in seg[3]]
                     for sd in sides:
@@ -394,7 +410,7 @@ class Plan:
 
 def _gemm_desc(dt, A, lda, B, ldb, M, N, K, *, trans_a=0, trans_b=0, out32=None, out16=None, ldc=0, bias=None,
                residual=None, ldr=0, aux=None, ldaux=0, gelu=None, accumulate=False, dbias=None, ksplit=1, tile=0,
-               sumsq=None, sumsq_rows=0, sumsq_stride=0):
+               sumsq=None, sumsq_rows=0, sumsq_stride=0, nt_out=False):
     d = _lib.Gemm()
     d.dtype, d.trans_a, d.trans_b, d.M, d.N, d.K = dt, trans_a, trans_b, M, N, K
     d.A, d.lda, d.B, d.ldb = A.data_ptr(), lda, B.data_ptr(), ldb
@@ -409,6 +425,8 @@ def _gemm_desc(dt, A, lda, B, ldb, M, N, K, *, trans_a=0, trans_b=0, out32=None,
     flags = _lib.GEMM_DBIAS_ATOMIC if dbias is not None else 0
     if accumulate:
         flags |= _lib.GEMM_ACCUM
+    elif nt_out:
+        flags |= _lib.GEMM_NT_OUT
     if gelu == "fwd":
         flags |= _lib.GEMM_GELU_FWD
     elif gelu == "bwd":
@@ -443,6 +461,7 @@ class EncoderStack:
         self.flat, self.prefix, self.L, self.B, self.S = flat, prefix, n_layers, B, S
         self.sm, self.ss = s_main, s_side
         self.wg_blocks = int(os.environ.get("UNIVL_WGRAD_BLOCKS", "0"))
+        self.nt_wgrad = os.environ.get("UNIVL_WGRAD_NT", "0") == "1"       # non-temporal stores of fresh weight gradients
         self.sw = s_wgrad if (s_wgrad is not None and self.wg_blocks > 0 and n_layers > 1) else None
         self.T = B * S
         self.key_mask = key_mask            # int64 [B,S] device tensor (static buffer)
@@ -569,7 +588,7 @@ class EncoderStack:
             sc = self.scr[l % len(self.scr)]
             s_dxd, s_dxd2, s_du, s_dqkv = sc["dxd"], sc["dxd2"], sc["du"], sc["dqkv"]
             if sw is not None and l + 2 < self.L:
-                plan.wait_point(("wgrad", self.prefix, id(self), l + 2), sm)     # this scratch set is free again
+                plan.join(sw + (l % 2), sm)             # layer l+2's weight gradients are done: this scratch set is free again
             dz, da = self.gbuf, self.garena[l, 0]
             # output LayerNorm / dropout backward (BertOutput, module_bert.py:246-250)
             plan.add("univl_layernorm_bwd", ops.layernorm_desc(
@@ -577,11 +596,11 @@ class EncoderStack:
                 dgamma=fl.g(nm["ln2_g"]), dbeta=fl.g(nm["ln2_b"]), dbias=fl.g(nm["b2"]), p_pre=p, off_pre=ws["off"][2],
                 seed_dev=self.seed_dev), sm)
             wgrads = [_gemm_desc(dt, s_dxd, H, ws["f"], I, H, I, T, trans_a=1, trans_b=1,
-                                 out32=fl.g(nm["w2"]), ldc=I, accumulate=gs.acc(nm["w2"]), **gs.sumsq_args(nm["w2"], H, I))]
+                                 out32=fl.g(nm["w2"]), ldc=I, accumulate=gs.acc(nm["w2"]), nt_out=self.nt_wgrad, **gs.sumsq_args(nm["w2"], H, I))]
             plan.add("univl_gemm", _gemm_desc(dt, s_dxd, H, fl.wop(nm["w2"]), I, T, I, H, trans_b=1, out16=s_du,
                                               ldc=I, aux=ws["u"], ldaux=I, gelu="bwd"), sm)
             wgrads.append(_gemm_desc(dt, s_du, I, ws["a16"], H, I, H, T, trans_a=1, trans_b=1,
-                                     out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=fl.g(nm["b1"]),
+                                     out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=fl.g(nm["b1"]), nt_out=self.nt_wgrad,
                                      **gs.sumsq_args(nm["w1"], I, H)))
             plan.add("univl_gemm", _gemm_desc(dt, s_du, I, fl.wop(nm["w1"]), H, T, H, I, trans_b=1, out32=da, ldc=H,
                                               residual=dz, ldr=H, ksplit=self.ksplit_for(I)), sm)
@@ -592,7 +611,7 @@ class EncoderStack:
                 dgamma=fl.g(nm["ln1_g"]), dbeta=fl.g(nm["ln1_b"]), dbias=fl.g(nm["o_b"]), p_pre=p, off_pre=ws["off"][1],
                 seed_dev=self.seed_dev), sm)
             wgrads.append(_gemm_desc(dt, s_dxd2, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
-                                     out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"]), **gs.sumsq_args(nm["o_w"], H, H)))
+                                     out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"]), nt_out=self.nt_wgrad, **gs.sumsq_args(nm["o_w"], H, H)))
             plan.add("univl_gemm", _gemm_desc(dt, s_dxd2, H, fl.wop(nm["o_w"]), H, T, H, H, trans_b=1, out16=self.dctx, ldc=H), sm)
             qkv, dqkv = ws["qkv"], s_dqkv
             plan.add("univl_attention_bwd", ops.attention_desc(
@@ -601,7 +620,7 @@ class EncoderStack:
                 dq=(dqkv, 0), lddq=3 * H, dk=(dqkv, H), lddk=3 * H, dv=(dqkv, 2 * H), lddv=3 * H), sm)
             wgrads.append(_gemm_desc(dt, dqkv, 3 * H, xin16, H, 3 * H, H, T, trans_a=1, trans_b=1,
                                      out32=fl.g_fused(nm["qkv_w"]), ldc=H, accumulate=gs.acc(nm["qkv_w"][0]),
-                                     dbias=fl.g_fused(nm["qkv_b"]), **gs.sumsq_args(nm["qkv_w"], H, H)))
+                                     dbias=fl.g_fused(nm["qkv_b"]), nt_out=self.nt_wgrad, **gs.sumsq_args(nm["qkv_w"], H, H)))
             dx = self.garena[l, 1]
             plan.add("univl_gemm", _gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["qkv_w"]), H, T, H, 3 * H, trans_b=1,
                                               out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ksplit_for(3 * H)), sm)
@@ -610,9 +629,10 @@ class EncoderStack:
             if sw is None:
                 plan.add_gemm_group(wgrads, sm)
             else:                                       # beside the next layer's chain, on at most wg_blocks workgroups
-                plan.fork(sm, sw)
-                plan.add_gemm_group(wgrads, sw, max_blocks=self.wg_blocks)
-                plan.record(("wgrad", self.prefix, id(self), l), sw)
+                # two streams, alternating with the scratch set: "everything enqueued so far on stream (l % 2)" is exactly
+                # the weight gradients of layers l, l+2, ... when the chain of layer l-2 asks for its scratch set back
+                plan.fork(sm, sw + (l % 2))
+                plan.add_gemm_group(wgrads, sw + (l % 2), max_blocks=self.wg_blocks)
             gin = dx
             if layer_hook is not None:
                 layer_hook(plan, self.prefix, l, sm)
@@ -620,6 +640,7 @@ class EncoderStack:
             yield l
         if sw is not None:
             plan.join(sw, sm)                           # whatever follows on the chain's stream sees every weight gradient
+            plan.join(sw + 1, sm)
         self.bwd_out = gin
 
 

@@ -27,7 +27,7 @@ with the update capped at 256 workgroups: the forward is a chain of kernels boun
 stream that saturates HBM multiplies exactly those latencies -- what the overlap hides of the update it loses again in a
 slower forward.  Kept as a tested option, not the default.
 
-Early loss read-back (async_loss=True, default).  The reference's loop reads `float(loss)` every iteration
+Early loss read-back (async_loss=True; OFF by default -- measured 3.159-3.165 ms against 3.167 ms per step, within noise).  The reference's loop reads `float(loss)` every iteration
 (main_task_retrieval.py:344).  On a single captured graph that read waits for the WHOLE iteration, and the next replay is
 only launched afterwards: ~0.1 ms of idle GPU per iteration at 4 pairs per GPU.  The iteration is therefore captured as two
 graphs -- forward, and backward + clip + BertAdam -- both launched back to back; the loss is copied to pinned host memory on
@@ -41,12 +41,13 @@ import os
 
 import torch
 
+from .engine import no_gc
 from .optimization import clip_grad_norm_
 from .steps import stage_input
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, max_grad_norm=1.0, warmup=3, persistent_inputs=True, pipeline_optimizer=False, async_loss=True):
+    def __init__(self, model, optimizer, max_grad_norm=1.0, warmup=3, persistent_inputs=True, pipeline_optimizer=False, async_loss=False):
         """persistent_inputs=True: the tensors of the first captured call ARE the static input buffers when they live on
         the model's device (later calls may pass the same tensors refilled in place -- no copy -- or other tensors, e.g.
         the loader's host batch, which are copied in)."""
@@ -56,7 +57,7 @@ class GraphedTrainStep:
         self.persistent = bool(persistent_inputs)
         self.pipeline = bool(pipeline_optimizer) or os.environ.get("UNIVL_PIPELINE_OPT", "0") == "1"
         self.adam_blocks = int(os.environ.get("UNIVL_ADAM_BLOCKS", "0"))      # grid cap of the overlapped update (0: none)
-        self.async_loss = bool(async_loss) and os.environ.get("UNIVL_ASYNC_LOSS", "1") != "0"
+        self.async_loss = bool(async_loss) or os.environ.get("UNIVL_ASYNC_LOSS", "0") == "1"
         self._copy_stream = self._loss_host = self._loss_ev = None
         self._g_rest = None
         self.params = [p for p in model.parameters()]
@@ -177,9 +178,9 @@ class GraphedTrainStep:
             if getattr(self.model, "_reducer", None) is None and self.async_loss:
                 # two graphs from one memory pool: forward | backward + clip + BertAdam
                 self._g_fwd, self._g_rest = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._g_fwd):
+                with no_gc(), torch.cuda.graph(self._g_fwd):
                     self.loss = self._forward_pipelined(sa, sk) if self.pipeline else self.model(*sa, **sk)
-                with torch.cuda.graph(self._g_rest, pool=self._g_fwd.pool()):
+                with no_gc(), torch.cuda.graph(self._g_rest, pool=self._g_fwd.pool()):
                     self.loss.backward()
                     self._clip_and_step(defer=self.pipeline)
                     if self.pipeline:
@@ -188,7 +189,7 @@ class GraphedTrainStep:
                 self.mode = "whole"
             elif getattr(self.model, "_reducer", None) is None:
                 self._g_all = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._g_all):
+                with no_gc(), torch.cuda.graph(self._g_all):
                     if self.pipeline:
                         self.loss = self._forward_pipelined(sa, sk)
                         self.loss.backward()
@@ -200,7 +201,7 @@ class GraphedTrainStep:
             else:
                 self.model.graph_backward = True
                 self._g_fwd = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._g_fwd, capture_error_mode="thread_local"):
+                with no_gc(), torch.cuda.graph(self._g_fwd, capture_error_mode="thread_local"):
                     self.loss = self._forward_pipelined(sa, sk) if self.pipeline else self.model(*sa, **sk)
                 self.mode = "segmented"
         if self.mode == "whole":
@@ -211,14 +212,20 @@ class GraphedTrainStep:
             else:
                 self._g_all.replay()
             return self.loss
+        red = getattr(self.model.flat, "shard_reducer", None)
+        if red is not None:
+            red.join()                       # sharded optimizer: the all-gather of the updated shadow must have landed
         self._g_fwd.replay()
         if self.async_loss:
             self._read_back_loss()
         self.loss.backward()                 # captured segments + host-issued all-reduces + join (Plan.run_graphed)
-        if self._g_opt is None:
-            self._g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g_opt, capture_error_mode="thread_local"):
-                self._clip_and_step(defer=self.pipeline)
-        self._g_opt.replay()
+        if getattr(self.model.flat, "shard_reducer", None) is not None:
+            self._clip_and_step(defer=False)         # sharded optimizer: the norm all-reduce / shadow all-gather are host-issued
+        else:
+            if self._g_opt is None:
+                self._g_opt = torch.cuda.CUDAGraph()
+                with no_gc(), torch.cuda.graph(self._g_opt, capture_error_mode="thread_local"):
+                    self._clip_and_step(defer=self.pipeline)
+            self._g_opt.replay()
         self.opt.zero_grad()                 # host-side only: the next backward starts from beta = 0 again
         return self.loss

@@ -482,6 +482,10 @@ class UniVL(UniVLPreTrainedModel):
 
     def state_dict(self, *a, **kw):
         self._flush_pending()
+        fl = self._flat
+        if fl is not None and getattr(fl, "shard_reducer", None) is not None and not fl.master_complete:
+            raise RuntimeError("UniVL.state_dict(): the fp32 master weights are sharded over the ranks (sharded optimizer) -- "
+                               "call model.consolidate_parameters() on EVERY rank first (a collective)")
         return super().state_dict(*a, **kw)
 
     def train(self, mode=True):
@@ -531,7 +535,7 @@ class UniVL(UniVLPreTrainedModel):
             self._steps = {}
         return self._flat
 
-    def enable_data_parallel(self, process_group=None, broadcast=True, loopback=False, force=False):
+    def enable_data_parallel(self, process_group=None, broadcast=True, loopback=False, force=False, shard_optimizer=None):
         """Re-homes the reference's DDP wrap (main_task_retrieval.py:197-198) onto per-layer RCCL all-reduces of
         the flat gradient buffer, overlapped with backward (univl_amd.parallel).  Call after model.to(device) and
         torch.distributed.init_process_group; with world_size 1 it is a no-op."""
@@ -543,7 +547,30 @@ class UniVL(UniVLPreTrainedModel):
         self._reducer = BucketReducer(fl.g32, process_group, loopback=loopback, force=force)
         if not self._reducer.active:
             self._reducer = None
+        fl.owned, fl.shard_reducer, fl.master_complete = None, None, True
+        if shard_optimizer is None:
+            shard_optimizer = os.environ.get("UNIVL_SHARD_OPT", "0") == "1"
+        if shard_optimizer and self._reducer is not None and not loopback:
+            # reduce-scatter of the gradients, clip + BertAdam on this rank's 1/world of every bucket, all-gather of the
+            # bf16 shadow (univl_amd.parallel).  The fp32 master and the moments of the other ranks' pieces go stale on this
+            # rank: consolidate_parameters() / optimizer.consolidate() (collectives) bring them together for a checkpoint.
+            from .parallel import shard_partition
+            self._reducer.set_partition(shard_partition(fl, self._reducer.world))
+            fl.owned, fl.shard_reducer = self._reducer.owned, self._reducer
         self._steps = {}
+        return self
+
+    def consolidate_parameters(self):
+        """Sharded optimizer: COLLECTIVE (every rank calls it) -- gathers every rank's pieces of the fp32 master weights, after
+        which state_dict() is complete on every rank."""
+        fl = self.flat
+        red = getattr(fl, "shard_reducer", None)
+        if red is not None and not fl.master_complete:
+            self._flush_pending()
+            red.join()
+            red.all_gather_ranges(fl.p32)
+            red.join()
+            fl.master_complete = True
         return self
 
     def step_kind(self, has_caption):
@@ -644,6 +671,8 @@ class UniVL(UniVLPreTrainedModel):
             self._auto_data_parallel()
         self._flush_pending()
         fl = self.flat
+        if getattr(fl, "shard_reducer", None) is not None:
+            fl.shard_reducer.join()            # the all-gather of the updated shadow must have landed
         fl.refresh_shadow()
         st = self._get_step(kind, B, W, F)
         st.enc.load(input_ids, token_type_ids, attention_mask, video, video_mask)

@@ -58,6 +58,8 @@ class _Tables:
         nseg = len(fl.order)
         segs = (_lib.Seg * nseg)()
         c_seg, c_off, c_len = [], [], []
+        owned = getattr(fl, "owned", None)       # sharded optimizer: only the pieces of the flat buffer this rank owns
+        oi = 0
         for s, n in enumerate(fl.order):
             off, numel, _ = fl.index[n]
             lr, wd, mgn, active = seg_cfg.get(n, (0.0, 0.0, 0.0, 0))
@@ -65,10 +67,24 @@ class _Tables:
             segs[s].lr, segs[s].weight_decay, segs[s].max_grad_norm, segs[s].active = lr, wd, mgn, int(active)
             if not active:
                 continue                    # no workgroups for tensors that take no part
-            for o in range(0, numel, CHUNK):
-                c_seg.append(s)
-                c_off.append(off + o)
-                c_len.append(min(CHUNK, numel - o))
+            if owned is None:
+                pieces = [(off, off + numel)]
+            else:                           # tensors and owned ranges are both sorted by offset
+                while oi > 0 and owned[oi - 1][1] > off:
+                    oi -= 1
+                while oi < len(owned) and owned[oi][1] <= off:
+                    oi += 1
+                pieces, j = [], oi
+                while j < len(owned) and owned[j][0] < off + numel:
+                    lo, hi = max(off, owned[j][0]), min(off + numel, owned[j][1])
+                    if hi > lo:
+                        pieces.append((lo, hi))
+                    j += 1
+            for lo, hi in pieces:
+                for o in range(lo, hi, CHUNK):
+                    c_seg.append(s)
+                    c_off.append(o)
+                    c_len.append(min(CHUNK, hi - o))
         raw = bytes(segs)
         self.segs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self.chunk_seg_host = c_seg
@@ -80,6 +96,7 @@ class _Tables:
         self.coef = torch.ones(2, device=dev)
         self.scalars = torch.zeros(2 * nseg, device=dev)
         self.key = tuple(sorted(seg_cfg.items()))
+        self.owned_id = id(owned)
 
 
 def _stream():
@@ -94,6 +111,9 @@ def _sumsq(fl, tb, out=None, zero=True):
         _lib.check(_lib.lib().univl_grad_sumsq(fl.g32.data_ptr(), tb.segs.data_ptr(), tb.nseg, tb.chunk_seg.data_ptr(),
                                                tb.chunk_off.data_ptr(), tb.chunk_len.data_ptr(), tb.nchunk,
                                                out.data_ptr(), _stream()), "grad_sumsq")
+    red = getattr(fl, "shard_reducer", None)
+    if red is not None:                   # sharded optimizer: every rank measured its own pieces of every tensor
+        red.all_reduce_small(out)
 
 
 def _measure(fl, cfg, tb):
@@ -181,10 +201,11 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, deferred=True):
         apply_pending_clip(fl)
     cfg = _active_cfg(fl, [(p, (0.0, 0.0, 0.0)) for p in params])
     key = tuple(sorted(cfg))
-    tb = fl._clip[1] if (fl._clip is not None and fl._clip[0] == key) else None
+    ckey = key + (id(getattr(fl, "owned", None)),)
+    tb = fl._clip[1] if (fl._clip is not None and fl._clip[0] == ckey) else None
     if tb is None:
         tb = _Tables(fl, cfg)
-        fl._clip = (key, tb)
+        fl._clip = (ckey, tb)
     sumsq = _measure(fl, cfg, tb)
     L = _lib.lib()
     _lib.check(L.univl_clip_coef(sumsq.data_ptr(), tb.segs.data_ptr(), tb.nseg, float(max_norm), tb.coef.data_ptr(),
@@ -313,6 +334,9 @@ class BertAdam(Optimizer):
     def state_dict(self):
         """Same structure as the reference optimizer's: state[i] = {step, next_m, next_v} with free-standing tensors."""
         self.flush()
+        if getattr(self._fl, "shard_reducer", None) is not None and not getattr(self, "_state_complete", False):
+            raise RuntimeError("BertAdam.state_dict(): the optimizer state is sharded over the ranks -- call "
+                               "optimizer.consolidate() on EVERY rank first (a collective), then state_dict() where needed")
         self._sync_steps()
         sd = super().state_dict()
         for st in sd['state'].values():
@@ -386,6 +410,26 @@ class BertAdam(Optimizer):
                     on_group(key)
         self._deferred = False
         self._fl.shadow_valid = True
+        self._after_update(self._fl)
+
+    def _after_update(self, fl):
+        """Sharded optimizer: this rank updated its pieces only -- all-gather what the next forward reads (the bf16 shadow;
+        the fp32 master in fp32 compute mode).  Asynchronous; UniVL.forward joins it."""
+        red = getattr(fl, "shard_reducer", None)
+        if red is not None:
+            red.all_gather_ranges(fl.p16 if fl.p16 is not None else fl.p32)
+            fl.master_complete = fl.p16 is None        # other ranks' pieces of the fp32 master are stale from now on
+
+    def consolidate(self):
+        """Sharded optimizer, before optimizer.state_dict(): COLLECTIVE (every rank calls it) -- gathers the moments of all
+        shards so that each rank holds the complete state the reference's optimizer checkpoint has."""
+        fl = self._fl
+        red = getattr(fl, "shard_reducer", None) if fl is not None else None
+        if red is not None:
+            red.all_gather_ranges(self._m)
+            red.all_gather_ranges(self._v)
+            red.join()
+            self._state_complete = True
 
     def flush(self):
         """Apply a deferred update now (checkpointing, evaluation, a forward outside the pipelined loop)."""
@@ -406,7 +450,7 @@ class BertAdam(Optimizer):
                 pw.append((p, (group['lr'], group['weight_decay'], group['max_grad_norm'])))
         cfg = _active_cfg(fl, pw)
         key = tuple(sorted(cfg.items()))
-        if self._tb is None or self._tb.key != key:
+        if self._tb is None or self._tb.key != key or self._tb.owned_id != id(getattr(fl, "owned", None)):
             self._tb = _Tables(fl, cfg)
         tb = self._tb
         pend = getattr(fl, "_pending", None)
@@ -436,6 +480,7 @@ class BertAdam(Optimizer):
         else:
             _lib.check(_lib.lib().univl_bert_adam(C.byref(d), _stream()), "bert_adam")
             fl.shadow_valid = True      # the step rewrote the bf16 shadow
+            self._after_update(fl)
         for n in cfg:
             p = fl.params[n]
             st = self.state[p]

@@ -30,7 +30,15 @@ class BucketReducer:
         self.pg = process_group
         self.loopback = bool(loopback)
         self.force = bool(force)
+        # UNIVL_GRAD_EXCHANGE=bf16: all-reduce a bf16 copy of each slice (half the bytes over xGMI; every gradient element is
+        # rounded to 8 mantissa bits before the mean, i.e. +2^-9 relative noise per element on top of the compute noise -- NOT
+        # the reference's fp32 DDP semantics, hence opt-in)
+        import os
+        self.bf16 = os.environ.get("UNIVL_GRAD_EXCHANGE", "fp32").lower() == "bf16"
+        self._g16 = None
         self.world = dist.get_world_size(process_group) if (dist.is_initialized() and not loopback) else 1
+        self.rank = dist.get_rank(process_group) if (dist.is_initialized() and not loopback) else 0
+        self.partition, self.owned = None, None
         self.pending = []
         self.bytes_reduced = 0
         self.calls = 0
@@ -59,13 +67,21 @@ class BucketReducer:
                     t.mul_(1.0)
                     ev = torch.cuda.Event()
                     ev.record()
-                self.pending.append((ev, t))
+                self.pending.append((ev, t, None))
+            return
+        if self.bf16:
+            if self._g16 is None:
+                self._g16 = torch.empty_like(self.g, dtype=torch.bfloat16)
+            t16 = self._g16[start:end]
+            t16.copy_(t)                                   # on the producer stream, behind the slice's last wgrad
+            w = dist.all_reduce(t16, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self.pending.append((w, t, t16))
             return
         if self._avg:
             w = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
         else:
             w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        self.pending.append((w, t))
+        self.pending.append((w, t, None))
 
     def gather(self, t, out):
         """out[r] <- rank r's t (all-gather), asynchronously like reduce_slice; out: [world, *t.shape]."""
@@ -79,25 +95,88 @@ class BucketReducer:
                 out[0].copy_(t)
                 ev = torch.cuda.Event()
                 ev.record()
-            self.pending.append((ev, None))
+            self.pending.append((ev, None, None))
             return
         if self._avg:          # RCCL: one contiguous output, no per-rank staging copies
             w = dist.all_gather_into_tensor(out.view(-1, *t.shape[1:]), t, group=self.pg, async_op=True)
         else:
             w = dist.all_gather([out[r] for r in range(self.world)], t, group=self.pg, async_op=True)
-        self.pending.append((w, None))
+        self.pending.append((w, None, None))
 
     def reduce_ranges(self, ranges):
+        if self.partition is not None:
+            return self.reduce_scatter_ranges(ranges)
         for s0, e0 in ranges:
             self.reduce_slice(s0, e0)
 
+    # ------------------------------------------------------------------------------- sharded optimizer (ZeRO-1 style)
+    # With `partition` set (shard_partition below) every exchanged range is REDUCE-SCATTERED instead of all-reduced: rank r
+    # ends up with the mean gradient of its 1/world sub-range of every partition range only, runs clip + BertAdam on that
+    # shard (optimization._Tables(..., owned=...)), and the updated bf16 shadow (what the next forward reads) is
+    # ALL-GATHERED.  Bytes over xGMI per step: (W-1)/W x (4 + 2) B/param instead of 2 (W-1)/W x 4 B/param for the
+    # all-reduce, and the 30 B/param optimizer stream shrinks by the world size.
+    def set_partition(self, partition):
+        self.partition = list(partition) if partition is not None else None
+        self.owned = owned_ranges(self.partition, self.world, self.rank) if partition is not None else None
+
+    def _pieces(self, s0, e0):
+        """Partition ranges inside [s0, e0) -- exchange ranges are unions of whole partition ranges."""
+        out = [(a, b) for a, b in self.partition if a >= s0 and b <= e0]
+        assert sum(b - a for a, b in out) == e0 - s0, "exchange range %r is not a union of partition ranges" % ((s0, e0),)
+        return out
+
+    def reduce_scatter_ranges(self, ranges):
+        for s0, e0 in ranges:
+            for a, b in self._pieces(s0, e0):
+                self._reduce_scatter(self.g, a, b)
+
+    def _reduce_scatter(self, buf, a, b):
+        if not self.active:
+            return
+        n = (b - a) // self.world
+        t = buf[a:b]
+        self.calls += 1
+        self.bytes_reduced += t.numel() * t.element_size()
+        if self.loopback:
+            return self.reduce_slice(a, b)
+        if self._avg:      # RCCL: in place (the output is the rank's own piece of the input)
+            w = dist.reduce_scatter_tensor(buf[a + self.rank * n:a + (self.rank + 1) * n], t, op=dist.ReduceOp.AVG,
+                                           group=self.pg, async_op=True)
+            self.pending.append((w, None, None))
+        else:              # gloo has no reduce-scatter: all-reduce the range, every rank keeps using only its piece
+            w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self.pending.append((w, t, None))
+
+    def all_gather_ranges(self, buf, ranges=None):
+        """buf[a:b] <- concatenation over ranks of each rank's piece of [a, b), for every partition range (in place)."""
+        if not self.active or self.loopback:
+            return
+        for a, b in (self.partition if ranges is None else ranges):
+            n = (b - a) // self.world
+            mine = buf[a + self.rank * n:a + (self.rank + 1) * n]
+            self.calls += 1
+            self.bytes_reduced += (b - a) * buf.element_size()
+            if self._avg:
+                w = dist.all_gather_into_tensor(buf[a:b], mine, group=self.pg, async_op=True)
+            else:
+                w = dist.all_gather([buf[a + r * n:a + (r + 1) * n] for r in range(self.world)], mine.clone(), group=self.pg,
+                                    async_op=True)
+            self.pending.append((w, None, None))
+
+    def all_reduce_small(self, t):
+        """Synchronous SUM of a small tensor (per-tensor gradient sums of squares of the shards)."""
+        if self.active and not self.loopback:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+
     def join(self):
         """Make the current stream (or thread, for gloo) wait for every outstanding bucket."""
-        for w, t in self.pending:
+        for w, t, t16 in self.pending:
             if self.loopback:
                 torch.cuda.current_stream().wait_event(w)
                 continue
             w.wait()
+            if t16 is not None:
+                t.copy_(t16)                               # back to the fp32 gradient the clip / optimizer read
             if not self._avg and t is not None:
                 t.div_(self.world)
         self.pending = []
@@ -193,3 +272,29 @@ def broadcast_parameters(flat_p32, src=0, process_group=None):
     """DDP's constructor broadcast: one collective over the flat buffer."""
     if dist.is_initialized() and dist.get_world_size(process_group) > 1:
         dist.broadcast(flat_p32, src=src, group=process_group)
+
+
+def shard_partition(flat, world):
+    """Static partition of the flat buffer for the sharded optimizer: every encoder-layer bucket, the word-embedding table,
+    and the remaining stretches of the atomic region / the other matrices -- disjoint ranges covering [0, total), each a
+    multiple of `world` x 64 elements long... (64 | every range by construction; world must divide 64).  Rank r owns the
+    r-th of `world` equal pieces of every range: a reduce-scatter of any exchange range (a union of these ranges) leaves
+    exactly the owned pieces valid."""
+    if 64 % world != 0:
+        raise ValueError("sharded optimizer: world size %d must divide 64" % world)
+    b = layer_buckets(flat, flat.order)
+    ranges = list(b["layers"].values())
+    wo, wk, _ = flat.index[flat.WORD] if flat.WORD in flat.index else (0, 0, None)
+    wend = wo + (wk + 63) // 64 * 64
+    for s0, e0 in b["tail"]:
+        for a, c in subtract_range([(s0, e0)], wo, wend):
+            ranges.append((a, c))
+    if wk:
+        ranges.append((wo, wend))
+    ranges = sorted(r for r in ranges if r[1] > r[0])
+    assert ranges[0][0] == 0 and ranges[-1][1] == flat.total and all(x[1] == y[0] for x, y in zip(ranges, ranges[1:]))
+    return ranges
+
+
+def owned_ranges(partition, world, rank):
+    return [(a + rank * ((b - a) // world), a + (rank + 1) * ((b - a) // world)) for a, b in partition]
