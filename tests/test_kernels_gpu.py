@@ -168,6 +168,16 @@ def test_gemm_group_wgrads(dtype, T):
     for db, dY in dbs:
         if db is not None:
             assert rel_err(db, dY.double().cpu().sum(0)) < (1e-5 if dtype == torch.float32 else 2e-3)
+    # the same launch on a capped grid (univl_gemm_group_limited: the workgroups walk the tiles): identical results
+    for k, dW in enumerate(outs):
+        dW.fill_(1.0 if k == 1 else 0.0)
+    for db, _ in dbs:
+        if db is not None:
+            db.zero_()
+    ops.gemm_group(descs, max_blocks=96)
+    for k, dW in enumerate(outs):
+        if not (k == 2 and T > 256):
+            assert torch.equal(dW, singles[k]), ("capped grid", k)
     with pytest.raises(RuntimeError):
         ops.gemm_group(descs + descs[:1])                  # more than GEMM_GROUP_MAX members
     mixed = [descs[0], ops.gemm_desc(dbs[0][1], dbs[0][1], 4, 4, 64, out32=torch.zeros(4, 4, device=DEV))]

@@ -455,13 +455,15 @@ class EncoderStack:
 
     def __init__(self, flat, prefix, n_layers, B, S, key_mask, p_drop, seed_dev, sites, splitk=True, s_main=0, s_side=1,
                  s_wgrad=None):
-        """s_wgrad: stream index for "background" weight gradients (None: they run in the chain).  With it, a layer's
-        grouped weight-gradient launch is capped at UNIVL_WGRAD_BLOCKS workgroups and runs on that stream beside the
-        NEXT layer's dgrad chain; the four operands it reads live in two alternating scratch sets."""
+        """s_wgrad / UNIVL_WGRAD_BLOCKS (EXPERIMENTAL, off): "background" weight gradients -- a layer's grouped weight-gradient
+        launch capped at that many workgroups on two alternating side streams beside the next layer's dgrad chain, its four
+        operands in two alternating scratch sets.  Runs correctly when enqueued directly; capturing that fork / join
+        pattern into a hipGraph crashes inside hipStreamEndCapture on ROCm 7.0.2 (profiles/README.md, round 2), and the
+        step is only fast as a graph, so it stays off."""
         self.flat, self.prefix, self.L, self.B, self.S = flat, prefix, n_layers, B, S
         self.sm, self.ss = s_main, s_side
         self.wg_blocks = int(os.environ.get("UNIVL_WGRAD_BLOCKS", "0"))
-        self.nt_wgrad = os.environ.get("UNIVL_WGRAD_NT", "0") == "1"       # non-temporal stores of fresh weight gradients
+        self.nt_wgrad = os.environ.get("UNIVL_WGRAD_NT", "0") == "1"       # non-temporal stores of fresh weight gradients (A/B: no gain)
         self.sw = s_wgrad if (s_wgrad is not None and self.wg_blocks > 0 and n_layers > 1) else None
         self.T = B * S
         self.key_mask = key_mask            # int64 [B,S] device tensor (static buffer)

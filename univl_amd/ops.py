@@ -85,10 +85,11 @@ def gemm(A, B, M, N, K, **kw):
     _lib.check(_lib.lib().univl_gemm(_BYREF(d), _stream()), "gemm")
 
 
-def gemm_group(descs):
-    """Independent GEMMs (same dtype and operand layouts, at most GEMM_GROUP_MAX) in one launch."""
+def gemm_group(descs, max_blocks=0):
+    """Independent GEMMs (same dtype and operand layouts, at most GEMM_GROUP_MAX) in one launch; max_blocks > 0 caps the
+    grid (the kernel walks its tiles)."""
     arr = (_lib.Gemm * len(descs))(*descs)
-    _lib.check(_lib.lib().univl_gemm_group(arr, len(descs), _stream()), "gemm_group")
+    _lib.check(_lib.lib().univl_gemm_group_limited(arr, len(descs), int(max_blocks), _stream()), "gemm_group")
 
 
 def layernorm_desc(dtype, rows, N, *, x=None, x_f64=False, residual=None, pos=None, pos_period=0, gamma=None,

@@ -419,6 +419,7 @@ class BertAdam(Optimizer):
         if red is not None:
             red.all_gather_ranges(fl.p16 if fl.p16 is not None else fl.p32)
             fl.master_complete = fl.p16 is None        # other ranks' pieces of the fp32 master are stale from now on
+            self._state_complete = False               # ... and so are their pieces of the moments
 
     def consolidate(self):
         """Sharded optimizer, before optimizer.state_dict(): COLLECTIVE (every rank calls it) -- gathers the moments of all
