@@ -454,8 +454,13 @@ class EncoderStack:
     H, NH, I = 768, 12, 3072
 
     def __init__(self, flat, prefix, n_layers, B, S, key_mask, p_drop, seed_dev, sites, splitk=True, s_main=0, s_side=1,
-                 s_wgrad=None):
-        """s_wgrad / UNIVL_WGRAD_BLOCKS (EXPERIMENTAL, off): "background" weight gradients -- a layer's grouped weight-gradient
+                 s_wgrad=None, s_offload=None, n_offload=0):
+        """s_offload / n_offload: the grouped weight-gradient launch of the first n_offload layers to be processed (the LAST
+        layers of the stack) is enqueued on stream s_offload -- the other encoder stack's stream, which has slack: the video
+        stack is half as deep as the text stack -- instead of the stack's own chain.  Those layers keep their four wgrad
+        operands in buffers of their own (nothing waits for a scratch set to be free again).
+
+        s_wgrad / UNIVL_WGRAD_BLOCKS (EXPERIMENTAL, off): "background" weight gradients -- a layer's grouped weight-gradient
         launch capped at that many workgroups on two alternating side streams beside the next layer's dgrad chain, its four
         operands in two alternating scratch sets.  Runs correctly when enqueued directly; capturing that fork / join
         pattern into a hipGraph crashes inside hipStreamEndCapture on ROCm 7.0.2 (profiles/README.md, round 2), and the
@@ -465,6 +470,8 @@ class EncoderStack:
         self.wg_blocks = int(os.environ.get("UNIVL_WGRAD_BLOCKS", "0"))
         self.nt_wgrad = os.environ.get("UNIVL_WGRAD_NT", "0") == "1"       # non-temporal stores of fresh weight gradients (A/B: no gain)
         self.sw = s_wgrad if (s_wgrad is not None and self.wg_blocks > 0 and n_layers > 1) else None
+        self.s_off = s_offload if (s_offload is not None and n_offload > 0 and self.sw is None) else None
+        self.n_off = min(int(n_offload), n_layers) if self.s_off is not None else 0
         self.T = B * S
         self.key_mask = key_mask            # int64 [B,S] device tensor (static buffer)
         self.p = float(p_drop)
@@ -493,7 +500,7 @@ class EncoderStack:
         # projection (separate buffers: the four wgrads of a layer are one grouped launch), du, dqkv.  Two sets when the
         # weight gradients of layer l run while layer l-1's chain already produces its own.
         self.scr = [dict(dxd=e(T, H, dtype=ct), dxd2=e(T, H, dtype=ct), du=e(T, I, dtype=ct), dqkv=e(T, 3 * H, dtype=ct))
-                    for _ in range(2 if self.sw is not None else 1)]
+                    for _ in range(2 if self.sw is not None else 1 + self.n_off)]
         # split-K for the N=768 products when the grid would not fill the chip: ~3 K-steps of 128 per workgroup
         self.tiles = ((T + 63) // 64) * (H // 64)
         self.splitk = splitk and self.tiles < 128
@@ -587,7 +594,8 @@ class EncoderStack:
         for l in range(self.L - 1, -1, -1):
             ws, nm = self.layers[l], self._names(l)
             xin32, xin16 = (x0_32, x0_16) if l == 0 else (self.layers[l - 1]["o32"], self.layers[l - 1]["o16"])
-            sc = self.scr[l % len(self.scr)]
+            off = self.s_off is not None and (self.L - 1 - l) < self.n_off       # this layer's wgrads go to the other stream
+            sc = self.scr[1 + (self.L - 1 - l)] if off else self.scr[l % len(self.scr) if sw is not None else 0]
             s_dxd, s_dxd2, s_du, s_dqkv = sc["dxd"], sc["dxd2"], sc["du"], sc["dqkv"]
             if sw is not None and l + 2 < self.L:
                 plan.join(sw + (l % 2), sm)             # layer l+2's weight gradients are done: this scratch set is free again
@@ -628,7 +636,10 @@ class EncoderStack:
                                               out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ksplit_for(3 * H)), sm)
             # the layer's four weight-gradient GEMMs only consume tensors the chain above produced (dxd, du, dxd2, dqkv
             # are distinct buffers): one grouped launch, after which the scratch may be reused by the next layer
-            if sw is None:
+            if off:
+                plan.fork(sm, self.s_off)               # the other stack's stream picks them up once this chain got here
+                plan.add_gemm_group(wgrads, self.s_off)
+            elif sw is None:
                 plan.add_gemm_group(wgrads, sm)
             else:                                       # beside the next layer's chain, on at most wg_blocks workgroups
                 # two streams, alternating with the scratch set: "everything enqueued so far on stream (l % 2)" is exactly
@@ -643,6 +654,8 @@ class EncoderStack:
         if sw is not None:
             plan.join(sw, sm)                           # whatever follows on the chain's stream sees every weight gradient
             plan.join(sw + 1, sm)
+        if self.s_off is not None:
+            plan.join(self.s_off, sm)
         self.bwd_out = gin
 
 
