@@ -51,6 +51,11 @@ def get_args():
     ap.add_argument("--loopback", action="store_true",
                     help="single GPU: run the data-parallel schedule (exchange points, segmented hipGraphs) with identity "
                          "exchanges on a communication stream -- exercises the N>1 code path without a second GPU")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="single rank: still initialise the RCCL process group and run the N > 1 code path (bucketed exchange, "
+                         "segmented hipGraphs) with real world-size-1 collectives")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="N > 1: reduce-scatter + sharded clip / BertAdam + all-gather of the bf16 shadow instead of all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / PCIe-inclusive side measurements")
     ap.add_argument("--dropout", type=float, default=0.1)
@@ -196,9 +201,13 @@ def main():
     if world != args.gpus and rank == 0:
         print("[bench] --gpus %d but the launcher started %d rank(s); using %d" % (args.gpus, world, world), file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
         assert torch.cuda.device_count() > local_rank, "rank %d has no GPU %d" % (rank, local_rank)
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -220,8 +229,8 @@ def main():
     tc = task_config(args, world)
     model = UniVL.from_pretrained("bert-base-uncased", "visual-base", "cross-base", "decoder-base", task_config=tc)
     model.to(dev).train()
-    if world > 1:
-        model.enable_data_parallel()
+    if world > 1 or args.force_dp:
+        model.enable_data_parallel(force=args.force_dp, shard_optimizer=args.shard_optimizer)
     elif args.loopback:
         model.enable_data_parallel(loopback=True)
     opt = make_optimizer(model, BertAdam)
