@@ -413,9 +413,16 @@ def main():
                                host_inputs=bool(args.host_inputs), exchange=exchange, params=n_params,
                                last_loss=round(last, 6)),
                    pcie_inclusive=pcie, roofline=roofline, cpu_baseline=cpu_base)
-        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner to stdout through C stdio: flush that first, so that the JSON line is the LAST line
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:   # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

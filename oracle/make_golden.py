@@ -49,7 +49,11 @@ CASES = {
     "joint_b16": (dict(batch_size=16), 16, 1316),
     "joint_b128": (dict(batch_size=128), 128, 13128),
     # FT-Align (--train_sim_after_cross) at 48x48: 16 (text, video) pairs x 96 tokens through the 2-layer cross encoder
-    "align_full": (dict(batch_size=4, train_sim_after_cross=True), 4, 2104),
+    # (data seed picked so that no hinge argument of the 4x4 max-margin loss, margin + s_ij - s_ii, is closer than 0.07 to
+    #  zero: with seed 2104 one sits at 8.5e-4, inside the bf16 noise of the logits (2e-3), and whether that hinge counts --
+    #  i.e. an O(30 %) step in every gradient of this 16-pair batch -- is a coin flip of the rounding in ANY bf16
+    #  implementation; the loss is not differentiable there, so no gradient parity is defined)
+    "align_full": (dict(batch_size=4, train_sim_after_cross=True), 4, 2105),
     # cfg4: caption finetune stage two, 128 x 96, 3 decoder layers, 4 rows per GPU
     "caption_full": (dict(batch_size=4, stage_two=True, task_type="caption", max_words=128, max_frames=96), 4, 3104),
     # cfg5: pretrain stage two, 2 videos x n_pair 3 = 6 rows, 48 x 64, five losses

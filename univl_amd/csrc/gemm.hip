@@ -401,14 +401,38 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     }
 }
 
+// XCD-aware workgroup -> tile map.  The dispatcher deals workgroups round-robin over the 8 XCDs (linear id % 8, x fastest),
+// and every XCD has its own L2: with the plain (x = column tile, y = row tile) grid the row tiles that share one WEIGHT
+// tile land on different XCDs and each of them pulls that tile from HBM again (round-2 PMC pass: 2.9 GB of HBM traffic per
+// step for 1.4 GB of algorithmic operand + output bytes).  Here every XCD takes a contiguous run of the tile list ordered
+// (column tile, k slice, row tile) with the row tile fastest, so the row tiles of one weight tile sit behind one L2.  The map
+// is a bijection for any grid (the first total % 8 XCDs take one tile more); only the placement changes, never the result.
+__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz) {
+    const int nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
+    const int total = nx * ny * nz;
+    if (total < 16 || ny == 1) return;
+    const int L = bx + nx * (by + ny * bz);
+    const int c = L & 7, k = L >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int t = c * q + (c < r ? c : r) + k;
+    by = t % ny;
+    const int u = t / ny;
+    bz = u % nz;
+    bx = u / nz;
+}
+
 template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
-    gemm_tile<T, TA, TB, BM, BN, D, NC>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.flags & UNIVL_GEMM_XCD_MAP) xcd_tile(bx, by, bz);
+    gemm_tile<T, TA, TB, BM, BN, D, NC>(p, bx, by, bz, gridDim.z);
 }
 
 template <typename T, bool TA, bool TB, int BM, int BN, int NC, int BURST>
 __global__ __launch_bounds__(256) void gemm_burst_kernel(GemmArgs p) {
-    gemm_tile<T, TA, TB, BM, BN, 2, NC, BURST>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.flags & UNIVL_GEMM_XCD_MAP) xcd_tile(bx, by, bz);
+    gemm_tile<T, TA, TB, BM, BN, 2, NC, BURST>(p, bx, by, bz, gridDim.z);
 }
 
 template <typename T, bool TA, bool TB, int BM, int BN, int NC, int BURST>
@@ -566,7 +590,8 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, bool& big, int&
     a.A = d->A; a.B = d->B; a.lda = d->lda; a.ldb = d->ldb; a.M = d->M; a.N = d->N; a.K = d->K;
     a.C32 = d->C32; a.C16 = d->C16; a.ldc = d->ldc; a.bias = d->bias; a.R = d->R; a.ldr = d->ldr;
     a.aux = d->aux; a.ldaux = d->ldaux; a.dbias = d->dbias; a.alpha = d->alpha;
-    a.flags = flags | (ksplit > 1 ? UNIVL_GEMM_ATOMIC : 0);
+    static const int xcd_map = [] { const char* e = getenv("UNIVL_GEMM_XCD"); return e ? atoi(e) : 1; }();
+    a.flags = flags | (ksplit > 1 ? UNIVL_GEMM_ATOMIC : 0) | (xcd_map ? UNIVL_GEMM_XCD_MAP : 0);
     a.ksplit_len = klen;
     a.sumsq = d->sumsq; a.sumsq_rows = d->sumsq_rows; a.sumsq_stride = d->sumsq_stride;
     return UNIVL_OK;

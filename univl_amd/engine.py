@@ -33,6 +33,50 @@ def no_gc():
             gc.enable()
 
 
+GUARDED = []          # UNIVL_GUARD=1 (debugging): (tag, base tensor, guard elements, payload elements) of every workspace
+
+
+def _workspace(dev, zeros=False):
+    """Allocator of the persistent workspaces.  Debugging switches: UNIVL_POISON=1 fills floating-point buffers with NaN, so
+    that a kernel reading something no kernel has written yet shows up in the outputs instead of depending on what the
+    caching allocator happens to hand back; UNIVL_GUARD=1 puts a sentinel band before and after every buffer
+    (check_guards() reports the buffers whose neighbourhood a kernel wrote into)."""
+    poison = os.environ.get("UNIVL_POISON", "0") == "1" and not zeros
+    guard = os.environ.get("UNIVL_GUARD", "0") == "1"
+
+    def e(*s, dtype=torch.float32):
+        shape = tuple(s[0]) if (len(s) == 1 and isinstance(s[0], (tuple, list))) else tuple(s)
+        n = 1
+        for d in shape:
+            n *= d
+        if guard:
+            G = 1024
+            base = torch.empty(n + 2 * G, device=dev, dtype=dtype)
+            base.view(torch.uint8).fill_(0xA5)
+            t = base[G:G + n].view(shape)
+            import traceback
+            GUARDED.append(("%s %s @%s" % (shape, dtype, traceback.extract_stack(limit=3)[0].lineno), base, G, n))
+        else:
+            t = torch.empty(shape, device=dev, dtype=dtype)
+        if zeros:
+            t.zero_()
+        elif poison and dtype.is_floating_point:
+            t.fill_(float("nan"))
+        return t
+    return e
+
+
+def check_guards():
+    bad = []
+    for tag, base, G, n in GUARDED:
+        raw = base.view(torch.uint8)
+        esz = base.element_size()
+        lo, hi = raw[:G * esz], raw[(G + n) * esz:]
+        if bool((lo != 0xA5).any()) or bool((hi != 0xA5).any()):
+            bad.append((tag, int((lo != 0xA5).sum()), int((hi != 0xA5).sum())))
+    return bad
+
+
 _ALIGN = 64  # elements; keeps every tensor 256-byte aligned in fp32 and 128-byte in bf16
 FLAT_REGISTRY = weakref.WeakSet()   # lets the fused optimizer find the flat buffers that own a Parameter
 
@@ -480,7 +524,7 @@ class EncoderStack:
         ct = flat.compute_dtype
         self.bf = ct == torch.bfloat16
         f32 = torch.float32
-        e = lambda *s, dtype=f32: torch.empty(*s, device=dev, dtype=dtype)
+        e = _workspace(dev)
         self.layers = []
         # fp32 GEMM outputs that may be produced by split-K atomics live in two arenas zeroed ONCE per pass
         self.yarena = e(n_layers, 2, T, H)
@@ -674,7 +718,7 @@ class DecoderStack:
         dev, H, I, Tq, Tkv = flat.device, self.H, self.I, self.Tq, self.Tkv
         ct = flat.compute_dtype
         self.bf = ct == torch.bfloat16
-        e = lambda *s, dtype=torch.float32: torch.empty(*s, device=dev, dtype=dtype)
+        e = _workspace(dev)
         self.layers = []
         for l in range(n_layers):
             ws = dict(qkv=e(Tq, 3 * H, dtype=ct), lse1=e(B, self.NH, Wd), ctx1=e(Tq, H, dtype=ct), y1=e(Tq, H), st1=e(Tq, 2),

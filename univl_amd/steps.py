@@ -23,7 +23,8 @@ H = 768
 
 
 def _e(dev):
-    return lambda *s, dtype=torch.float32: torch.zeros(*s, device=dev, dtype=dtype)
+    from .engine import _workspace
+    return _workspace(dev, zeros=True)
 
 
 class Ctx:
