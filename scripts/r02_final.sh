@@ -3,7 +3,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-OUT=gpurun_out/r02g
+OUT=gpurun_out/r02m
 mkdir -p $OUT
 python -c "
 from univl_amd import _lib
@@ -17,6 +17,11 @@ cp gpurun_out/parity_errors.json $OUT/ 2>/dev/null
 tail -4 $OUT/pytest.log
 (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/smoke.log); tail -2 $OUT/smoke.log
 timeout 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-300 $OUT/bench.json
+for r in 1 2; do
+  UNIVL_GEMM_XCD=0 timeout 300 python bench.py --steps 150 --warmup 20 --no-cpu-baseline > $OUT/bench_xcd0_$r.json 2> $OUT/bench_xcd0_$r.err
+  UNIVL_GEMM_XCD=1 timeout 300 python bench.py --steps 150 --warmup 20 --no-cpu-baseline > $OUT/bench_xcd1_$r.json 2> $OUT/bench_xcd1_$r.err
+done
+UNIVL_GEMM_XCD=0 timeout 300 python bench.py --batch 16 --no-cpu-baseline > $OUT/bench_b16_xcd0.json 2> $OUT/bench_b16_xcd0.err
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver.json 2> $OUT/bench_driver.err
 timeout 300 python bench.py --batch 16 --no-cpu-baseline > $OUT/bench_b16.json 2> $OUT/bench_b16.err
 timeout 300 python bench.py --batch 128 --no-cpu-baseline > $OUT/bench_b128.json 2> $OUT/bench_b128.err
