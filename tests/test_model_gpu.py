@@ -47,10 +47,25 @@ BF16_GRAD_GATES = {
 }
 
 
+_NOISE_KEYS = {"gnorm": ("grad_norm_rel_max", 1.0), "gsample": ("grad_sample_rel_max", 1.0),
+               "gmedian": ("grad_sample_rel_median", 1.0), "gtop": ("grad_sample_rel_median", 1.5)}
+
+
 def gates_for(name, dtype):
+    """bf16 gradient gates of the loss-amplified branches: the branch floor above, or -- when the case has an entry in
+    tests/golden/bf16_autocast_noise.json -- what the REFERENCE's own bf16 autocast run shows against its fp32 run for the
+    same statistic, whichever is larger (align_full, round 2: ours gnorm 0.13 / gmedian 0.18 / gsample 0.57, the
+    reference's autocast 0.28 / 0.35 / 1.16).  Outputs (hidden / sim / logits / loss) never take this path."""
     g = dict(GATES[dtype])
-    if dtype == torch.bfloat16:
-        g.update(BF16_GRAD_GATES.get(name.split("_")[0], {}))
+    branch = name.split("_")[0]
+    if dtype == torch.bfloat16 and branch in BF16_GRAD_GATES:
+        g.update(BF16_GRAD_GATES[branch])
+        import json
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_autocast_noise.json")
+        ref = json.load(open(path)).get(name)
+        if ref:
+            for k, (rk, f) in _NOISE_KEYS.items():
+                g[k] = max(g[k], f * float(ref[rk]))
     return g
 
 
