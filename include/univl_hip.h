@@ -88,14 +88,17 @@ typedef struct UnivlGemm {
     float alpha;
     int32_t flags;
     int32_t ksplit;        /* >1: split the contraction over gridDim.z, fp32 atomics into pre-zeroed C32 */
-    int32_t tile;          /* 0 auto, 64, 128 */
+    int32_t tile;          /* 0 auto; 64 (64x64, 4 waves), 128 (128x128, 4 waves), 256 (256x128, 8 waves; bf16, else 128) */
     /* optional, no split-K: every wave stores the sum of squares of the FINAL values it wrote to
-     *   sumsq[(m0 / sumsq_rows) * sumsq_stride + (((m0 % sumsq_rows) / tile) * tiles_x + tile_x) * 4 + wave]
+     *   sumsq[(m0 / sumsq_rows) * sumsq_stride + (((m0 % sumsq_rows) / tile) * tiles_x + tile_x) * waves + wave]
      * (sumsq_rows = 0: the whole output is one tensor).  Partial sums, no atomics: thousands of workgroups adding to one
      * address serialise in L2.  univl_sumsq_finish folds them into per-tensor sums.  Lets the weight-gradient GEMMs
      * produce the gradient norms clip_grad_norm_ (main_task_retrieval.py:347) and BertAdam's per-parameter clip
-     * (optimization.py:135-136) need, instead of a separate 4 B/param pass.  sumsq_rows must be a multiple of 128. */
+     * (optimization.py:135-136) need, instead of a separate 4 B/param pass.  sumsq_rows must be a multiple of 128 (of 256 for the
+     * 256-row tile, which is otherwise replaced by the 128 tile).  At most rows x N / 1024 partial sums per tensor. */
     float* sumsq; int32_t sumsq_rows; int32_t sumsq_stride;
+    int32_t stages;        /* LDS pipeline depth: 0 auto, 2 (double buffer), 3 (ring with counted DMA waits; bf16, else 2) */
+    int32_t waves;         /* waves per workgroup on the 64 / 128 tiles: 0 auto, 4, 8 (bf16, else 4); the 256 tile always runs 8 */
 } UnivlGemm;
 int univl_gemm(const UnivlGemm* desc, hipStream_t stream);
 /* n (1..UNIVL_GEMM_GROUP_MAX) independent problems with the same dtype / trans_a / trans_b in ONE launch: the four

@@ -185,6 +185,94 @@ def test_gemm_group_wgrads(dtype, T):
         ops.gemm_group(mixed)                              # different operand layouts
 
 
+GEMM_VARIANTS = [(64, 3, 4), (64, 2, 8), (64, 3, 8), (128, 3, 4), (128, 2, 8), (128, 3, 8), (256, 2, 8), (256, 3, 8)]   # UnivlGemm.tile, .stages, .waves
+
+
+@pytest.mark.parametrize("M,N,K", [(700, 1000, 768), (6144, 768, 3072), (300, 264, 100), (256, 128, 64), (260, 130, 200),
+                                    (1024, 2304, 1096)])
+def test_gemm_ring_and_wide_tile_forward_dgrad(M, N, K):
+    """The three-stage ring (counted DMA waits), the 8-wave workgroups and the 256 x 128 tile against the 128-tile / 4-wave
+    double-buffered kernel: BIT-identical (every output element contracts the same 32-deep chunks in the same order in every
+    variant), and the double-buffered kernel against fp64.  Shapes: ragged rows / columns, contraction shorter than the ring
+    (K = 64, 100), a partial last K tile (K = 200, 1096), the MFMA-bound shape of bs 128 (6144 x 768 x 3072)."""
+    dtype = torch.bfloat16
+    Kp = (K + 7) // 8 * 8
+    A = torch.zeros(M, Kp); A[:, :K] = gen(M, K, seed=1)
+    B = torch.zeros(N, Kp); B[:, :K] = gen(N, K, seed=2, scale=0.05)
+    bias = gen(N, seed=3).to(DEV)
+    Ad, Bd = A.to(DEV, dtype), B.to(DEV, dtype)
+    ldc = (N + 7) // 8 * 8
+    base = torch.zeros(M, ldc, device=DEV)
+    base16 = torch.zeros(M, ldc, device=DEV, dtype=dtype)
+    ops.gemm(Ad, Bd, M, N, K, out32=base, out16=base16, bias=bias, tile=128, stages=2, waves=4)
+    ref = Ad.double().cpu()[:, :K] @ Bd.double().cpu()[:, :K].T + bias.double().cpu()
+    assert rel_err(base[:, :N], ref) < 2e-3
+    # dgrad layout: dX[M, Kp] = dY[M, N] . W[N, Kp]   (B T-major) + fp32 residual
+    Np = (N + 7) // 8 * 8
+    dY = torch.zeros(M, Np); dY[:, :N] = gen(M, N, seed=4)
+    dYd = dY.to(DEV, dtype)
+    Wd = torch.zeros(Np, Kp, device=DEV, dtype=dtype); Wd[:N] = Bd
+    res = gen(M, Kp, seed=5).to(DEV)
+    dbase = torch.zeros(M, Kp, device=DEV)
+    ops.gemm(dYd, Wd, M, Kp, N, trans_b=True, out32=dbase, residual=res, tile=128, stages=2, waves=4)
+    ref = dYd.double().cpu()[:, :N] @ Wd.double().cpu()[:N] + res.double().cpu()
+    assert rel_err(dbase, ref) < 2e-3
+    for tile, stages, waves in GEMM_VARIANTS:
+        for rep in range(3):                               # a race in the ring would come and go
+            out = torch.zeros(M, ldc, device=DEV)
+            o16 = torch.zeros(M, ldc, device=DEV, dtype=dtype)
+            ops.gemm(Ad, Bd, M, N, K, out32=out, out16=o16, bias=bias, tile=tile, stages=stages, waves=waves)
+            assert torch.equal(out, base), ("forward", tile, stages, waves, rep, float((out - base).abs().max()))
+            assert torch.equal(o16, base16), ("forward bf16", tile, stages, waves, rep)
+            out = torch.zeros(M, Kp, device=DEV)
+            ops.gemm(dYd, Wd, M, Kp, N, trans_b=True, out32=out, residual=res, tile=tile, stages=stages, waves=waves)
+            assert torch.equal(out, dbase), ("dgrad", tile, stages, waves, rep, float((out - dbase).abs().max()))
+
+
+@pytest.mark.parametrize("T", [192, 1000, 6144])
+def test_gemm_ring_and_wide_tile_wgrad(T):
+    """Weight-gradient layout (both operands T-major) with the fused bias gradient, accumulate, the per-tensor sum of squares
+    (three tensors of 768 rows in one launch) and the grouped launch: every variant against the double-buffered 128 tile."""
+    dtype = torch.bfloat16
+    dY = gen(T, 2304, seed=1).to(DEV, dtype)
+    X = gen(T, 768, seed=2).to(DEV, dtype)
+    X2 = gen(T, 3072, seed=3).to(DEV, dtype)
+    dY768 = dY[:, :768].contiguous()
+    stride = (768 // 64) * (768 // 64) * 4
+
+    def run(tile, stages, waves, group):
+        out = torch.full((2304, 768), 0.5, device=DEV)
+        db = torch.full((2304,), 0.25, device=DEV)
+        part = torch.zeros(3 * stride, device=DEV)
+        kw = dict(trans_a=True, trans_b=True, out32=out, dbias=db, accumulate=True, sumsq=part, sumsq_rows=768,
+                  sumsq_stride=stride, tile=tile, stages=stages, waves=waves)
+        if group:
+            o2 = torch.zeros(768, 3072, device=DEV)
+            d2 = ops.gemm_desc(dY768, X2, 768, 3072, T, trans_a=True, trans_b=True, out32=o2, tile=tile, stages=stages, waves=waves)
+            ops.gemm_group([ops.gemm_desc(dY, X, 2304, 768, T, **kw), d2])
+            return out, db, part.view(3, stride).sum(1), o2
+        ops.gemm(dY, X, 2304, 768, T, **kw)
+        return out, db, part.view(3, stride).sum(1), None
+
+    b_out, b_db, b_ss, _ = run(128, 2, 4, False)
+    assert rel_err(b_out, dY.double().cpu().T @ X.double().cpu() + 0.5) < 2e-3
+    assert rel_err(b_ss, (b_out.double() ** 2).view(3, -1).sum(1).cpu()) < 1e-5
+    b_o2 = torch.zeros(768, 3072, device=DEV)
+    ops.gemm(dY768, X2, 768, 3072, T, trans_a=True, trans_b=True, out32=b_o2, tile=128, stages=2, waves=4)
+    assert rel_err(b_o2, dY768.double().cpu().T @ X2.double().cpu()) < 2e-3
+    for tile, stages, waves in GEMM_VARIANTS:
+        plain = torch.zeros(2304, 768, device=DEV)         # no sum of squares: the 64 tile keeps its 8 waves
+        ops.gemm(dY, X, 2304, 768, T, trans_a=True, trans_b=True, out32=plain, tile=tile, stages=stages, waves=waves)
+        assert rel_err(plain + 0.5, b_out) < 1e-6, ("plain", tile, stages, waves)
+        for group in (False, True):
+            out, db, ss, o2 = run(tile, stages, waves, group)
+            assert torch.equal(out, b_out), (tile, stages, waves, group)
+            assert rel_err(db, b_db) < 1e-5                # 64- / 128- / 256-row tiles sum the bias gradient in different orders
+            assert rel_err(ss, b_ss) < 1e-5
+            if o2 is not None:
+                assert torch.equal(o2, b_o2), ("group member 2", tile, stages, waves)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_fused_sum_of_squares(dtype):
     """UnivlGemm.sumsq: the wgrad epilogue accumulates the per-tensor sum of squares of what it stores (single tensor,

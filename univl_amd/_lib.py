@@ -18,7 +18,8 @@ class Gemm(C.Structure):
     _fields_ = [("dtype", i32), ("trans_a", i32), ("trans_b", i32), ("M", i32), ("N", i32), ("K", i32),
                 ("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C32", vp), ("C16", vp), ("ldc", i64),
                 ("bias", vp), ("R", vp), ("ldr", i64), ("aux", vp), ("ldaux", i64), ("dbias", vp),
-                ("alpha", f32), ("flags", i32), ("ksplit", i32), ("tile", i32), ("sumsq", vp), ("sumsq_rows", i32), ("sumsq_stride", i32)]
+                ("alpha", f32), ("flags", i32), ("ksplit", i32), ("tile", i32), ("sumsq", vp), ("sumsq_rows", i32), ("sumsq_stride", i32),
+                ("stages", i32), ("waves", i32)]
 
 
 class LayerNorm(C.Structure):

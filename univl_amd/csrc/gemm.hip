@@ -43,15 +43,15 @@ struct GemmArgs {
 // K-major tile ([ROWS][BK], fragment = two 8-byte reads per lane over 16 consecutive rows): swz = r & 15 (RB 256) or
 // (r >> 1) & 7 (RB 128).  T-major tile ([BK][ROWS], transpose-read of 4 k-rows x 32 B per 16 lanes): swz = (r & 7) << 1
 // (RB >= 256) or r & 6 (RB 128).
-template <typename T, bool TR, int ROWS, int BK> struct Tile {
+template <typename T, bool TR, int ROWS, int BK, int NT = 256> struct Tile {
     static constexpr int EPC = Mma<T>::EPC;
     static constexpr int RB = (TR ? ROWS : BK) * (int)sizeof(T);     // bytes per LDS row
     static constexpr int NR = TR ? BK : ROWS;                        // LDS rows
     static constexpr int CPR = RB / 16;                              // 16-byte pieces per row
     static constexpr int BYTES = NR * RB;
     static constexpr int CHUNKS = BYTES / 16;
-    static constexpr int PER_THREAD = CHUNKS / 256;
-    static_assert(CHUNKS % 256 == 0 && (CPR == 8 || CPR == 16 || CPR == 32), "unsupported tile geometry");
+    static constexpr int PER_THREAD = CHUNKS / NT;                   // NT = threads of the workgroup
+    static_assert(CHUNKS % NT == 0 && (CPR == 8 || CPR == 16 || CPR == 32), "unsupported tile geometry");
 
     __device__ static __forceinline__ int swz(int r) {
         if (TR) return CPR == 8 ? (r & 6) : ((r & 7) << 1);
@@ -60,7 +60,7 @@ template <typename T, bool TR, int ROWS, int BK> struct Tile {
     __device__ static __forceinline__ int byte_of(int r, int q) { return r * RB + ((q ^ swz(r)) << 4); }
     // LDS piece L (lane-linear) holds tile piece (r, q):  r = L / CPR,  q = (L % CPR) ^ swz(r)
     __device__ static __forceinline__ void coords(int c, int tid, int& r, int& q) {
-        const int L = tid + 256 * c;
+        const int L = tid + NT * c;
         r = L / CPR;
         q = (L % CPR) ^ swz(r);
     }
@@ -89,7 +89,7 @@ template <typename T, bool TR, int ROWS, int BK> struct Tile {
 #pragma unroll
         for (int c = 0; c < PER_THREAD; ++c)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)P[c],
-                                             (__attribute__((address_space(3))) void*)(wbase + c * 4096), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(wbase + c * (NT * 16)), 16, 0, 0);
     }
     // last, partial K tile (krem < BK contraction indices left; P + skip points at the tile start): through
     // registers, clamped addresses, zero fill of everything at or beyond krem
@@ -123,7 +123,7 @@ template <typename T, bool TR, int ROWS, int BK> struct Tile {
                     v[d] &= m;
                 }
             }
-            *reinterpret_cast<u32x4_t*>(stage + (tid + 256 * c) * 16) = v;
+            *reinterpret_cast<u32x4_t*>(stage + (tid + NT * c) * 16) = v;
         }
     }
     // element (row r, column e) of the tile, for scalar access
@@ -170,25 +170,34 @@ template <typename T, bool TR, int ROWS, int BK> struct Tile {
 // BURST = n: up to n stages, ALL of the workgroup's K steps are issued before the first wait and multiplied after ONE
 // barrier.  At M <= a few hundred rows the K loop is a chain of dependent DMA round trips, not MFMA work: a workgroup
 // whose whole contraction slice (<= n x BK) fits the 160 KB LDS pays one round trip instead of K / BK of them.
-template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC, int BURST = 0>
+//
+// D = 2: the two-stage loop above.  D = 3 / 4: a ring of D stages with COUNTED waits -- the tiles of the next D - 2 K steps stay
+// in flight across the barrier (s_waitcnt vmcnt(pieces of the younger tiles) instead of vmcnt(0)), so a workgroup that is
+// alone on its compute unit (the 256x128 tile: 8 waves, 144 KB of LDS) still has two DMA round trips under way while it
+// multiplies.  WGM x WGN waves; every wave owns a (BM / WGM) x (BN / WGN) sub-tile.
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC, int BURST = 0, int WGM = 2, int WGN = 2>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const int by, const int bz, const int nz) {
     constexpr int CH = Mma<T>::CH;
     constexpr int BK = NC * CH;          // contraction depth of one LDS stage (NC chunks of CH)
-    using TileA = Tile<T, TA, BM, BK>;
-    using TileB = Tile<T, TB, BN, BK>;
-    constexpr int WM = BM / 2, WN = BN / 2;      // per-wave sub-tile
+    constexpr int NW = WGM * WGN, NT = 64 * NW;
+    using TileA = Tile<T, TA, BM, BK, NT>;
+    using TileB = Tile<T, TB, BN, BK, NT>;
+    constexpr int WM = BM / WGM, WN = BN / WGN;      // per-wave sub-tile
     constexpr int MI = WM / 16, NI = WN / 16;
-    static_assert(D == 2, "two LDS stages");
+    static_assert(D >= 2 && D <= 4, "two LDS stages, or a ring of three / four");
+    static_assert(BM <= NT, "the bias-gradient pass uses one thread per tile row");
 
     // ONE dynamic LDS object (a second __shared__ object makes hipcc drain vmcnt(0) before every ds_read)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* sA = smem_raw;
-    unsigned char* sB = sA + 2 * TileA::BYTES;
+    unsigned char* sB = sA + D * TileA::BYTES;
     constexpr int STAGE = TileA::BYTES + TileB::BYTES;       // BURST layout: stage s = [A_s | B_s] at smem_raw + s * STAGE
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i = lane & 15;
-    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
     const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = bz * p.ksplit_len;
     const int kend = min(p.K, kbeg + p.ksplit_len);
@@ -252,6 +261,45 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         __syncthreads();                                     // carries the vmcnt(0) for every DMA issued above
         const int nst = nfull + (krem > 0 ? 1 : 0);
         for (int t = 0; t < nst; ++t) compute(smem_raw + t * STAGE, smem_raw + t * STAGE + TileA::BYTES);
+    } else if constexpr (D > 2) {
+        // ring of D stages: tile t lives in stage t % D; tiles t+1 .. t+D-2 are in flight while tile t is multiplied
+        constexpr int PIECES = TileA::PER_THREAD + TileB::PER_THREAD;      // DMA instructions per wave and tile
+        const int npre = min(D - 1, nfull);
+        for (int s = 0; s < npre; ++s) {
+            TileA::issue(pa, sA + s * TileA::BYTES, tid);
+            TileB::issue(pb, sB + s * TileB::BYTES, tid);
+            TileA::advance(pa, stepA);
+            TileB::advance(pb, stepB);
+        }
+        int cur = 0, nxt = (D - 1) % D;           // stage of tile t / of tile t + D - 1 (= the stage tile t - 1 just left)
+        for (int t = 0; t < nfull; ++t) {
+            // this wave's pieces of tile t have landed once at most the pieces of the younger tiles are outstanding
+            const int young = min(D - 2, nfull - 1 - t);
+            if (young >= 2) wait_vm<2 * PIECES>();
+            else if (young == 1) wait_vm<PIECES>();
+            else wait_vm<0>();
+            // ... and behind the barrier everybody's have; every wave has also retired its reads of stage (t - 1) % D
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + D - 1 < nfull) {
+                TileA::issue(pa, sA + nxt * TileA::BYTES, tid);
+                TileB::issue(pb, sB + nxt * TileB::BYTES, tid);
+                TileA::advance(pa, stepA);
+                TileB::advance(pb, stepB);
+            }
+            compute(sA + cur * TileA::BYTES, sB + cur * TileB::BYTES);
+            cur = (cur + 1 == D) ? 0 : cur + 1;
+            nxt = (nxt + 1 == D) ? 0 : nxt + 1;
+        }
+        if (krem > 0) {
+            // stage nfull % D: last read D - 1 barriers ago (or never), no DMA targets it
+            unsigned char* cA = sA + cur * TileA::BYTES;
+            unsigned char* cB = sB + cur * TileB::BYTES;
+            TileA::store_tail(ta, cA, krem, tid);
+            TileB::store_tail(tb, cB, krem, tid);
+            __syncthreads();
+            compute(cA, cB);
+        }
     } else {
     if (nfull > 0) {
         // double-buffered LDS-DMA pipeline: tile t+1 streams into the other stage while tile t is multiplied; the
@@ -389,7 +437,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         const int tensor = p.sumsq_rows > 0 ? m0 / p.sumsq_rows : 0;
         const int mloc = p.sumsq_rows > 0 ? m0 % p.sumsq_rows : m0;
         const int nx = (p.N + BN - 1) / BN;
-        if (lane == 0) p.sumsq[(long)tensor * p.sumsq_stride + ((mloc / BM) * nx + bx) * 4 + wave] = ssq;
+        if (lane == 0) p.sumsq[(long)tensor * p.sumsq_stride + ((mloc / BM) * nx + bx) * NW + wave] = ssq;
     }
     if (want_dbias && tid < BM) {
         const int row = m0 + tid;
@@ -421,11 +469,11 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz) {
     bx = u / nz;
 }
 
-template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
+template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmArgs p) {
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (p.flags & UNIVL_GEMM_XCD_MAP) xcd_tile(bx, by, bz);
-    gemm_tile<T, TA, TB, BM, BN, D, NC>(p, bx, by, bz, gridDim.z);
+    gemm_tile<T, TA, TB, BM, BN, D, NC, 0, WGM, WGN>(p, bx, by, bz, gridDim.z);
 }
 
 template <typename T, bool TA, bool TB, int BM, int BN, int NC, int BURST>
@@ -462,8 +510,8 @@ struct GroupArgs {
 // A grid smaller than the number of tiles walks them with stride gridDim.x: the "background" form of the layer's
 // weight-gradient launch (engine.EncoderStack, UNIVL_WGRAD_BLOCKS) occupies only that many workgroups while the next
 // layer's latency-bound dgrad chain runs beside it on another stream.
-template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC>
-__global__ __launch_bounds__(256, 2) void gemm_group_kernel(GroupArgs g) {
+template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_group_kernel(GroupArgs g) {
   const int total = g.first[UNIVL_GEMM_GROUP_MAX];
   for (int w = blockIdx.x; w < total; w += gridDim.x) {
     int idx = 0;
@@ -478,48 +526,48 @@ __global__ __launch_bounds__(256, 2) void gemm_group_kernel(GroupArgs g) {
     const int local = w - first;
     const int bz = local / nxy, rem = local - bz * nxy;
     const int by = rem / nx, bx = rem - by * nx;
-    gemm_tile<T, TA, TB, BM, BN, D, NC>(p, bx, by, bz, nz);
+    gemm_tile<T, TA, TB, BM, BN, D, NC, 0, WGM, WGN>(p, bx, by, bz, nz);
     if (gridDim.x < total) __syncthreads();           // the next tile's DMA reuses the LDS stages
   }
 }
 
-template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC>
+template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC, int WGM = 2, int WGN = 2>
 int launch_group(const GroupArgs& g, int max_blocks, hipStream_t stream) {
-    constexpr int BK = NC * Mma<T>::CH;
-    using TileA = Tile<T, TA, BM, BK>;
-    using TileB = Tile<T, TB, BN, BK>;
+    constexpr int BK = NC * Mma<T>::CH, NT = 64 * WGM * WGN;
+    using TileA = Tile<T, TA, BM, BK, NT>;
+    using TileB = Tile<T, TB, BN, BK, NT>;
     // NC == 6 is the one-K-step variant: only stage 0 of B is ever touched (A keeps the two-stage offset layout)
-    const size_t smem = NC == 6 ? 2 * TileA::BYTES + TileB::BYTES : 2 * (TileA::BYTES + TileB::BYTES);
+    const size_t smem = NC == 6 ? 2 * TileA::BYTES + TileB::BYTES : D * (TileA::BYTES + TileB::BYTES);
     static bool attr_done[UNIVL_MAX_DEVICES] = {};   // per instantiation, per device
-    if (smem > 48 * 1024) univl_allow_lds(gemm_group_kernel<T, TA, TB, BM, BN, D, NC>, smem, attr_done);
+    if (smem > 48 * 1024) univl_allow_lds(gemm_group_kernel<T, TA, TB, BM, BN, D, NC, WGM, WGN>, smem, attr_done);
     const int total = g.first[UNIVL_GEMM_GROUP_MAX];
     const int grid = (max_blocks > 0 && max_blocks < total) ? max_blocks : total;
-    hipLaunchKernelGGL((gemm_group_kernel<T, TA, TB, BM, BN, D, NC>), dim3(grid), dim3(256), smem, stream, g);
+    hipLaunchKernelGGL((gemm_group_kernel<T, TA, TB, BM, BN, D, NC, WGM, WGN>), dim3(grid), dim3(NT), smem, stream, g);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
 
-template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC>
+template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC, int WGM = 2, int WGN = 2>
 int launch(const GemmArgs& a, int ksplit, hipStream_t stream) {
-    constexpr int BK = NC * Mma<T>::CH;
-    using TileA = Tile<T, TA, BM, BK>;
-    using TileB = Tile<T, TB, BN, BK>;
+    constexpr int BK = NC * Mma<T>::CH, NT = 64 * WGM * WGN;
+    using TileA = Tile<T, TA, BM, BK, NT>;
+    using TileB = Tile<T, TB, BN, BK, NT>;
     // NC == 6 is the one-K-step variant: only stage 0 of B is ever touched (A keeps the two-stage offset layout)
-    const size_t smem = NC == 6 ? 2 * TileA::BYTES + TileB::BYTES : 2 * (TileA::BYTES + TileB::BYTES);
+    const size_t smem = NC == 6 ? 2 * TileA::BYTES + TileB::BYTES : D * (TileA::BYTES + TileB::BYTES);
     static bool attr_done[UNIVL_MAX_DEVICES] = {};   // per instantiation, per device
-    if (smem > 48 * 1024) univl_allow_lds(gemm_kernel<T, TA, TB, BM, BN, D, NC>, smem, attr_done);
+    if (smem > 48 * 1024) univl_allow_lds(gemm_kernel<T, TA, TB, BM, BN, D, NC, WGM, WGN>, smem, attr_done);
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, ksplit);
-    hipLaunchKernelGGL((gemm_kernel<T, TA, TB, BM, BN, D, NC>), grid, dim3(256), smem, stream, a);
+    hipLaunchKernelGGL((gemm_kernel<T, TA, TB, BM, BN, D, NC, WGM, WGN>), grid, dim3(NT), smem, stream, a);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
 
-template <typename T, int BM, int BN, int D, int NC>
+template <typename T, int BM, int BN, int D, int NC, int WGM = 2, int WGN = 2>
 int dispatch_trans(const GemmArgs& a, int ta, int tb, int ksplit, hipStream_t s) {
-    if (!ta && !tb) return launch<T, false, false, BM, BN, D, NC>(a, ksplit, s);
-    if (!ta && tb) return launch<T, false, true, BM, BN, D, NC>(a, ksplit, s);
-    if (ta && tb) return launch<T, true, true, BM, BN, D, NC>(a, ksplit, s);
-    return launch<T, true, false, BM, BN, D, NC>(a, ksplit, s);
+    if (!ta && !tb) return launch<T, false, false, BM, BN, D, NC, WGM, WGN>(a, ksplit, s);
+    if (!ta && tb) return launch<T, false, true, BM, BN, D, NC, WGM, WGN>(a, ksplit, s);
+    if (ta && tb) return launch<T, true, true, BM, BN, D, NC, WGM, WGN>(a, ksplit, s);
+    return launch<T, true, false, BM, BN, D, NC, WGM, WGN>(a, ksplit, s);
 }
 
 }  // namespace
@@ -551,12 +599,55 @@ __global__ __launch_bounds__(256) void dot_kernel(GemmArgs p) {
     }
 }
 
-// validation + kernel arguments shared by the single and the grouped entry point
-static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, bool& big, int& nc) {
+// validation + kernel arguments shared by the single and the grouped entry point.
+// Tile geometry (UnivlGemm.tile, 0 = chosen here) and pipeline depth (UnivlGemm.stages, 0 = chosen here):
+//   64   64 x 64,  4 waves, BK = 128 bf16   -- everything below ~256 big tiles: parallelism over tile efficiency
+//   128  128 x 128, 4 waves, BK = 64        -- two workgroups per compute unit
+//   256  256 x 128, 8 waves (4 x 2), BK = 64, bf16 only -- 85 flop per staged byte instead of 64; one workgroup per compute
+//        unit, which is what the three-stage ring is for
+// stages = 2: the double-buffered loop; 3: ring with counted waits (bf16 only).  waves = 4 | 8 (tiles 64 / 128, bf16 only).
+struct Choice { int tile, nc, stages, waves; };
+
+static inline long env_long(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
+
+static Choice choose(const UnivlGemm* d, int forced_tile) {
+    static const long big_min = env_long("UNIVL_GEMM_BIG_MIN", 256L);
+    static const long t256_min = env_long("UNIVL_GEMM_T256_MIN", 0L);              // 0: never picked automatically
+    static const int stages_dflt = (int)env_long("UNIVL_GEMM_STAGES", 2L);         // tiles 64 / 128
+    static const int stages256 = (int)env_long("UNIVL_GEMM_STAGES256", 3L);
+    static const int one_step = (int)env_long("UNIVL_GEMM_ONESTEP", 1L);
+    const bool bf16 = d->dtype == UNIVL_BF16;
+    const int want = forced_tile ? forced_tile : d->tile;
+    const long tiles128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
+    const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 127) / 128);
+    Choice c;
+    c.tile = (want >= 128 || (want == 0 && tiles128 >= big_min)) ? 128 : 64;
+    if (bf16 && (want == 256 || (want == 0 && c.tile == 128 && t256_min > 0 && tiles256 >= t256_min))) c.tile = 256;
+    if (c.tile == 256 && d->sumsq && d->sumsq_rows % 256 != 0) c.tile = 128;     // a tile must not straddle two tensors
+    c.nc = c.tile == 64 ? 4 : 2;
+    const int ksplit = d->ksplit < 1 ? 1 : d->ksplit;
+    // weight gradients at 4 pairs x 48 tokens contract over exactly 192 rows: one 192-deep stage = ONE DMA round trip
+    // per workgroup, no partial tile through registers (the 128-deep stage needs a 128-step plus a masked 64-tail)
+    if (one_step && c.tile == 64 && bf16 && d->trans_a && d->trans_b && d->K == 192 && ksplit == 1) c.nc = 6;
+    c.stages = d->stages ? d->stages : (c.tile == 256 ? stages256 : stages_dflt);
+    if (c.stages < 2 || c.stages > 3 || !bf16 || c.nc == 6) c.stages = 2;
+    // 8 waves on the 64 / 128 tiles: the same tile cut into twice as many wave sub-tiles.  Less MFMA work per fragment read, but
+    // twice as many waves issuing LDS-DMA -- a wave sustains ~25 GB/s of DMA, and below a few hundred rows that, not MFMA, is
+    // what a K step waits for.
+    static const int waves_dflt = (int)env_long("UNIVL_GEMM_WAVES", 4L);
+    c.waves = c.tile == 256 ? 8 : (d->waves ? d->waves : waves_dflt);
+    if (c.waves != 8 || !bf16 || c.nc == 6 || (d->sumsq && c.tile == 64)) c.waves = c.tile == 256 ? 8 : 4;   // sumsq: rows x N / 1024 slots
+    return c;
+}
+
+static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int forced_tile = 0) {
     UNIVL_CHECK_ARG(d != nullptr, UNIVL_EINVAL, "univl_gemm: null descriptor");
     UNIVL_CHECK_ARG(d->dtype == UNIVL_F32 || d->dtype == UNIVL_BF16, UNIVL_EUNSUPPORTED, "univl_gemm: dtype %d", d->dtype);
     UNIVL_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, UNIVL_EINVAL, "univl_gemm: empty problem %dx%dx%d", d->M, d->N, d->K);
     UNIVL_CHECK_ARG(d->A && d->B && (d->C32 || d->C16), UNIVL_EINVAL, "univl_gemm: null operand");
+    UNIVL_CHECK_ARG(d->tile == 0 || d->tile == 64 || d->tile == 128 || d->tile == 256, UNIVL_EINVAL, "univl_gemm: tile %d (0, 64, 128, 256)", d->tile);
+    UNIVL_CHECK_ARG(d->stages == 0 || d->stages == 2 || d->stages == 3, UNIVL_EINVAL, "univl_gemm: stages %d (0, 2, 3)", d->stages);
+    UNIVL_CHECK_ARG(d->waves == 0 || d->waves == 4 || d->waves == 8, UNIVL_EINVAL, "univl_gemm: waves %d (0, 4, 8)", d->waves);
     const int epc = d->dtype == UNIVL_BF16 ? 8 : 4;
     UNIVL_CHECK_ARG(aligned16(d->A) && aligned16(d->B) && d->lda % epc == 0 && d->ldb % epc == 0, UNIVL_EALIGN,
                     "univl_gemm: operands must be 16-byte aligned with leading dims a multiple of %d (lda=%ld ldb=%ld)",
@@ -564,19 +655,12 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, bool& big, int&
     const int flags = d->flags;
     UNIVL_CHECK_ARG(!((flags & (UNIVL_GEMM_GELU_FWD | UNIVL_GEMM_GELU_BWD)) && !d->aux), UNIVL_EINVAL,
                     "univl_gemm: GELU epilogue needs aux");
-    // tile choice: 128x128 once the grid fills the chip (>= 256 tiles, measured: +6 % at bs 128 over 384, same at bs 16), else 64x64 for parallelism.  The small tile stages
-    // 4 chunks (128 bf16 / 64 f32) per barrier: at M <= a few hundred the kernel is a latency chain of K steps
-    // (DMA -> barrier -> ds_read -> MFMA), so fewer, deeper steps win; 2 stages of 32 KB stay in flight.
-    const long tiles128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
-    static const long big_min = [] { const char* e = getenv("UNIVL_GEMM_BIG_MIN"); return e ? atol(e) : 256L; }();
-    big = d->tile == 128 || (d->tile == 0 && tiles128 >= big_min);
-    nc = big ? 2 : 4;
+    // tile choice: 128x128 once the grid fills the chip (>= 256 tiles, measured: +6 % at bs 128 over 384, same at bs 16), else
+    // 64x64 for parallelism.  The small tile stages 4 chunks (128 bf16 / 64 f32) per barrier: at M <= a few hundred the kernel
+    // is a latency chain of K steps (DMA -> barrier -> ds_read -> MFMA), so fewer, deeper steps win.
+    c = choose(d, forced_tile);
     ksplit = d->ksplit < 1 ? 1 : d->ksplit;
-    // weight gradients at 4 pairs x 48 tokens contract over exactly 192 rows: one 192-deep stage = ONE DMA round trip
-    // per workgroup, no partial tile through registers (the 128-deep stage needs a 128-step plus a masked 64-tail)
-    static const int one_step = [] { const char* e = getenv("UNIVL_GEMM_ONESTEP"); return e ? atoi(e) : 1; }();
-    if (one_step && !big && d->dtype == UNIVL_BF16 && d->trans_a && d->trans_b && d->K == 192 && ksplit == 1) nc = 6;
-    const int BK = (d->dtype == UNIVL_BF16 ? 32 : 16) * nc;
+    const int BK = (d->dtype == UNIVL_BF16 ? 32 : 16) * c.nc;
     int klen = ((d->K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
     ksplit = (d->K + klen - 1) / klen;
     if (ksplit > 1) {
@@ -590,7 +674,7 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, bool& big, int&
     a.A = d->A; a.B = d->B; a.lda = d->lda; a.ldb = d->ldb; a.M = d->M; a.N = d->N; a.K = d->K;
     a.C32 = d->C32; a.C16 = d->C16; a.ldc = d->ldc; a.bias = d->bias; a.R = d->R; a.ldr = d->ldr;
     a.aux = d->aux; a.ldaux = d->ldaux; a.dbias = d->dbias; a.alpha = d->alpha;
-    static const int xcd_map = [] { const char* e = getenv("UNIVL_GEMM_XCD"); return e ? atoi(e) : 1; }();
+    static const int xcd_map = (int)env_long("UNIVL_GEMM_XCD", 1L);
     a.flags = flags | (ksplit > 1 ? UNIVL_GEMM_ATOMIC : 0) | (xcd_map ? UNIVL_GEMM_XCD_MAP : 0);
     a.ksplit_len = klen;
     a.sumsq = d->sumsq; a.sumsq_rows = d->sumsq_rows; a.sumsq_stride = d->sumsq_stride;
@@ -600,9 +684,9 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, bool& big, int&
 extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
     UNIVL_ON_STREAM_DEVICE(stream);
     GemmArgs a;
-    int ksplit, nc;
-    bool big;
-    const int rc = prepare(d, a, ksplit, big, nc);
+    int ksplit;
+    Choice c;
+    const int rc = prepare(d, a, ksplit, c);
     if (rc != UNIVL_OK) return rc;
     if (d->dtype == UNIVL_F32 && !d->trans_a && !d->trans_b && d->M <= 32 && d->N <= 32 && ksplit == 1 && d->tile == 0 &&
         !d->bias && !d->R && !d->dbias && !d->sumsq && !(d->flags & (UNIVL_GEMM_GELU_FWD | UNIVL_GEMM_GELU_BWD))) {
@@ -610,21 +694,38 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
         UNIVL_LAUNCH_CHECK();
         return UNIVL_OK;
     }
+    const int ta = d->trans_a, tb = d->trans_b;
     if (d->dtype == UNIVL_BF16) {
-        if (big) return dispatch_trans<__bf16, 128, 128, 2, 2>(a, d->trans_a, d->trans_b, ksplit, stream);
-        if (nc == 6) return launch<__bf16, true, true, 64, 64, 2, 6>(a, ksplit, stream);
+        if (c.tile == 256) {
+            if (c.stages == 3) return dispatch_trans<__bf16, 256, 128, 3, 2, 4, 2>(a, ta, tb, ksplit, stream);
+            return dispatch_trans<__bf16, 256, 128, 2, 2, 4, 2>(a, ta, tb, ksplit, stream);
+        }
+        if (c.tile == 128 && c.waves == 8) {
+            if (c.stages == 3) return dispatch_trans<__bf16, 128, 128, 3, 2, 2, 4>(a, ta, tb, ksplit, stream);
+            return dispatch_trans<__bf16, 128, 128, 2, 2, 2, 4>(a, ta, tb, ksplit, stream);
+        }
+        if (c.tile == 128) {
+            if (c.stages == 3) return dispatch_trans<__bf16, 128, 128, 3, 2>(a, ta, tb, ksplit, stream);
+            return dispatch_trans<__bf16, 128, 128, 2, 2>(a, ta, tb, ksplit, stream);
+        }
+        if (c.nc == 6) return launch<__bf16, true, true, 64, 64, 2, 6>(a, ksplit, stream);
         // small-M forward / dgrad products whose contraction slice (the host's split-K choice) is at most 6 x 128 deep:
         // the whole slice in one LDS-DMA burst, half-width tiles (64x32 forward, 32x64 dgrad) so that twice as many
-        // compute units share the operand traffic (UNIVL_GEMM_BURST=0: the two-stage kernel, for A/B runs)
-        static const int burst = [] { const char* e = getenv("UNIVL_GEMM_BURST"); return e ? atoi(e) : 0; }();
+        // compute units share the operand traffic (UNIVL_GEMM_BURST=1; measured no better than the two-stage kernel, off)
+        static const int burst = (int)env_long("UNIVL_GEMM_BURST", 0L);
         if (burst && d->tile == 0 && !d->trans_a && a.ksplit_len <= 6 * 128 && !d->sumsq) {
             if (!d->trans_b) return launch_burst<__bf16, false, false, 64, 32, 4, 6>(a, ksplit, stream);
             return launch_burst<__bf16, false, true, 32, 64, 4, 6>(a, ksplit, stream);
         }
-        return dispatch_trans<__bf16, 64, 64, 2, 4>(a, d->trans_a, d->trans_b, ksplit, stream);
+        if (c.waves == 8) {
+            if (c.stages == 3) return dispatch_trans<__bf16, 64, 64, 3, 4, 2, 4>(a, ta, tb, ksplit, stream);
+            return dispatch_trans<__bf16, 64, 64, 2, 4, 2, 4>(a, ta, tb, ksplit, stream);
+        }
+        if (c.stages == 3) return dispatch_trans<__bf16, 64, 64, 3, 4>(a, ta, tb, ksplit, stream);
+        return dispatch_trans<__bf16, 64, 64, 2, 4>(a, ta, tb, ksplit, stream);
     }
-    if (big) return dispatch_trans<float, 128, 128, 2, 2>(a, d->trans_a, d->trans_b, ksplit, stream);
-    return dispatch_trans<float, 64, 64, 2, 4>(a, d->trans_a, d->trans_b, ksplit, stream);
+    if (c.tile == 128) return dispatch_trans<float, 128, 128, 2, 2>(a, ta, tb, ksplit, stream);
+    return dispatch_trans<float, 64, 64, 2, 4>(a, ta, tb, ksplit, stream);
 }
 
 extern "C" int univl_gemm_group(const UnivlGemm* d, int n, hipStream_t stream) {
@@ -637,48 +738,54 @@ extern "C" int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_block
                     UNIVL_GEMM_GROUP_MAX);
     if (n == 1 && max_blocks <= 0) return univl_gemm(d, stream);
     GroupArgs g;
-    bool big_all = true;
-    // the group runs one kernel instantiation: the 128x128 tile only if every member would pick it
+    // the group runs one kernel instantiation: the smallest tile / shallowest pipeline any member would pick alone
+    int tile_all = 256, stages_all = 3, waves_all = 8;
     for (int i = 0; i < n; ++i) {
         UNIVL_CHECK_ARG(d[i].dtype == d[0].dtype && d[i].trans_a == d[0].trans_a && d[i].trans_b == d[0].trans_b, UNIVL_EINVAL,
                         "univl_gemm_group: members must share dtype and operand layouts");
-        const long tiles128 = (long)((d[i].M + 127) / 128) * ((d[i].N + 127) / 128);
-        static const long big_min = [] { const char* e = getenv("UNIVL_GEMM_BIG_MIN"); return e ? atol(e) : 256L; }();
-        big_all = big_all && (d[i].tile == 128 || (d[i].tile == 0 && tiles128 >= big_min));
+        const Choice ci = choose(&d[i], 0);
+        tile_all = ci.tile < tile_all ? ci.tile : tile_all;
+        stages_all = ci.stages < stages_all ? ci.stages : stages_all;
+        waves_all = ci.waves < waves_all ? ci.waves : waves_all;
     }
     int total = 0, nc_all = 0;
-    const int bm = big_all ? 128 : 64;
+    const int bm = tile_all, bn = tile_all == 256 ? 128 : tile_all;
     for (int i = 0; i < UNIVL_GEMM_GROUP_MAX; ++i) {
         g.first[i] = total;
         if (i >= n) { g.p[i] = g.p[0]; g.nx[i] = g.nxy[i] = g.nz[i] = 1; continue; }
-        UnivlGemm di = d[i];
-        di.tile = bm;
-        int ksplit, nc;
-        bool big;
-        const int rc = prepare(&di, g.p[i], ksplit, big, nc);
+        int ksplit;
+        Choice ci;
+        const int rc = prepare(&d[i], g.p[i], ksplit, ci, tile_all);
         if (rc != UNIVL_OK) return rc;
-        nc_all = (i == 0) ? nc : (nc_all == nc ? nc : -1);
-        g.nx[i] = (di.N + bm - 1) / bm;
-        g.nxy[i] = g.nx[i] * ((di.M + bm - 1) / bm);
+        UNIVL_CHECK_ARG(ci.tile == tile_all, UNIVL_EINVAL, "univl_gemm_group: member %d cannot run the group's %d tile (sumsq_rows %d)", i, tile_all, d[i].sumsq_rows);
+        nc_all = (i == 0) ? ci.nc : (nc_all == ci.nc ? ci.nc : -1);
+        g.nx[i] = (d[i].N + bn - 1) / bn;
+        g.nxy[i] = g.nx[i] * ((d[i].M + bm - 1) / bm);
         g.nz[i] = ksplit;
         total += g.nxy[i] * ksplit;
     }
     g.first[UNIVL_GEMM_GROUP_MAX] = total;
     const bool ta = d[0].trans_a, tb = d[0].trans_b;
-#define UNIVL_GROUP_CASE(T, BMN, NCV)                                                                        \
-    do {                                                                                                     \
-        if (!ta && !tb) return launch_group<T, false, false, BMN, BMN, 2, NCV>(g, max_blocks, stream);       \
-        if (!ta && tb) return launch_group<T, false, true, BMN, BMN, 2, NCV>(g, max_blocks, stream);         \
-        if (ta && tb) return launch_group<T, true, true, BMN, BMN, 2, NCV>(g, max_blocks, stream);           \
-        return launch_group<T, true, false, BMN, BMN, 2, NCV>(g, max_blocks, stream);                        \
+    const int D = nc_all == 6 ? 2 : stages_all;
+#define UNIVL_GROUP_CASE(T, BMV, BNV, DV, NCV, WM_, WN_)                                                               \
+    do {                                                                                                               \
+        if (!ta && !tb) return launch_group<T, false, false, BMV, BNV, DV, NCV, WM_, WN_>(g, max_blocks, stream);      \
+        if (!ta && tb) return launch_group<T, false, true, BMV, BNV, DV, NCV, WM_, WN_>(g, max_blocks, stream);        \
+        if (ta && tb) return launch_group<T, true, true, BMV, BNV, DV, NCV, WM_, WN_>(g, max_blocks, stream);          \
+        return launch_group<T, true, false, BMV, BNV, DV, NCV, WM_, WN_>(g, max_blocks, stream);                       \
     } while (0)
     UNIVL_CHECK_ARG(nc_all > 0, UNIVL_EINVAL, "univl_gemm_group: members disagree on the K-step depth (mixed contraction lengths)");
     if (d[0].dtype == UNIVL_BF16) {
-        if (big_all) UNIVL_GROUP_CASE(__bf16, 128, 2);
+        if (tile_all == 256) { if (D == 3) UNIVL_GROUP_CASE(__bf16, 256, 128, 3, 2, 4, 2); UNIVL_GROUP_CASE(__bf16, 256, 128, 2, 2, 4, 2); }
+        const bool w8 = waves_all == 8 && nc_all != 6;
+        if (tile_all == 128 && w8) { if (D == 3) UNIVL_GROUP_CASE(__bf16, 128, 128, 3, 2, 2, 4); UNIVL_GROUP_CASE(__bf16, 128, 128, 2, 2, 2, 4); }
+        if (tile_all == 128) { if (D == 3) UNIVL_GROUP_CASE(__bf16, 128, 128, 3, 2, 2, 2); UNIVL_GROUP_CASE(__bf16, 128, 128, 2, 2, 2, 2); }
         if (nc_all == 6) return launch_group<__bf16, true, true, 64, 64, 2, 6>(g, max_blocks, stream);
-        UNIVL_GROUP_CASE(__bf16, 64, 4);
+        if (w8) { if (D == 3) UNIVL_GROUP_CASE(__bf16, 64, 64, 3, 4, 2, 4); UNIVL_GROUP_CASE(__bf16, 64, 64, 2, 4, 2, 4); }
+        if (D == 3) UNIVL_GROUP_CASE(__bf16, 64, 64, 3, 4, 2, 2);
+        UNIVL_GROUP_CASE(__bf16, 64, 64, 2, 4, 2, 2);
     }
-    if (big_all) UNIVL_GROUP_CASE(float, 128, 2);
-    UNIVL_GROUP_CASE(float, 64, 4);
+    if (tile_all == 128) UNIVL_GROUP_CASE(float, 128, 128, 2, 2, 2, 2);
+    UNIVL_GROUP_CASE(float, 64, 64, 2, 4, 2, 2);
 #undef UNIVL_GROUP_CASE
 }

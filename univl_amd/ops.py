@@ -48,7 +48,7 @@ def probe_layouts():
 
 def gemm_desc(A, B, M, N, K, *, trans_a=False, trans_b=False, out32=None, out16=None, bias=None, residual=None, aux=None,
               gelu=None, accumulate=False, dbias=None, dbias_atomic=False, ksplit=1, tile=0, alpha=1.0, sumsq=None,
-              sumsq_rows=0, sumsq_stride=0):
+              sumsq_rows=0, sumsq_stride=0, stages=0, waves=0):
     _require_gpu(A, B, out32, out16)
     d = _lib.Gemm()
     d.dtype = dtype_code(A.dtype)
@@ -76,6 +76,7 @@ def gemm_desc(A, B, M, N, K, *, trans_a=False, trans_b=False, out32=None, out16=
         flags |= _lib.GEMM_DBIAS_ATOMIC
     d.flags, d.ksplit, d.tile = flags, ksplit, tile
     d.sumsq, d.sumsq_rows, d.sumsq_stride = _p(sumsq), sumsq_rows, sumsq_stride
+    d.stages, d.waves = int(stages), int(waves)
     return d
 
 
