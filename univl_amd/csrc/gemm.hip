@@ -32,6 +32,7 @@ struct GemmArgs {
     int flags;
     int ksplit_len;   // contraction length handled by one z-slice (multiple of BK)
     float* sumsq; int sumsq_rows, sumsq_stride;
+    int gm;           // row tiles per L2 block of the tile order (0: plain order)
 };
 
 // One operand tile in LDS: UNPADDED rows of RB = 128 or 256 bytes, filled by direct global->LDS DMA
@@ -449,37 +450,60 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     }
 }
 
-// XCD-aware workgroup -> tile map.  The dispatcher deals workgroups round-robin over the 8 XCDs (linear id % 8, x fastest),
-// and every XCD has its own L2: with the plain (x = column tile, y = row tile) grid the row tiles that share one WEIGHT
-// tile land on different XCDs and each of them pulls that tile from HBM again (round-2 PMC pass: 2.9 GB of HBM traffic per
-// step for 1.4 GB of algorithmic operand + output bytes).  Here every XCD takes a contiguous run of the tile list ordered
-// (column tile, k slice, row tile) with the row tile fastest, so the row tiles of one weight tile sit behind one L2.  The map
-// is a bijection for any grid (the first total % 8 XCDs take one tile more); only the placement changes, never the result.
-__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz) {
+// XCD-aware, L2-blocked workgroup -> tile map.  The dispatcher deals workgroups round-robin over the 8 XCDs (linear id % 8,
+// x fastest), and every XCD has its own 4 MB L2: with the plain (x = column tile, y = row tile) grid the row tiles that share
+// one WEIGHT tile land on different XCDs and each of them pulls that tile from HBM again (round-2 PMC pass: 2.9 GB of HBM
+// traffic per step for 1.4 GB of algorithmic operand + output bytes).  Here every XCD takes a contiguous run of a tile LIST
+// (the first total % 8 XCDs take one tile more), and the list is ordered so that the ~64 workgroups an XCD runs at a time
+// form a compact block of the output:
+//   * at most `gm` row tiles (small M): (column tile, k slice, row tile) with the row tile fastest -- the row tiles of one
+//     weight tile sit behind one L2;
+//   * more (M in the thousands): bands of `gm` row tiles, inside a band column by column -- a window of 64 consecutive tiles
+//     is a gm x (64 / gm) block that reads gm + 64 / gm operand panels instead of 64 + 1 (at M = 6144 the activation operand
+//     alone is 9-38 MB: with the row tile fastest over all 48 row tiles every panel is evicted before its next use).
+// A bijection for any grid; only the placement changes, never the result.
+__device__ __forceinline__ void tile_of(int t, int nx, int ny, int nz, int gm, int& bx, int& by, int& bz) {
+    if (gm <= 0 || ny <= gm) {
+        by = t % ny;
+        const int u = t / ny;
+        bz = u % nz;
+        bx = u / nz;
+    } else {
+        const int per = nx * ny;
+        bz = t / per;
+        const int r = t - bz * per;
+        const int band = r / (gm * nx), first = band * gm;
+        const int rows = min(ny - first, gm);
+        const int rr = r - band * gm * nx;
+        by = first + rr % rows;
+        bx = rr / rows;
+    }
+}
+
+__device__ __forceinline__ int xcd_run(int L, int total) {      // linear workgroup id -> position in the tile list
+    const int c = L & 7, k = L >> 3;
+    const int q = total >> 3, r = total & 7;
+    return c * q + (c < r ? c : r) + k;
+}
+
+__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz, int gm) {
     const int nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
     const int total = nx * ny * nz;
     if (total < 16 || ny == 1) return;
-    const int L = bx + nx * (by + ny * bz);
-    const int c = L & 7, k = L >> 3;
-    const int q = total >> 3, r = total & 7;
-    const int t = c * q + (c < r ? c : r) + k;
-    by = t % ny;
-    const int u = t / ny;
-    bz = u % nz;
-    bx = u / nz;
+    tile_of(xcd_run(bx + nx * (by + ny * bz), total), nx, ny, nz, gm, bx, by, bz);
 }
 
 template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC, int WGM, int WGN>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmArgs p) {
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (p.flags & UNIVL_GEMM_XCD_MAP) xcd_tile(bx, by, bz);
+    if (p.flags & UNIVL_GEMM_XCD_MAP) xcd_tile(bx, by, bz, p.gm);
     gemm_tile<T, TA, TB, BM, BN, D, NC, 0, WGM, WGN>(p, bx, by, bz, gridDim.z);
 }
 
 template <typename T, bool TA, bool TB, int BM, int BN, int NC, int BURST>
 __global__ __launch_bounds__(256) void gemm_burst_kernel(GemmArgs p) {
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (p.flags & UNIVL_GEMM_XCD_MAP) xcd_tile(bx, by, bz);
+    if (p.flags & UNIVL_GEMM_XCD_MAP) xcd_tile(bx, by, bz, p.gm);
     gemm_tile<T, TA, TB, BM, BN, 2, NC, BURST>(p, bx, by, bz, gridDim.z);
 }
 
@@ -513,7 +537,9 @@ struct GroupArgs {
 template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC, int WGM, int WGN>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_group_kernel(GroupArgs g) {
   const int total = g.first[UNIVL_GEMM_GROUP_MAX];
-  for (int w = blockIdx.x; w < total; w += gridDim.x) {
+  const bool remap = (g.p[0].flags & UNIVL_GEMM_XCD_MAP) && gridDim.x >= total && total >= 16;   // one workgroup per tile
+  for (int w0 = blockIdx.x; w0 < total; w0 += gridDim.x) {
+    const int w = remap ? xcd_run(w0, total) : w0;
     int idx = 0;
 #pragma unroll
     for (int i = 1; i < UNIVL_GEMM_GROUP_MAX; ++i) idx += (w >= g.first[i]) ? 1 : 0;
@@ -524,8 +550,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_group_kernel(GroupArgs
     for (int i = 1; i < UNIVL_GEMM_GROUP_MAX; ++i)
         if (idx == i) { p = g.p[i]; first = g.first[i]; nx = g.nx[i]; nxy = g.nxy[i]; nz = g.nz[i]; }
     const int local = w - first;
-    const int bz = local / nxy, rem = local - bz * nxy;
-    const int by = rem / nx, bx = rem - by * nx;
+    int bx, by, bz;
+    if (remap) {
+        tile_of(local, nx, nxy / nx, nz, p.gm, bx, by, bz);
+    } else {
+        bz = local / nxy;
+        const int rem = local - bz * nxy;
+        by = rem / nx;
+        bx = rem - by * nx;
+    }
     gemm_tile<T, TA, TB, BM, BN, D, NC, 0, WGM, WGN>(p, bx, by, bz, nz);
     if (gridDim.x < total) __syncthreads();           // the next tile's DMA reuses the LDS stages
   }
@@ -634,7 +667,7 @@ static Choice choose(const UnivlGemm* d, int forced_tile) {
     // 8 waves on the 64 / 128 tiles: the same tile cut into twice as many wave sub-tiles.  Less MFMA work per fragment read, but
     // twice as many waves issuing LDS-DMA -- a wave sustains ~25 GB/s of DMA, and below a few hundred rows that, not MFMA, is
     // what a K step waits for.
-    static const int waves_dflt = (int)env_long("UNIVL_GEMM_WAVES", 4L);
+    static const int waves_dflt = (int)env_long("UNIVL_GEMM_WAVES", 8L);          // measured (profiles/README.md, round 2): -2 % per step at 4 pairs, -5 % at 128
     c.waves = c.tile == 256 ? 8 : (d->waves ? d->waves : waves_dflt);
     if (c.waves != 8 || !bf16 || c.nc == 6 || (d->sumsq && c.tile == 64)) c.waves = c.tile == 256 ? 8 : 4;   // sumsq: rows x N / 1024 slots
     return c;
@@ -678,6 +711,8 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int 
     a.flags = flags | (ksplit > 1 ? UNIVL_GEMM_ATOMIC : 0) | (xcd_map ? UNIVL_GEMM_XCD_MAP : 0);
     a.ksplit_len = klen;
     a.sumsq = d->sumsq; a.sumsq_rows = d->sumsq_rows; a.sumsq_stride = d->sumsq_stride;
+    static const int gm = (int)env_long("UNIVL_GEMM_GM", 8L);
+    a.gm = gm;
     return UNIVL_OK;
 }
 
@@ -747,6 +782,26 @@ extern "C" int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_block
         tile_all = ci.tile < tile_all ? ci.tile : tile_all;
         stages_all = ci.stages < stages_all ? ci.stages : stages_all;
         waves_all = ci.waves < waves_all ? ci.waves : waves_all;
+    }
+    // Members too small for the 128 tile on their own (a layer's weight gradients: 36-144 tiles each) fill the chip TOGETHER:
+    // with a deep contraction (thousands of tokens) the 64 tile moves twice the operand bytes per flop through every compute
+    // unit and the fabric, so the group takes the 128 tile once it has UNIVL_GEMM_GROUP_BIG_MIN of them (0: never).
+    static const long group_big_min = env_long("UNIVL_GEMM_GROUP_BIG_MIN", 0L);
+    if (group_big_min > 0 && tile_all == 64) {
+        long sum = 0;
+        bool deep = true;
+        for (int i = 0; i < n; ++i) {
+            sum += (long)((d[i].M + 127) / 128) * ((d[i].N + 127) / 128);
+            deep = deep && d[i].K >= 1024 && d[i].tile == 0;
+        }
+        if (deep && sum >= group_big_min) {
+            tile_all = 128; stages_all = 3; waves_all = 8;
+            for (int i = 0; i < n; ++i) {
+                const Choice ci = choose(&d[i], 128);
+                stages_all = ci.stages < stages_all ? ci.stages : stages_all;
+                waves_all = ci.waves < waves_all ? ci.waves : waves_all;
+            }
+        }
     }
     int total = 0, nc_all = 0;
     const int bm = tile_all, bn = tile_all == 256 ? 128 : tile_all;
