@@ -110,6 +110,11 @@ int univl_gemm_group(const UnivlGemm* descs, int32_t n, hipStream_t stream);
  * the critical path -- a layer's weight gradients -- can run beside the next layer's latency-bound kernels on another
  * stream without taking the compute units away from them. */
 int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_blocks, hipStream_t stream);
+/* Host-side evaluation of the kernels' workgroup -> tile maps (no device work; lets a CPU test prove they are bijections):
+ * what 0: plain-grid map, in out[0..2] = hardware block index, out = the tile that block computes;
+ * what 1: out[0] <- position of linear workgroup out[0] in the XCD-grouped tile list of nx tiles;
+ * what 2: out[0..2] <- tile number out[0] of an nx x ny x nz problem (a grouped launch's member). */
+int univl_gemm_tile_map(int32_t what, int32_t nx, int32_t ny, int32_t nz, int32_t gm, int32_t* out);
 
 /* ------------------------------------------------------------------------------------------ LayerNorm
  * TF-style LayerNorm (until_module.py:40-53: biased variance, eps inside the sqrt) fused with what surrounds it

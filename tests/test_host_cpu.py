@@ -112,3 +112,40 @@ def test_bert_adam_argument_validation():
         BertAdam(m.parameters(), lr=1e-3, warmup=1.5)
     with pytest.raises(ValueError):
         BertAdam(m.parameters(), lr=1e-3, b1=1.0)
+
+
+def _tile_map(what, nx, ny, nz, gm, a, b=0, c=0):
+    import ctypes as C
+    out = (C.c_int32 * 3)(a, b, c)
+    assert _lib.lib().univl_gemm_tile_map(what, nx, ny, nz, gm, out) == 0
+    return out[0], out[1], out[2]
+
+
+@pytest.mark.parametrize("gm", [0, 4, 8, 16])
+def test_gemm_workgroup_to_tile_maps_are_bijections(gm):
+    """The XCD-aware / L2-blocked tile order of gemm.hip only re-orders the tiles: every tile of the grid is computed by
+    exactly one workgroup, for every grid shape the plans produce (row tiles 1..96, split-K 1..8) and for ragged ones."""
+    shapes = [(36, 3, 1), (12, 3, 2), (12, 3, 8), (48, 3, 1), (6, 1, 1), (5, 3, 1), (1, 3, 8), (18, 12, 1), (6, 48, 1),
+              (24, 96, 1), (239, 4, 1), (7, 13, 3), (3, 9, 2), (477, 1, 1), (2, 2, 2), (16, 1, 1), (1, 17, 1), (6, 47, 2)]
+    for nx, ny, nz in shapes:
+        total = nx * ny * nz
+        # plain grid (gemm_kernel): hardware (x, y, z) -> tile
+        seen = set()
+        for z in range(nz):
+            for y in range(ny):
+                for x in range(nx):
+                    t = _tile_map(0, nx, ny, nz, gm, x, y, z)
+                    assert 0 <= t[0] < nx and 0 <= t[1] < ny and 0 <= t[2] < nz, (nx, ny, nz, gm, (x, y, z), t)
+                    seen.add(t)
+        assert len(seen) == total, (nx, ny, nz, gm)
+        # grouped launch (gemm_group_kernel): list position, then the member's local tile
+        pos = sorted(_tile_map(1, total, 1, 1, gm, w)[0] for w in range(total))
+        assert pos == list(range(total)), (total,)
+        local = {_tile_map(2, nx, ny, nz, gm, t) for t in range(total)}
+        assert len(local) == total and all(0 <= a < nx and 0 <= b < ny and 0 <= c < nz for a, b, c in local), (nx, ny, nz, gm)
+    # workgroups dealt to one XCD (linear id % 8) take a CONTIGUOUS run of the list: that is what keeps the row tiles
+    # that share a weight tile behind one L2
+    total = 108
+    for c in range(8):
+        run = [_tile_map(1, total, 1, 1, gm, w)[0] for w in range(c, total, 8)]
+        assert run == list(range(run[0], run[0] + len(run)))

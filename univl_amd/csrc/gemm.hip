@@ -462,7 +462,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 //     is a gm x (64 / gm) block that reads gm + 64 / gm operand panels instead of 64 + 1 (at M = 6144 the activation operand
 //     alone is 9-38 MB: with the row tile fastest over all 48 row tiles every panel is evicted before its next use).
 // A bijection for any grid; only the placement changes, never the result.
-__device__ __forceinline__ void tile_of(int t, int nx, int ny, int nz, int gm, int& bx, int& by, int& bz) {
+__host__ __device__ __forceinline__ void tile_of(int t, int nx, int ny, int nz, int gm, int& bx, int& by, int& bz) {
     if (gm <= 0 || ny <= gm) {
         by = t % ny;
         const int u = t / ny;
@@ -473,24 +473,28 @@ __device__ __forceinline__ void tile_of(int t, int nx, int ny, int nz, int gm, i
         bz = t / per;
         const int r = t - bz * per;
         const int band = r / (gm * nx), first = band * gm;
-        const int rows = min(ny - first, gm);
+        const int rows = (ny - first) < gm ? (ny - first) : gm;
         const int rr = r - band * gm * nx;
         by = first + rr % rows;
         bx = rr / rows;
     }
 }
 
-__device__ __forceinline__ int xcd_run(int L, int total) {      // linear workgroup id -> position in the tile list
+__host__ __device__ __forceinline__ int xcd_run(int L, int total) {      // linear workgroup id -> position in the tile list
     const int c = L & 7, k = L >> 3;
     const int q = total >> 3, r = total & 7;
     return c * q + (c < r ? c : r) + k;
 }
 
-__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz, int gm) {
-    const int nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
+// the map of a plain (x, y, z) grid; grids below 16 workgroups and single-row-tile grids keep the plain order
+__host__ __device__ __forceinline__ void xcd_tile_grid(int nx, int ny, int nz, int gm, int& bx, int& by, int& bz) {
     const int total = nx * ny * nz;
     if (total < 16 || ny == 1) return;
     tile_of(xcd_run(bx + nx * (by + ny * bz), total), nx, ny, nz, gm, bx, by, bz);
+}
+
+__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz, int gm) {
+    xcd_tile_grid(gridDim.x, gridDim.y, gridDim.z, gm, bx, by, bz);
 }
 
 template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC, int WGM, int WGN>
@@ -713,6 +717,21 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int 
     a.sumsq = d->sumsq; a.sumsq_rows = d->sumsq_rows; a.sumsq_stride = d->sumsq_stride;
     static const int gm = (int)env_long("UNIVL_GEMM_GM", 8L);
     a.gm = gm;
+    return UNIVL_OK;
+}
+
+// Host-side evaluation of the workgroup -> tile maps above (no device work): what = 0, the plain-grid map of gemm_kernel
+// (in: the hardware block index in out[0..2]; out: the tile it computes); what = 1, xcd_run(out[0], nx) -> out[0] (the grouped
+// launch's list position); what = 2, tile_of(out[0], ...) (a group member's local tile).  tests/test_host_cpu.py proves the
+// maps are bijections for every grid shape the plans produce -- a map that is not one would silently skip tiles.
+extern "C" int univl_gemm_tile_map(int32_t what, int32_t nx, int32_t ny, int32_t nz, int32_t gm, int32_t* out) {
+    UNIVL_CHECK_ARG(out != nullptr && nx > 0 && ny > 0 && nz > 0 && what >= 0 && what <= 2, UNIVL_EINVAL,
+                    "univl_gemm_tile_map: what=%d grid=%dx%dx%d", what, nx, ny, nz);
+    int bx = out[0], by = out[1], bz = out[2];
+    if (what == 0) xcd_tile_grid(nx, ny, nz, gm, bx, by, bz);
+    else if (what == 1) bx = xcd_run(out[0], nx);
+    else tile_of(out[0], nx, ny, nz, gm, bx, by, bz);
+    out[0] = bx; out[1] = by; out[2] = bz;
     return UNIVL_OK;
 }
 
