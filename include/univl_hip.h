@@ -50,6 +50,11 @@ int univl_init(int device);
 /* Clears n <= UNIVL_ZERO_MAX device buffers (16-byte aligned) with one launch; ptrs / bytes are HOST arrays read at call time. */
 #define UNIVL_ZERO_MAX 16
 int univl_zero_many(void* const* ptrs, const int64_t* bytes, int32_t n, hipStream_t stream);
+/* n <= UNIVL_ZERO_MAX device-to-device copies (dst[i] <- src[i], bytes[i] each; non-overlapping) with one launch: the input
+ * staging of UniVL.forward (modeling.py:192-202 hands over input_ids / token_type_ids / attention_mask / video / video_mask) and
+ * the loss hand-off as ONE kernel node of the captured step instead of one memcpy node each.  16-byte aligned pairs move as
+ * 16-byte words, others bytewise.  srcs / dsts / bytes are HOST arrays read at call time. */
+int univl_copy_many(const void* const* srcs, void* const* dsts, const int64_t* bytes, int32_t n, hipStream_t stream);
 int univl_destroy(void);
 /* Data-parallel gradient exchange for hosts that own an RCCL communicator themselves (the Python host goes through
  * torch.distributed's "nccl" backend = RCCL, main_task_retrieval.py:23,197-198, instead): in-place all-reduce of

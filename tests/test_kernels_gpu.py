@@ -793,3 +793,31 @@ def test_zero_many_and_word_row_bookkeeping():
     assert abs(float(out) - float((ref.double() ** 2).sum())) < 1e-3 * float(out)
     ops.rows_zero(table, lst, meta)
     assert float(table.abs().max()) == 0.0
+
+
+def test_copy_many_bit_exact():
+    """univl_copy_many: several device-to-device copies in one launch (input staging / loss hand-off of the training step) --
+    bit-exact for aligned buffers (16-byte words), misaligned views and sizes that are not a multiple of 16, with the bytes
+    around every destination untouched."""
+    g = torch.Generator().manual_seed(3)
+    sizes = [4, 1536, 1537 * 8, 48 * 1024 * 8 * 4, 24, 16, 1, 3 * 1024 * 1024 + 5]
+    pairs, checks = [], []
+    for k, nb in enumerate(sizes):
+        src_base = torch.randint(0, 256, (nb + 64,), generator=g, dtype=torch.uint8).to(DEV)
+        dst_base = torch.full((nb + 64,), 0xEE, dtype=torch.uint8, device=DEV)
+        so, do = ((0, 0), (8, 0), (0, 4), (16, 16), (3, 5), (0, 0), (1, 2), (32, 32))[k]
+        src, dst = src_base[so:so + nb], dst_base[do:do + nb]
+        pairs.append((dst, src))
+        checks.append((dst_base, do, nb, src.clone()))
+    ops.copy_many(pairs)
+    torch.cuda.synchronize()
+    for dst_base, do, nb, want in checks:
+        assert torch.equal(dst_base[do:do + nb], want)
+        assert bool((dst_base[:do] == 0xEE).all()) and bool((dst_base[do + nb:] == 0xEE).all())
+    # typed tensors, as UniVL.forward stages them
+    ids = torch.randint(0, 30522, (4, 48), generator=g).to(DEV)
+    video = torch.randn(4 * 48, 1024, generator=g, dtype=torch.float64).to(DEV)
+    loss = torch.randn(1, generator=g).to(DEV)
+    d_ids, d_video, d_loss = torch.zeros_like(ids), torch.zeros_like(video), torch.empty((), device=DEV)
+    ops.copy_many([(d_ids, ids), (d_video, video), (d_loss, loss)])
+    assert torch.equal(d_ids, ids) and torch.equal(d_video, video) and float(d_loss) == float(loss)

@@ -604,4 +604,8 @@ def test_sparse_word_table_bookkeeping_matches_dense_clear(monkeypatch):
     t0, w0 = run(False)
     for a, b in zip(t1, t0):
         assert a[0] == pytest.approx(b[0], rel=1e-5) and a[1] == pytest.approx(b[1], rel=1e-5) and a[2] == b[2], (t1, t0)
-    assert max_abs(w1, w0) < 1e-7
+    # Not bit-equal: the two runs order their fp32 atomics (embedding scatter-add, split-K, LayerNorm column sums) differently,
+    # and BertAdam's m / sqrt(v) turns a 1e-7 relative gradient difference into ~1e-7 absolute on a parameter (measured over
+    # the round-2 sessions: 0.4e-7 ... 1.5e-7).  One BertAdam step moves a touched element by lr * |m| / sqrt(v) ~ 3e-4 here, so
+    # a row the sparse bookkeeping forgot to clear or to count would show up ~1000x above this gate.
+    assert max_abs(w1, w0) < 5e-7

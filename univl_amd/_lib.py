@@ -99,6 +99,7 @@ def lib():
     L.univl_rows_append.argtypes = [vp, i32, vp, i32, vp, i32, vp]
     L.univl_rows_sumsq.argtypes = [vp, i64, vp, vp, vp, vp]
     L.univl_zero_many.argtypes = [vp, vp, i32, vp]
+    L.univl_copy_many.argtypes = [vp, vp, vp, i32, vp]
     L.univl_maxmargin_loss.argtypes = [vp, i32, i32, f32, vp, vp, vp, vp]
     L.univl_crossen_loss.argtypes = [vp, i32, i32, vp, vp, vp]
     L.univl_milnce_loss.argtypes = [vp, i32, i32, i32, vp, vp, vp]
@@ -138,7 +139,7 @@ EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_dev
             "univl_allreduce_bucket", "univl_gemm", "univl_gemm_group_limited", "univl_gemm_group", "univl_gemm_tile_map",
             "univl_layernorm_fwd", "univl_layernorm_bwd", "univl_attention_fwd", "univl_attention_bwd",
             "univl_embed_text_fwd", "univl_embed_text_bwd", "univl_embed_scatter", "univl_rows_zero", "univl_rows_append",
-            "univl_rows_sumsq", "univl_zero_many", "univl_pool_fwd", "univl_pool_bwd",
+            "univl_rows_sumsq", "univl_zero_many", "univl_copy_many", "univl_pool_fwd", "univl_pool_bwd",
             "univl_maxmargin_loss", "univl_crossen_loss", "univl_milnce_loss", "univl_rank_counts", "univl_gather_rows", "univl_log_softmax_rows", "univl_scale_by_device_scalar", "univl_pair_concat_fwd", "univl_pair_concat_bwd", "univl_postype_fwd", "univl_postype_bwd", "univl_tanh_fwd",
             "univl_tanh_bwd", "univl_gelu_bwd", "univl_colsum", "univl_scale_ct_by_device_scalar", "univl_simdense_fwd", "univl_simdense_bwd", "univl_ce_loss", "univl_mfm_nce_loss", "univl_grad_sumsq", "univl_sumsq_finish",
             "univl_clip_coef", "univl_scale_grads", "univl_bert_adam", "univl_bert_adam_range", "univl_cast_bf16", "univl_bump_counter", "univl_probe_layouts"]

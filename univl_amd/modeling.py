@@ -320,6 +320,18 @@ class DecoderModel(nn.Module):
         self.classifier = _DecoderClassifierParams(cfg.hidden_size, word_w)
 
 
+def _loss_out(step):
+    """A fresh 0-d tensor holding the step's loss (the step's own buffer is rewritten by the next forward).  A kernel node,
+    not clone(): a device-to-device memcpy is a ~10 us node of the captured step."""
+    out = torch.empty((), device=step.loss.device, dtype=step.loss.dtype)
+    if out.is_cuda and os.environ.get("UNIVL_COPY_KERNEL", "1") != "0":
+        from . import ops
+        ops.copy_many([(out, step.loss)])
+    else:
+        out.copy_(step.loss[0])
+    return out
+
+
 class _StepLossFn(torch.autograd.Function):
     """loss = UniVL.forward(...): the whole forward is one static plan, the whole backward another; parameter gradients
     are written straight into the flat gradient buffer (p.grad are views of it)."""
@@ -328,7 +340,7 @@ class _StepLossFn(torch.autograd.Function):
     def forward(ctx, anchor, model, step):
         model._run_plan(step.fwd, step)
         ctx.model, ctx.step, ctx.anchor = model, step, anchor
-        return step.loss[0].clone()
+        return _loss_out(step)
 
     @staticmethod
     def backward(ctx, gout):
@@ -633,9 +645,7 @@ class UniVL(UniVLPreTrainedModel):
         fl = self.flat
         used = self.used_parameter_names(st.kind)
         fresh = all(fl.params[n].grad is None for n in (used[0], used[-1]))
-        if gout is None:
-            st.gout.fill_(1.0)
-        else:
+        if gout is not None:                 # st.gout holds 1.0 between backwards (steps.Step): plain loss.backward() writes nothing
             st.gout.copy_(gout.reshape(1).to(torch.float32))
         if fl._pending is not None:          # a deferred clip nobody consumed: it scales the OLD gradients, as torch's did
             from .optimization import apply_pending_clip
@@ -653,6 +663,8 @@ class UniVL(UniVLPreTrainedModel):
         elif getattr(fl, "_word_rows", None) is not None:
             fl._word_rows[1][1] = 1                            # a dense writer ran: every row counts as listed from now on
         fl.attach_grads(used)
+        if gout is not None:
+            st.gout.fill_(1.0)
 
     def forward(self, input_ids, token_type_ids, attention_mask, video, video_mask=None,
                 pairs_masked_text=None, pairs_token_labels=None, masked_video=None, video_labels_index=None,
@@ -688,7 +700,7 @@ class UniVL(UniVLPreTrainedModel):
             out._univl = (self, st)
             return out
         self._run_plan(st.fwd, st)
-        return st.loss[0].clone()
+        return _loss_out(st)
 
     def get_sequence_visual_output(self, input_ids, token_type_ids, attention_mask, video, video_mask, shaped=False):
         """modeling.py:299-313.  `shaped=True` means the caller already flattened the pair dim AND normalised the video

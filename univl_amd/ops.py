@@ -226,6 +226,18 @@ def zero_many(tensors):
         _lib.check(L.univl_zero_many(ptrs, sizes, len(ts), _stream()), "zero_many")
 
 
+def copy_many(pairs):
+    """One launch for several device-to-device copies: pairs = [(dst, src), ...], same device, contiguous, equal byte sizes."""
+    import ctypes as C
+    L = _lib.lib()
+    for i in range(0, len(pairs), 16):
+        ps = pairs[i:i + 16]
+        srcs = (C.c_void_p * len(ps))(*[s.data_ptr() for _, s in ps])
+        dsts = (C.c_void_p * len(ps))(*[d.data_ptr() for d, _ in ps])
+        sizes = (C.c_int64 * len(ps))(*[d.numel() * d.element_size() for d, _ in ps])
+        _lib.check(L.univl_copy_many(srcs, dsts, sizes, len(ps), _stream()), "copy_many")
+
+
 def rows_zero(table, lst, meta):
     _lib.check(_lib.lib().univl_rows_zero(_p(table), table.shape[0], _p(lst), _p(meta), _stream()), "rows_zero")
 

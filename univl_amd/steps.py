@@ -54,6 +54,26 @@ def stage_input(dst, src):
     dst.copy_(src.reshape(dst.shape), non_blocking=True)
 
 
+def stage_inputs(pairs):
+    """[(dst, src), ...] -> dst <- src for every pair.  Sources that already live on the destination's device with the same
+    dtype and a contiguous layout (the usual case once a loader hands over device tensors, and always under
+    graphed.GraphedTrainStep) go through ONE copy kernel (ops.copy_many): as separate dst.copy_(src) calls they are memcpy
+    nodes of the captured step, ~10 us each in the round-2 kernel trace.  Everything else (host tensors, other dtypes, strided
+    views) takes stage_input."""
+    fast = []
+    use_kernel = os.environ.get("UNIVL_COPY_KERNEL", "1") != "0"        # A/B switch
+    for dst, src in pairs:
+        src = torch.as_tensor(src)
+        if (use_kernel and src.device == dst.device and dst.is_cuda and src.dtype == dst.dtype and src.numel() == dst.numel()
+                and src.is_contiguous() and dst.is_contiguous()):
+            if src.data_ptr() != dst.data_ptr():
+                fast.append((dst, src))
+        else:
+            stage_input(dst, src)
+    if fast:
+        ops.copy_many(fast)
+
+
 class EncoderPass:
     """NormalizeVideo + BertModel + VisualModel for one set of inputs (modeling.py:196-202, 299-313)."""
 
@@ -97,11 +117,8 @@ class EncoderPass:
 
     def load(self, input_ids, token_type_ids, attention_mask, video, video_mask):
         B, W, F = self.B, self.W, self.F
-        stage_input(self.ids, input_ids)
-        stage_input(self.type_ids, token_type_ids)
-        stage_input(self.amask, attention_mask)
-        stage_input(self.vn32 if self.normalized_input else self.video, video)
-        stage_input(self.vmask, video_mask)
+        stage_inputs([(self.ids, input_ids), (self.type_ids, token_type_ids), (self.amask, attention_mask),
+                      (self.vn32 if self.normalized_input else self.video, video), (self.vmask, video_mask)])
 
     def build_forward(self, fwd):
         cx, n, fl, dt, bf = self.cx, self.N, self.cx.fl, self.cx.dt, self.cx.bf
@@ -561,6 +578,7 @@ class Step:
     def __init__(self, cx):
         self.cx = cx
         self.loss, self.gout = cx.e(1), cx.e(1)
+        self.gout.fill_(1.0)         # invariant: holds 1.0 between backwards (UniVL._run_backward restores it after an explicit gout)
         self.fwd = Plan()
         self.bwd = {}
         self.loss_terms = []
@@ -570,7 +588,7 @@ class Step:
         self.fwd.wait_point("all")               # nothing after the forward may overtake an optimizer update in flight
         terms = self.loss_terms
         if len(terms) == 1:
-            self.fwd.add_callable(lambda: self.loss.copy_(terms[0]))
+            self.loss = terms[0]         # the loss kernel's own output buffer IS the step's loss: no copy node
         else:
             def add():
                 torch.add(terms[0], terms[1], out=self.loss)
