@@ -14,7 +14,7 @@ as `pcie_inclusive`.
 
 One process per GPU, per-GPU batch fixed (weak scaling), gradient exchange over RCCL overlapped with the backward.
 Prints ONE JSON line (rank 0) with
-  roofline      the kernel family that owns the step (every gemm_kernel / gemm_group_kernel launch of one step, replayed
+  roofline      the kernel family that owns the step (every gemm_kernel / gemm_pair_kernel / gemm_group_kernel launch of one step, replayed
                 alone as a hipGraph and timed with HIP events on the launch stream): algorithmic bytes and flops taken from
                 the launch descriptors, fractions of the 8 TB/s HBM and 2.5 PFLOP/s bf16 MFMA peaks; plus `adam` (the fused
                 BertAdam update, the largest single kernel) and `step` (parameter-proportional bytes of a whole step / step time)
@@ -335,8 +335,7 @@ def main():
     if gstep is not None:
         gstep.flush()                # a pipelined optimizer step may still be pending
 
-    roofline = None
-    if not args.no_extras:
+    def side_measurements():
         # ---- fused BertAdam update, HIP events on the launch stream
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a, kw = call_args(inputs)
@@ -373,7 +372,7 @@ def main():
                     traffic = None
         step_bytes = int((8 + bpp) * n_params + 1.0e8)
         roofline = dict(
-            kernel="gemm_kernel / gemm_group_kernel family (univl_amd/csrc/gemm.hip): every dense contraction of one step",
+            kernel="gemm_kernel / gemm_pair_kernel / gemm_group_kernel family (univl_amd/csrc/gemm.hip): every dense contraction of one step",
             bound="hbm" if hbm_frac >= mfma_frac else "mfma",
             achieved=round(fam["algorithmic_bytes_per_step"] / fam_s / 1e9, 1) if hbm_frac >= mfma_frac
             else round(fam["flops_per_step"] / fam_s / 1e12, 1),
@@ -391,6 +390,14 @@ def main():
                       mfma_frac=round(pairs_per_s * 37.30e9 / world / 2.5e15, 4), hbm_bytes_per_step=step_bytes,
                       achieved_gbs=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                       hbm_frac=round(step_bytes / 8.0e12 / (ms_per_step * 1e-3), 4)))
+        return roofline
+
+    roofline = None
+    try:
+        roofline = None if args.no_extras else side_measurements()
+    except Exception as ex:      # noqa: BLE001 -- a failing side measurement must never cost the headline line
+        print("[bench] rank %d: roofline side measurements failed (%s: %s)" % (rank, type(ex).__name__, ex), file=sys.stderr)
+        roofline = dict(error="%s: %s" % (type(ex).__name__, ex))
     exchange = None
     if model._reducer is not None:
         stp = [v for v in model._steps.values() if hasattr(v, "exchange_points")]

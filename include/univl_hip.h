@@ -115,6 +115,11 @@ int univl_gemm_group(const UnivlGemm* descs, int32_t n, hipStream_t stream);
  * the critical path -- a layer's weight gradients -- can run beside the next layer's latency-bound kernels on another
  * stream without taking the compute units away from them. */
 int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_blocks, hipStream_t stream);
+/* One launch for a dgrad product (dY . W: A K-major, B T-major) and the weight-gradient product that consumes the
+ * same upstream gradient (dY^T . X: both T-major) -- the two halves of one nn.Linear backward (e.g. module_bert.py:233, 246): the
+ * weight-gradient tiles fill the compute units the latency-bound dgrad leaves idle.  bf16, 64 x 64 tiles only (returns
+ * UNIVL_EUNSUPPORTED otherwise -- callers fall back to univl_gemm + univl_gemm_group); dry_run != 0 validates without launching. */
+int univl_gemm_pair(const UnivlGemm* dgrad, const UnivlGemm* wgrad, int32_t dry_run, hipStream_t stream);
 /* Host-side evaluation of the kernels' workgroup -> tile maps (no device work; lets a CPU test prove they are bijections):
  * what 0: plain-grid map, in out[0..2] = hardware block index, out = the tile that block computes;
  * what 1: out[0] <- position of linear workgroup out[0] in the XCD-grouped tile list of nx tiles;

@@ -19,7 +19,7 @@ def rows(d):
 
 
 def family(name):
-    if "gemm_group_kernel" in name or "gemm_kernel" in name or "gemm_burst_kernel" in name:
+    if "gemm_group_kernel" in name or "gemm_kernel" in name or "gemm_burst_kernel" in name or "gemm_pair_kernel" in name:
         return "gemm"
     if "adam_apply" in name:
         return "adam"

@@ -149,3 +149,68 @@ def test_gemm_workgroup_to_tile_maps_are_bijections(gm):
     for c in range(8):
         run = [_tile_map(1, total, 1, 1, gm, w)[0] for w in range(c, total, 8)]
         assert run == list(range(run[0], run[0] + len(run)))
+
+
+@pytest.mark.parametrize("kw,kind", [(dict(), "joint"), (dict(train_sim_after_cross=True), "align"),
+                                     (dict(stage_two=True, task_type="caption", decoder_num_hidden_layers=1), "caption"),
+                                     (dict(stage_two=True, do_pretrain=True, use_mil=True, decoder_num_hidden_layers=1), "pretrain")])
+@pytest.mark.parametrize("fresh", [True, False])
+def test_riding_weight_gradients_only_repackage_the_backward_plan(kw, kind, fresh, monkeypatch):
+    """UNIVL_WGRAD_RIDE: a weight-gradient GEMM goes out in the launch of the dgrad GEMM fed by the same upstream gradient
+    (univl_gemm_pair) instead of the layer's grouped launch.  Built on the CPU for every branch of UniVL.forward, the two
+    backward plans must contain exactly the same GEMM descriptors (same shapes, flags, parameter / gradient / norm
+    pointers), every other launch in the same order, and every pair must join the two halves of ONE nn.Linear: the dgrad
+    reads the weight at the flat offset the weight gradient is written to."""
+    import ctypes as C
+    from univl_amd.steps import build_step
+    m, cfg = _model("bf16", **kw)
+    fl = FlatParams(list(m.named_parameters()), "cpu", torch.bfloat16)
+    m._flat, m._seed_dev = fl, torch.zeros(1, dtype=torch.int64)
+    m.train()
+
+    def flat_off(ptr):
+        """(buffer, element offset) for pointers into the flat parameter storage, None for workspaces"""
+        if not ptr:
+            return None
+        for tag, t in (("p16", fl.p16), ("p32", fl.p32), ("g32", fl.g32), ("partials", fl.partials)):
+            lo = t.data_ptr()
+            if lo <= ptr < lo + t.numel() * t.element_size():
+                return tag, (ptr - lo) // t.element_size()
+        return "ws"
+
+    def rec(d):
+        return (d.M, d.N, d.K, d.trans_a, d.trans_b, d.flags, d.ksplit, d.lda, d.ldb, d.ldc, flat_off(d.B), flat_off(d.C32),
+                flat_off(d.bias), flat_off(d.dbias), flat_off(d.sumsq), d.sumsq_rows, d.sumsq_stride, bool(d.aux), bool(d.R))
+
+    def canon(plan):
+        chain, wgrads, pairs = [], [], []
+        for i, op in enumerate(plan.ops):
+            kind_, name = op[0], op[3]
+            if kind_ == "call" and name == "univl_gemm":
+                d = plan.descs[i][0]
+                (wgrads if (d.trans_a and d.trans_b and flat_off(d.C32) and flat_off(d.C32)[0] == "g32") else chain).append(("gemm",) + rec(d))
+            elif kind_ == "group":
+                wgrads += [("gemm",) + rec(d) for d in plan.descs[i]]
+            elif kind_ == "pair":
+                dg, wg = plan.descs[i]
+                chain.append(("gemm",) + rec(dg))
+                wgrads.append(("gemm",) + rec(wg))
+                pairs.append((dg, wg))
+            elif kind_ in ("call", "py", "eager"):
+                chain.append((name,))
+        return chain, sorted(wgrads, key=repr), pairs
+
+    monkeypatch.setenv("UNIVL_WGRAD_RIDE", "0")
+    base = build_step(m, kind, 2, 16, 16, True).backward_plan(fresh)
+    monkeypatch.setenv("UNIVL_WGRAD_RIDE", "1")
+    ride = build_step(m, kind, 2, 16, 16, True).backward_plan(fresh)
+    c0, w0, p0 = canon(base)
+    c1, w1, p1 = canon(ride)
+    assert not p0 and len(p1) >= 4 * (cfg.text_num_hidden_layers + cfg.visual_num_hidden_layers)
+    assert c0 == c1
+    assert w0 == w1 and len(w0) >= len(p1)
+    for dg, wg in p1:
+        assert not dg.trans_a and dg.trans_b and wg.trans_a and wg.trans_b
+        assert flat_off(dg.B)[0] == "p16" and flat_off(wg.C32)[0] == "g32"
+        assert flat_off(dg.B)[1] == flat_off(wg.C32)[1], "a pair must be the two halves of one nn.Linear backward"
+        assert dg.A == wg.A and dg.K == wg.M and dg.N == wg.N and dg.M == wg.K        # same upstream gradient dY [tokens, out]

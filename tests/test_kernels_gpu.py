@@ -821,3 +821,49 @@ def test_copy_many_bit_exact():
     d_ids, d_video, d_loss = torch.zeros_like(ids), torch.zeros_like(video), torch.empty((), device=DEV)
     ops.copy_many([(d_ids, ids), (d_video, video), (d_loss, loss)])
     assert torch.equal(d_ids, ids) and torch.equal(d_video, video) and float(d_loss) == float(loss)
+
+
+@pytest.mark.parametrize("T,K_out,K_in,ks", [(192, 768, 768, 2), (192, 3072, 768, 8), (192, 768, 3072, 1), (192, 2304, 768, 6),
+                                            (384, 768, 768, 1), (100, 768, 3072, 1)])
+def test_gemm_pair_equals_separate_launches(T, K_out, K_in, ks):
+    """univl_gemm_pair (UNIVL_WGRAD_RIDE, default on): the dgrad product dX = dY . W and the weight-gradient product
+    dW = dY^T . X of one nn.Linear backward in ONE launch give what the two separate launches give -- bit for bit for the
+    weight gradient, its bias gradient and the non-split dgrad; split-K dgrads and the fused gradient norm within fp32
+    summation-order noise -- with the dgrad epilogues of the step (GELU' / residual / split-K) and beta = 1 accumulation."""
+    bf = torch.bfloat16
+    dY = gen(T, K_out, seed=1).to(DEV, bf)                     # upstream gradient [tokens, out features]
+    W = gen(K_out, K_in, seed=2, scale=0.05).to(DEV, bf)       # nn.Linear weight [out, in]
+    X = gen(T, K_in, seed=3).to(DEV, bf)                       # saved input activation
+    gelu = K_in == 3072 and ks == 1                            # FFN2-dgrad shape: GELU' epilogue, bf16 output
+    u = gen(T, K_in, seed=4).to(DEV, bf) if gelu else None
+    res = None if gelu else gen(T, K_in, seed=5).to(DEV)
+
+    def run(pair):
+        dX32 = None if gelu else torch.zeros(T, K_in, device=DEV)
+        dX16 = torch.zeros(T, K_in, device=DEV, dtype=bf) if gelu else None
+        dW = gen(K_out, K_in, seed=6).to(DEV)                  # accumulate into an existing gradient (beta = 1)
+        db = torch.zeros(K_out, device=DEV)
+        part = torch.zeros(K_out * K_in // 1024, device=DEV)
+        dg = ops.gemm_desc(dY, W, T, K_in, K_out, trans_b=True, out32=dX32, out16=dX16, aux=u, gelu="bwd" if gelu else None,
+                           residual=res, ksplit=ks)
+        wg = ops.gemm_desc(dY, X, K_out, K_in, T, trans_a=True, trans_b=True, out32=dW, accumulate=True, dbias=db,
+                           sumsq=part, sumsq_rows=0, sumsq_stride=part.numel())
+        if pair:
+            assert ops.gemm_pair(dg, wg), "the C side refused a bf16 64-tile pair"
+        else:
+            _lib.check(_lib.lib().univl_gemm(ops._BYREF(dg), ops._stream()), "gemm")
+            _lib.check(_lib.lib().univl_gemm(ops._BYREF(wg), ops._stream()), "gemm")
+        torch.cuda.synchronize()
+        return (dX16 if gelu else dX32).float().cpu(), dW.cpu(), db.cpu(), float(part.double().sum())
+
+    x1, w1, b1, s1 = run(True)
+    x0, w0, b0, s0 = run(False)
+    ref_w = gen(K_out, K_in, seed=6).double() + dY.double().cpu().T @ X.double().cpu()
+    assert rel_err(w0, ref_w) < 1e-2 and rel_err(w1, ref_w) < 1e-2
+    assert torch.equal(w1, w0), float((w1 - w0).abs().max())
+    assert torch.equal(b1, b0)
+    if ks == 1:
+        assert torch.equal(x1, x0)
+    else:
+        assert rel_err(x1, x0) < 1e-5
+    assert abs(s1 - s0) <= 1e-5 * abs(s0) and s0 > 0

@@ -609,3 +609,23 @@ def test_sparse_word_table_bookkeeping_matches_dense_clear(monkeypatch):
     # the round-2 sessions: 0.4e-7 ... 1.5e-7).  One BertAdam step moves a touched element by lr * |m| / sqrt(v) ~ 3e-4 here, so
     # a row the sparse bookkeeping forgot to clear or to count would show up ~1000x above this gate.
     assert max_abs(w1, w0) < 5e-7
+
+
+@pytest.mark.parametrize("ride", ["1", "0"])
+@pytest.mark.parametrize("name", ["joint_full", "caption_small", "pretrain_small"])
+def test_weight_gradient_packaging_matches_golden(golden_dir, name, ride, monkeypatch):
+    """UNIVL_WGRAD_RIDE=1 (default): every encoder weight-gradient GEMM goes out in the launch of the dgrad GEMM that consumes the
+    same upstream gradient (univl_gemm_pair); =0: the layer's grouped launch at the end of its chain.  Both give the loss and
+    the gradients of the reference's golden vectors inside the ordinary bf16 gates, and the plan really is what the switch says."""
+    monkeypatch.setenv("UNIVL_WGRAD_RIDE", ride)
+    test_forward_backward_vs_reference_golden(golden_dir, name, torch.bfloat16)
+    cfg, rows, dseed = case_config(name)
+    model, _ = build(cfg, torch.bfloat16)
+    model.train()
+    call(model, O.synthetic_batch(cfg, rows, seed=dseed)).backward()
+    st = next(iter(model._steps.values()))
+    kinds = [op[3] for op in st.backward_plan(True).ops]
+    if ride == "1":
+        assert kinds.count("univl_gemm_pair") >= 4 * (cfg.text_num_hidden_layers + cfg.visual_num_hidden_layers)
+    else:
+        assert kinds.count("univl_gemm_pair") == 0 and kinds.count("univl_gemm_group") >= cfg.text_num_hidden_layers + cfg.visual_num_hidden_layers

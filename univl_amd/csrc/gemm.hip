@@ -438,7 +438,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         const int tensor = p.sumsq_rows > 0 ? m0 / p.sumsq_rows : 0;
         const int mloc = p.sumsq_rows > 0 ? m0 % p.sumsq_rows : m0;
         const int nx = (p.N + BN - 1) / BN;
-        if (lane == 0) p.sumsq[(long)tensor * p.sumsq_stride + ((mloc / BM) * nx + bx) * NW + wave] = ssq;
+        if constexpr (NW == 8 && BM * BN == 64 * 64) {
+            // the host reserves 4 slots per 64 x 64 tile (rows x N / 1024): waves w and w + 4 share one (p.sumsq is uniform)
+            __syncthreads();                     // every wave is past its last fragment read: the stages are free
+            float* red = reinterpret_cast<float*>(smem_raw);
+            if (lane == 0) red[wave] = ssq;
+            __syncthreads();
+            if (lane == 0 && wave < 4) p.sumsq[(long)tensor * p.sumsq_stride + ((mloc / BM) * nx + bx) * 4 + wave] = red[wave] + red[wave + 4];
+        } else {
+            if (lane == 0) p.sumsq[(long)tensor * p.sumsq_stride + ((mloc / BM) * nx + bx) * NW + wave] = ssq;
+        }
     }
     if (want_dbias && tid < BM) {
         const int row = m0 + tid;
@@ -580,6 +589,60 @@ int launch_group(const GroupArgs& g, int max_blocks, hipStream_t stream) {
     const int total = g.first[UNIVL_GEMM_GROUP_MAX];
     const int grid = (max_blocks > 0 && max_blocks < total) ? max_blocks : total;
     hipLaunchKernelGGL((gemm_group_kernel<T, TA, TB, BM, BN, D, NC, WGM, WGN>), dim3(grid), dim3(NT), smem, stream, g);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+// (engine.EncoderStack, UNIVL_WGRAD_RIDE, default on): a dgrad product and the weight-gradient product that consumes the SAME
+// upstream gradient in ONE launch.  At a few hundred tokens a dgrad kernel is a latency chain on 36-144 workgroups that leaves most
+// of the 256 compute units idle, while the layer's grouped weight-gradient launch (1728 tiles at 4 pairs x 48 tokens) is the longest
+// node of the backward chain (~29 us of ~100 us per layer) although nothing downstream waits for it.  Here the weight-gradient
+// tiles fill the compute units the dgrad leaves idle: the dgrad tiles take the first workgroup ids (dispatched first, spread over
+// the 8 XCDs; padded to a multiple of 8 so that the weight-gradient ids keep their own id % 8 = XCD relation), the weight-gradient
+// tiles follow.  No extra stream, no extra graph branch (every cross-branch edge of a hipGraph costs ~30 us here).
+// Both tile bodies are the 64 x 64 tile on 8 waves; NCW = K-step depth of the weight-gradient body (6: the 192-deep single step).
+struct PairArgs {
+    GemmArgs d, w;
+    int nd, nd_pad, nw;
+    int dnx, dny, dnz, wnx, wny, wnz;
+};
+
+__device__ __forceinline__ void pair_tile(int t, int total, int nx, int ny, int nz, int flags, int gm, int& bx, int& by, int& bz) {
+    if ((flags & UNIVL_GEMM_XCD_MAP) && total >= 16 && ny > 1) {
+        tile_of(xcd_run(t, total), nx, ny, nz, gm, bx, by, bz);
+    } else {
+        const int nxy = nx * ny;
+        bz = t / nxy;
+        const int rem = t - bz * nxy;
+        by = rem / nx;
+        bx = rem - by * nx;
+    }
+}
+
+template <int NCW>
+__global__ __launch_bounds__(512, 2) void gemm_pair_kernel(PairArgs a) {
+    const int w0 = blockIdx.x;
+    int bx, by, bz;
+    if (w0 < a.nd_pad) {
+        if (w0 >= a.nd) return;                                  // padding workgroup (whole block: no barrier is skipped)
+        pair_tile(w0, a.nd, a.dnx, a.dny, a.dnz, a.d.flags, a.d.gm, bx, by, bz);
+        gemm_tile<__bf16, false, true, 64, 64, 2, 4, 0, 2, 4>(a.d, bx, by, bz, a.dnz);
+    } else {
+        pair_tile(w0 - a.nd_pad, a.nw, a.wnx, a.wny, a.wnz, a.w.flags, a.w.gm, bx, by, bz);
+        gemm_tile<__bf16, true, true, 64, 64, 2, NCW, 0, 2, 4>(a.w, bx, by, bz, a.wnz);
+    }
+}
+
+template <int NCW>
+int launch_pair(const PairArgs& a, hipStream_t stream) {
+    using TA_d = Tile<__bf16, false, 64, 4 * 32, 512>;
+    using TA_w = Tile<__bf16, true, 64, NCW * 32, 512>;
+    const size_t smem_d = 2 * (size_t)(TA_d::BYTES + TA_d::BYTES);                 // A and B tiles are both 64 rows x BK
+    const size_t smem_w = NCW == 6 ? 3 * (size_t)TA_w::BYTES : 4 * (size_t)TA_w::BYTES;   // one-step form: stage 0 of B only
+    const size_t smem = smem_d > smem_w ? smem_d : smem_w;
+    static bool attr_done[UNIVL_MAX_DEVICES] = {};
+    univl_allow_lds(gemm_pair_kernel<NCW>, smem, attr_done);
+    hipLaunchKernelGGL((gemm_pair_kernel<NCW>), dim3(a.nd_pad + a.nw), dim3(512), smem, stream, a);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
@@ -780,6 +843,29 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
     }
     if (c.tile == 128) return dispatch_trans<float, 128, 128, 2, 2>(a, ta, tb, ksplit, stream);
     return dispatch_trans<float, 64, 64, 2, 4>(a, ta, tb, ksplit, stream);
+}
+
+extern "C" int univl_gemm_pair(const UnivlGemm* dgrad, const UnivlGemm* wgrad, int32_t dry_run, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    UNIVL_CHECK_ARG(dgrad != nullptr && wgrad != nullptr, UNIVL_EINVAL, "univl_gemm_pair: null descriptor");
+    PairArgs a;
+    int ksd, ksw;
+    Choice cd, cw;
+    int rc = prepare(dgrad, a.d, ksd, cd);
+    if (rc != UNIVL_OK) return rc;
+    rc = prepare(wgrad, a.w, ksw, cw);
+    if (rc != UNIVL_OK) return rc;
+    // both bodies are the 64 x 64 bf16 tile; the dgrad body stages 128-deep K steps, the weight-gradient body 128- or 192-deep ones
+    UNIVL_CHECK_ARG(dgrad->dtype == UNIVL_BF16 && wgrad->dtype == UNIVL_BF16 && !dgrad->trans_a && dgrad->trans_b && wgrad->trans_a &&
+                        wgrad->trans_b && cd.tile == 64 && cw.tile == 64 && cd.nc == 4 && (cw.nc == 4 || cw.nc == 6) && !dgrad->sumsq,
+                    UNIVL_EUNSUPPORTED, "univl_gemm_pair: needs a bf16 (K-major, T-major) product and a bf16 (T-major, T-major) product on the 64 tile");
+    a.dnx = (dgrad->N + 63) / 64; a.dny = (dgrad->M + 63) / 64; a.dnz = ksd;
+    a.wnx = (wgrad->N + 63) / 64; a.wny = (wgrad->M + 63) / 64; a.wnz = ksw;
+    a.nd = a.dnx * a.dny * a.dnz;
+    a.nd_pad = (a.nd + 7) / 8 * 8;
+    a.nw = a.wnx * a.wny * a.wnz;
+    if (dry_run) return UNIVL_OK;
+    return cw.nc == 6 ? launch_pair<6>(a, stream) : launch_pair<4>(a, stream);
 }
 
 extern "C" int univl_gemm_group(const UnivlGemm* d, int n, hipStream_t stream) {

@@ -298,6 +298,15 @@ class Plan:
             self.descs[len(self.ops)] = list(chunk)
             self.ops.append(("group", fn, (arr, len(chunk), int(max_blocks)), "univl_gemm_group", stream))
 
+    def add_gemm_pair(self, dgrad, wgrad, stream=0):
+        """A dgrad product and the weight-gradient product fed by the same upstream gradient as
+        ONE launch (univl_gemm_pair) -- the weight-gradient tiles fill the compute units the latency-bound dgrad leaves idle."""
+        fn = _lib.lib().univl_gemm_pair
+        arr = (_lib.Gemm * 2)(dgrad, wgrad)
+        self.keep.append(arr)
+        self.descs[len(self.ops)] = [dgrad, wgrad]
+        self.ops.append(("pair", fn, arr, "univl_gemm_pair", stream))
+
     def add_zeros(self, tensors, stream=0):
         """Clear several buffers with one launch (univl_zero_many)."""
         ts = [t for t in tensors if t is not None and t.numel() > 0]
@@ -355,6 +364,13 @@ class Plan:
                 if h is None:
                     h = handles[sidx] = C.c_void_p(self._stream(sidx, cur).cuda_stream)
                 rc = a(b[0], b[1], b[2], h)
+                if rc != 0:
+                    _lib.check(rc, name)
+            elif kind == "pair":
+                h = handles.get(sidx)
+                if h is None:
+                    h = handles[sidx] = C.c_void_p(self._stream(sidx, cur).cuda_stream)
+                rc = a(C.byref(b[0]), C.byref(b[1]), 0, h)
                 if rc != 0:
                     _lib.check(rc, name)
             elif kind == "record":
@@ -442,6 +458,8 @@ class Plan:
                 out.append((lambda h, fn=fn, arg=arg: fn(arg, h), self.descs[i]))
             elif kind == "group" and name.startswith(prefix):
                 out.append((lambda h, fn=fn, arg=arg: fn(arg[0], arg[1], arg[2], h), self.descs[i]))
+            elif kind == "pair" and name.startswith(prefix):
+                out.append((lambda h, fn=fn, arg=arg: fn(C.byref(arg[0]), C.byref(arg[1]), 0, h), self.descs[i]))
         return out
 
     @property
@@ -516,6 +534,14 @@ class EncoderStack:
         self.sw = s_wgrad if (s_wgrad is not None and self.wg_blocks > 0 and n_layers > 1) else None
         self.s_off = s_offload if (s_offload is not None and n_offload > 0 and self.sw is None) else None
         self.n_off = min(int(n_offload), n_layers) if self.s_off is not None else 0
+        # Every weight-gradient GEMM rides in the launch of the dgrad GEMM that consumes the same upstream gradient
+        # (Plan.add_gemm_pair) instead of the layer's grouped launch at the end of the chain: the grouped launch was the longest
+        # node of the backward chain (29 of ~100 us per layer at 4 pairs) although nothing downstream waits for it, and the dgrad
+        # kernels it now shares a launch with leave most compute units idle.  Measured 2.85 vs 3.11 ms per step at 4 pairs
+        # (profiles/r02h_ab_wgrad_ride.txt).  bf16, 64 x 64 tiles only -- the C side refuses other pairs (univl_gemm_pair dry run)
+        # and those weight gradients stay in the grouped launch.  UNIVL_WGRAD_RIDE=0: the grouped launch for all of them.
+        self.ride = (os.environ.get("UNIVL_WGRAD_RIDE", "1") == "1" and flat.compute_dtype == torch.bfloat16
+                     and self.sw is None and self.s_off is None)
         self.T = B * S
         self.key_mask = key_mask            # int64 [B,S] device tensor (static buffer)
         self.p = float(p_drop)
@@ -649,38 +675,51 @@ class EncoderStack:
                 dt, T, H, gamma=fl.w32(nm["ln2_g"]), y=ws["y2"], stats=ws["st2"], dout=gin, dx32=dz, dxd16=s_dxd,
                 dgamma=fl.g(nm["ln2_g"]), dbeta=fl.g(nm["ln2_b"]), dbias=fl.g(nm["b2"]), p_pre=p, off_pre=ws["off"][2],
                 seed_dev=self.seed_dev), sm)
-            wgrads = [_gemm_desc(dt, s_dxd, H, ws["f"], I, H, I, T, trans_a=1, trans_b=1,
-                                 out32=fl.g(nm["w2"]), ldc=I, accumulate=gs.acc(nm["w2"]), nt_out=self.nt_wgrad, **gs.sumsq_args(nm["w2"], H, I))]
-            plan.add("univl_gemm", _gemm_desc(dt, s_dxd, H, fl.wop(nm["w2"]), I, T, I, H, trans_b=1, out16=s_du,
-                                              ldc=I, aux=ws["u"], ldaux=I, gelu="bwd"), sm)
-            wgrads.append(_gemm_desc(dt, s_du, I, ws["a16"], H, I, H, T, trans_a=1, trans_b=1,
-                                     out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=fl.g(nm["b1"]), nt_out=self.nt_wgrad,
-                                     **gs.sumsq_args(nm["w1"], I, H)))
-            plan.add("univl_gemm", _gemm_desc(dt, s_du, I, fl.wop(nm["w1"]), H, T, H, I, trans_b=1, out32=da, ldc=H,
-                                              residual=dz, ldr=H, ksplit=self.ksplit_for(I)), sm)
+            wgrads = []
+
+            def emit(dgrad, wgrad):
+                """dgrad on the chain; its weight-gradient twin either into the layer's grouped launch (default) or into the
+                SAME launch (self.ride, where the C side accepts the pair: bf16, 64 x 64 tiles)."""
+                if self.ride and _lib.lib().univl_gemm_pair(C.byref(dgrad), C.byref(wgrad), 1, None) == 0:
+                    plan.add_gemm_pair(dgrad, wgrad, sm)
+                else:
+                    plan.add("univl_gemm", dgrad, sm)
+                    wgrads.append(wgrad)
+
+            w_ffn2 = _gemm_desc(dt, s_dxd, H, ws["f"], I, H, I, T, trans_a=1, trans_b=1,
+                                out32=fl.g(nm["w2"]), ldc=I, accumulate=gs.acc(nm["w2"]), nt_out=self.nt_wgrad, **gs.sumsq_args(nm["w2"], H, I))
+            emit(_gemm_desc(dt, s_dxd, H, fl.wop(nm["w2"]), I, T, I, H, trans_b=1, out16=s_du,
+                            ldc=I, aux=ws["u"], ldaux=I, gelu="bwd"), w_ffn2)
+            w_ffn1 = _gemm_desc(dt, s_du, I, ws["a16"], H, I, H, T, trans_a=1, trans_b=1,
+                                out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=fl.g(nm["b1"]), nt_out=self.nt_wgrad,
+                                **gs.sumsq_args(nm["w1"], I, H))
+            emit(_gemm_desc(dt, s_du, I, fl.wop(nm["w1"]), H, T, H, I, trans_b=1, out32=da, ldc=H,
+                            residual=dz, ldr=H, ksplit=self.ksplit_for(I)), w_ffn1)
             # attention-output LayerNorm / dropout backward (BertSelfOutput, module_bert.py:207-211)
             dy = self.gbuf
             plan.add("univl_layernorm_bwd", ops.layernorm_desc(
                 dt, T, H, gamma=fl.w32(nm["ln1_g"]), y=ws["y1"], stats=ws["st1"], dout=da, dx32=dy, dxd16=s_dxd2,
                 dgamma=fl.g(nm["ln1_g"]), dbeta=fl.g(nm["ln1_b"]), dbias=fl.g(nm["o_b"]), p_pre=p, off_pre=ws["off"][1],
                 seed_dev=self.seed_dev), sm)
-            wgrads.append(_gemm_desc(dt, s_dxd2, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
-                                     out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"]), nt_out=self.nt_wgrad, **gs.sumsq_args(nm["o_w"], H, H)))
-            plan.add("univl_gemm", _gemm_desc(dt, s_dxd2, H, fl.wop(nm["o_w"]), H, T, H, H, trans_b=1, out16=self.dctx, ldc=H), sm)
+            w_o = _gemm_desc(dt, s_dxd2, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
+                             out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"]), nt_out=self.nt_wgrad, **gs.sumsq_args(nm["o_w"], H, H))
+            emit(_gemm_desc(dt, s_dxd2, H, fl.wop(nm["o_w"]), H, T, H, H, trans_b=1, out16=self.dctx, ldc=H), w_o)
             qkv, dqkv = ws["qkv"], s_dqkv
             plan.add("univl_attention_bwd", ops.attention_desc(
                 dt, B, self.NH, S, S, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx"], H, ws["lse"],
                 key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev, dout=self.dctx, lddo=H,
                 dq=(dqkv, 0), lddq=3 * H, dk=(dqkv, H), lddk=3 * H, dv=(dqkv, 2 * H), lddv=3 * H), sm)
-            wgrads.append(_gemm_desc(dt, dqkv, 3 * H, xin16, H, 3 * H, H, T, trans_a=1, trans_b=1,
-                                     out32=fl.g_fused(nm["qkv_w"]), ldc=H, accumulate=gs.acc(nm["qkv_w"][0]),
-                                     dbias=fl.g_fused(nm["qkv_b"]), nt_out=self.nt_wgrad, **gs.sumsq_args(nm["qkv_w"], H, H)))
+            w_qkv = _gemm_desc(dt, dqkv, 3 * H, xin16, H, 3 * H, H, T, trans_a=1, trans_b=1,
+                               out32=fl.g_fused(nm["qkv_w"]), ldc=H, accumulate=gs.acc(nm["qkv_w"][0]),
+                               dbias=fl.g_fused(nm["qkv_b"]), nt_out=self.nt_wgrad, **gs.sumsq_args(nm["qkv_w"], H, H))
             dx = self.garena[l, 1]
-            plan.add("univl_gemm", _gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["qkv_w"]), H, T, H, 3 * H, trans_b=1,
-                                              out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ksplit_for(3 * H)), sm)
+            emit(_gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["qkv_w"]), H, T, H, 3 * H, trans_b=1,
+                            out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ksplit_for(3 * H)), w_qkv)
             # the layer's four weight-gradient GEMMs only consume tensors the chain above produced (dxd, du, dxd2, dqkv
             # are distinct buffers): one grouped launch, after which the scratch may be reused by the next layer
-            if off:
+            if not wgrads:
+                pass                                    # self.ride: every weight gradient went out with its dgrad
+            elif off:
                 plan.fork(sm, self.s_off)               # the other stack's stream picks them up once this chain got here
                 plan.add_gemm_group(wgrads, self.s_off)
             elif sw is None:

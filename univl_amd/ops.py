@@ -93,6 +93,16 @@ def gemm_group(descs, max_blocks=0):
     _lib.check(_lib.lib().univl_gemm_group_limited(arr, len(descs), int(max_blocks), _stream()), "gemm_group")
 
 
+def gemm_pair(dgrad, wgrad, dry_run=False):
+    """One launch for a dgrad product and the weight-gradient product fed by the same upstream gradient
+    (univl_gemm_pair).  Returns False when the C side does not take the pair (not bf16 / not on the 64 tile)."""
+    rc = _lib.lib().univl_gemm_pair(_BYREF(dgrad), _BYREF(wgrad), int(bool(dry_run)), _stream())
+    if rc == -3:
+        return False
+    _lib.check(rc, "gemm_pair")
+    return True
+
+
 def layernorm_desc(dtype, rows, N, *, x=None, x_f64=False, residual=None, pos=None, pos_period=0, gamma=None,
                    beta=None, eps=1e-12, y=None, stats=None, out32=None, out16=None, p_pre=0.0, p_post=0.0, seed=0,
                    off_pre=0, off_post=0, seed_dev=None, dout=None, dx32=None, dxd32=None, dxd16=None, dgamma=None,
