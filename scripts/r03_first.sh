@@ -41,6 +41,18 @@ ab b16_grouped 16 UNIVL_WGRAD_RIDE=0
 ab b128 128 UNIVL_X=0
 t=$(lim 60); [ $t -gt 0 ] && { timeout $t python bench.py --loopback --steps 150 --warmup 15 --no-cpu-baseline --no-extras > $OUT/ab_b4_loopback.json 2> $OUT/ab_b4_loopback.err; echo "b4_loopback: $(grep -o '"ms_per_step": [0-9.]*' $OUT/ab_b4_loopback.json)" | tee -a $OUT/ab_summary.txt; }
 stamp "A/B done"
+# EXPERIMENTAL (written blind at the end of round 2, never run on a GPU): the BertAdam update riding with the next forward
+t=$(lim 150); [ $t -gt 30 ] && { (UNIVL_EXPERIMENTAL=1 timeout $t python -m pytest tests/test_model_gpu.py -m gpu -x -q -k "adam_update_riding" > $OUT/pytest_adam_ride.log 2>&1; echo "rc=$?" >> $OUT/pytest_adam_ride.log); tail -3 $OUT/pytest_adam_ride.log; }
+abp() {   # name env...   (pipelined optimizer forms)
+  local name=$1 t; shift
+  t=$(lim 60); [ $t -gt 0 ] || return
+  env "$@" timeout $t python bench.py --pipeline --steps 150 --warmup 15 --no-cpu-baseline --no-extras > $OUT/ab_$name.json 2> $OUT/ab_$name.err
+  echo "$name: $(grep -o '"ms_per_step": [0-9.]*' $OUT/ab_$name.json) $(grep -o '"last_loss": [0-9.]*' $OUT/ab_$name.json)" | tee -a $OUT/ab_summary.txt
+}
+abp b4_adam_ride UNIVL_ADAM_RIDE=1
+abp b4_adam_ride_cap64 UNIVL_ADAM_RIDE=1 UNIVL_ADAM_BLOCKS=64
+abp b4_adam_sidestream UNIVL_ADAM_RIDE=0
+stamp "adam ride done"
 t=$(lim 100); [ $t -gt 20 ] && { (cd /tmp && timeout $t rocprofv3 --kernel-trace --stats -d $P/gpurun_out/r03a/prof -o eager --output-format csv -- python $P/bench.py --steps 20 --warmup 5 --no-graph --no-cpu-baseline --no-extras > $P/$OUT/prof_bench.json 2> $P/$OUT/prof_bench.err)
   find gpurun_out/r03a/prof -name "*kernel_stats.csv" -exec cp {} $OUT/eager_kernel_stats.csv \; ; rm -rf gpurun_out/r03a/prof; }
 t=$(lim 100); [ $t -gt 20 ] && { (cd /tmp && timeout $t rocprofv3 --kernel-trace --stats -d $P/gpurun_out/r03a/profg -o graph --output-format csv -- python $P/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras > $P/$OUT/profg_bench.json 2> $P/$OUT/profg_bench.err)

@@ -214,3 +214,27 @@ def test_riding_weight_gradients_only_repackage_the_backward_plan(kw, kind, fres
         assert flat_off(dg.B)[0] == "p16" and flat_off(wg.C32)[0] == "g32"
         assert flat_off(dg.B)[1] == flat_off(wg.C32)[1], "a pair must be the two halves of one nn.Linear backward"
         assert dg.A == wg.A and dg.K == wg.M and dg.N == wg.N and dg.M == wg.K        # same upstream gradient dY [tokens, out]
+
+
+def test_adam_rider_plan_builds_on_cpu(monkeypatch):
+    """UNIVL_ADAM_RIDE (experimental): in the forward plan the four products of every text / video layer but the last become rider
+    launches keyed by the NEXT layer of the same stack; nothing else changes, and the backward plan is untouched."""
+    from univl_amd.steps import build_step
+    m, cfg = _model("bf16")
+    m._flat, m._seed_dev = FlatParams(list(m.named_parameters()), "cpu", torch.bfloat16), torch.zeros(1, dtype=torch.int64)
+    m.train()
+    monkeypatch.setenv("UNIVL_ADAM_RIDE", "0")
+    base = build_step(m, "joint", 2, 16, 16, True)
+    monkeypatch.setenv("UNIVL_ADAM_RIDE", "1")
+    ride = build_step(m, "joint", 2, 16, 16, True)
+    names0 = [op[3] for op in base.fwd.ops]
+    names1 = [op[3] for op in ride.fwd.ops]
+    assert [n.replace("univl_gemm_rider", "univl_gemm") for n in names1] == names0
+    riders = [op[2] for op in ride.fwd.ops if op[0] == "rider"]
+    L_t, L_v = cfg.text_num_hidden_layers, cfg.visual_num_hidden_layers
+    assert len(riders) == 4 * ((L_t - 1) + (L_v - 1))
+    assert ride.fwd.rider_keys == {("layer", "bert", l) for l in range(1, L_t)} | {("layer", "visual", l) for l in range(1, L_v)}
+    for key in ride.fwd.rider_keys:
+        assert sorted(r[2] for r in riders if r[1] == key) == [0, 1, 2, 3]
+    assert not base.fwd.rider_keys and len(ride.fwd.launches("univl_gemm")) == len(base.fwd.launches("univl_gemm"))
+    assert [op[3] for op in ride.backward_plan(True).ops] == [op[3] for op in base.backward_plan(True).ops]

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "univl_hip.h"
+#include "adam_body.h"
 
 namespace {
 
@@ -647,6 +648,27 @@ int launch_pair(const PairArgs& a, hipStream_t stream) {
     return UNIVL_OK;
 }
 
+// EXPERIMENTAL (UNIVL_ADAM_RIDE=1 with graphed.GraphedTrainStep(pipeline_optimizer=True)): a forward product and a range of BertAdam
+// chunks in ONE launch.  The fused update is one 0.8 ms HBM stream (30 B per parameter) at the end of a step whose forward is a chain
+// of latency-bound kernels on a third of the compute units; its only ordering constraints are "after the clip of its own backward"
+// and "layer l's parameters before layer l's first kernel of the NEXT forward".  So the update of step t goes out with the forward of
+// step t + 1: the chunks of layer l + 1 as extra workgroups of the forward products of layer l (same stream: the kernel boundary is
+// the dependency), with no second stream and no graph branch -- the earlier side-stream form of this overlap lost ~0.6 ms to 19
+// cross-branch graph edges.  The GEMM tiles take the first workgroup ids (dispatched first).
+template <bool NT>
+__global__ __launch_bounds__(512, 2) void gemm_adam_kernel(GemmArgs g, int nd, int nd_pad, int nx, int ny, int nz, UnivlAdam a, int c0, int c1) {
+    const int w0 = blockIdx.x;
+    if (w0 < nd_pad) {
+        if (w0 >= nd) return;                                  // padding workgroup
+        int bx, by, bz;
+        pair_tile(w0, nd, nx, ny, nz, g.flags, g.gm, bx, by, bz);
+        gemm_tile<__bf16, false, false, 64, 64, 2, 4, 0, 2, 4>(g, bx, by, bz, nz);
+    } else {
+        const int nb = (int)gridDim.x - nd_pad;
+        for (int c = c0 + (w0 - nd_pad); c < c1; c += nb) adam_chunk<NT, 512>(a, c);
+    }
+}
+
 template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC, int WGM = 2, int WGN = 2>
 int launch(const GemmArgs& a, int ksplit, hipStream_t stream) {
     constexpr int BK = NC * Mma<T>::CH, NT = 64 * WGM * WGN;
@@ -866,6 +888,44 @@ extern "C" int univl_gemm_pair(const UnivlGemm* dgrad, const UnivlGemm* wgrad, i
     a.nw = a.wnx * a.wny * a.wnz;
     if (dry_run) return UNIVL_OK;
     return cw.nc == 6 ? launch_pair<6>(a, stream) : launch_pair<4>(a, stream);
+}
+
+extern "C" int univl_gemm_rider(const UnivlGemm* gemm, const UnivlAdam* adam, int32_t chunk_begin, int32_t chunk_count,
+                                int32_t max_blocks, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    UNIVL_CHECK_ARG(gemm != nullptr && adam != nullptr, UNIVL_EINVAL, "univl_gemm_rider: null descriptor");
+    UNIVL_CHECK_ARG(adam->p && adam->g && adam->m && adam->v && adam->segs && adam->chunk_seg && adam->chunk_off && adam->chunk_len &&
+                        adam->seg_scalars && adam->nchunk > 0 && chunk_begin >= 0 && chunk_count >= 0 &&
+                        chunk_begin + chunk_count <= adam->nchunk,
+                    UNIVL_EINVAL, "univl_gemm_rider: chunks [%d, +%d) of %d", chunk_begin, chunk_count, adam ? adam->nchunk : 0);
+    GemmArgs a;
+    int ks;
+    Choice c;
+    const int rc = prepare(gemm, a, ks, c);
+    if (rc != UNIVL_OK) return rc;
+    const bool fits = gemm->dtype == UNIVL_BF16 && !gemm->trans_a && !gemm->trans_b && c.tile == 64 && c.nc == 4 && !gemm->sumsq && !gemm->dbias;
+    if (!fits || chunk_count == 0) {          // not a product this kernel carries: the two launches one after the other (same result)
+        const int r1 = univl_gemm(gemm, stream);
+        if (r1 != UNIVL_OK || chunk_count == 0) return r1;
+        return univl_bert_adam_range(adam, chunk_begin, chunk_count, 0, max_blocks, stream);
+    }
+    const int nx = (gemm->N + 63) / 64, ny = (gemm->M + 63) / 64;
+    const int nd = nx * ny * ks, nd_pad = (nd + 7) / 8 * 8;
+    const int nb = (max_blocks > 0 && max_blocks < chunk_count) ? max_blocks : chunk_count;
+    const size_t smem = 4 * (size_t)Tile<__bf16, false, 64, 128, 512>::BYTES;          // two stages of A and B
+    static const int nt = (int)env_long("UNIVL_ADAM_NT", 1L);
+    static bool done_nt[UNIVL_MAX_DEVICES] = {}, done_t[UNIVL_MAX_DEVICES] = {};
+    if (nt) {
+        univl_allow_lds(gemm_adam_kernel<true>, smem, done_nt);
+        hipLaunchKernelGGL(gemm_adam_kernel<true>, dim3(nd_pad + nb), dim3(512), smem, stream, a, nd, nd_pad, nx, ny, ks, *adam, chunk_begin,
+                           chunk_begin + chunk_count);
+    } else {
+        univl_allow_lds(gemm_adam_kernel<false>, smem, done_t);
+        hipLaunchKernelGGL(gemm_adam_kernel<false>, dim3(nd_pad + nb), dim3(512), smem, stream, a, nd, nd_pad, nx, ny, ks, *adam, chunk_begin,
+                           chunk_begin + chunk_count);
+    }
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
 }
 
 extern "C" int univl_gemm_group(const UnivlGemm* d, int n, hipStream_t stream) {

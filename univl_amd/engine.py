@@ -276,6 +276,16 @@ class Plan:
         self.external = {}           # key -> event recorded by somebody else (see wait_point)
         self._side = {}
         self._segments = None
+        self.rider_keys = set()      # chunk-group keys this plan can carry beside its forward products (add_gemm_rider)
+        self.riders = None           # set for the duration of one run: dict(desc=UnivlAdam, ranges={key: (first, count)}, max_blocks=int)
+
+    def add_gemm_rider(self, desc, key, slot, nslots, stream=0):
+        """EXPERIMENTAL (UNIVL_ADAM_RIDE): a forward product that, while self.riders names a chunk range for `key`, also carries
+        the slot-th of nslots parts of that range of a prepared BertAdam update (univl_gemm_rider); otherwise a plain univl_gemm."""
+        self.keep.append(desc)
+        self.descs[len(self.ops)] = [desc]
+        self.rider_keys.add(key)
+        self.ops.append(("rider", _lib.lib().univl_gemm_rider, (desc, key, int(slot), int(nslots)), "univl_gemm_rider", stream))
 
     def add(self, fn_name, desc, stream=0):
         fn = getattr(_lib.lib(), fn_name)
@@ -364,6 +374,23 @@ class Plan:
                 if h is None:
                     h = handles[sidx] = C.c_void_p(self._stream(sidx, cur).cuda_stream)
                 rc = a(b[0], b[1], b[2], h)
+                if rc != 0:
+                    _lib.check(rc, name)
+            elif kind == "rider":
+                h = handles.get(sidx)
+                if h is None:
+                    h = handles[sidx] = C.c_void_p(self._stream(sidx, cur).cuda_stream)
+                desc, key, slot, nslots = b
+                rd = self.riders
+                rng = rd["ranges"].get(key) if rd else None
+                if rng is not None and (key, slot) in rd["used"]:
+                    rng = None               # a stack that runs twice in one forward (pretrain: clean and masked pass) carries once
+                if rng is None:
+                    rc = _lib.lib().univl_gemm(C.byref(desc), h)
+                else:
+                    rd["used"].add((key, slot))
+                    lo, hi = rng[0] + rng[1] * slot // nslots, rng[0] + rng[1] * (slot + 1) // nslots
+                    rc = a(C.byref(desc), C.byref(rd["desc"]), lo, hi - lo, int(rd.get("max_blocks", 0)), h)
                 if rc != 0:
                     _lib.check(rc, name)
             elif kind == "pair":
@@ -458,6 +485,8 @@ class Plan:
                 out.append((lambda h, fn=fn, arg=arg: fn(arg, h), self.descs[i]))
             elif kind == "group" and name.startswith(prefix):
                 out.append((lambda h, fn=fn, arg=arg: fn(arg[0], arg[1], arg[2], h), self.descs[i]))
+            elif kind == "rider" and name.startswith(prefix):
+                out.append((lambda h, d=arg[0]: _lib.lib().univl_gemm(C.byref(d), h), self.descs[i]))
             elif kind == "pair" and name.startswith(prefix):
                 out.append((lambda h, fn=fn, arg=arg: fn(C.byref(arg[0]), C.byref(arg[1]), 0, h), self.descs[i]))
         return out
@@ -542,6 +571,11 @@ class EncoderStack:
         # and those weight gradients stay in the grouped launch.  UNIVL_WGRAD_RIDE=0: the grouped launch for all of them.
         self.ride = (os.environ.get("UNIVL_WGRAD_RIDE", "1") == "1" and flat.compute_dtype == torch.bfloat16
                      and self.sw is None and self.s_off is None)
+        # EXPERIMENTAL, off: the forward products of layer l can carry the BertAdam chunks of layer l + 1 (Plan.add_gemm_rider)
+        # Only the text / video stacks: all their passes of one forward run one after the other on the stack's own stream, so a
+        # layer's update (carried by the FIRST pass through the layer before it) is complete before anybody reads the layer.
+        self.adam_ride = (os.environ.get("UNIVL_ADAM_RIDE", "0") == "1" and flat.compute_dtype == torch.bfloat16
+                          and prefix in ("bert", "visual"))
         self.T = B * S
         self.key_mask = key_mask            # int64 [B,S] device tensor (static buffer)
         self.p = float(p_drop)
@@ -618,22 +652,32 @@ class EncoderStack:
         for l, ws in enumerate(self.layers):
             nm = self._names(l)
             plan.wait_point(("layer", self.prefix, l), sm)
+            slot = [0]
+
+            def gemm(desc, _l=l, _slot=slot):
+                """a forward product of layer l; with self.adam_ride it can carry a quarter of layer l + 1's optimizer chunks"""
+                if self.adam_ride and _l + 1 < self.L:
+                    plan.add_gemm_rider(desc, ("layer", self.prefix, _l + 1), _slot[0], 4, sm)
+                    _slot[0] += 1
+                else:
+                    plan.add("univl_gemm", desc, sm)
+
             wqkv, bqkv = fl.wop_fused(nm["qkv_w"]), fl.w32_fused(nm["qkv_b"])
-            plan.add("univl_gemm", _gemm_desc(dt, x16, H, wqkv, H, T, 3 * H, H, out16=ws["qkv"], ldc=3 * H, bias=bqkv), sm)
+            gemm(_gemm_desc(dt, x16, H, wqkv, H, T, 3 * H, H, out16=ws["qkv"], ldc=3 * H, bias=bqkv))
             qkv = ws["qkv"]
             plan.add("univl_attention_fwd", ops.attention_desc(
                 dt, B, self.NH, S, S, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx"], H, ws["lse"],
                 key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, ws["ctx"], H, fl.wop(nm["o_w"]), H, T, H, H, out32=ws["y1"], ldc=H,
-                                              bias=fl.w32(nm["o_b"]), ksplit=self.ksplit_for(H)), sm)
+            gemm(_gemm_desc(dt, ws["ctx"], H, fl.wop(nm["o_w"]), H, T, H, H, out32=ws["y1"], ldc=H,
+                            bias=fl.w32(nm["o_b"]), ksplit=self.ksplit_for(H)))
             plan.add("univl_layernorm_fwd", ops.layernorm_desc(
                 dt, T, H, x=ws["y1"], residual=x32, gamma=fl.w32(nm["ln1_g"]), beta=fl.w32(nm["ln1_b"]), y=ws["y1"],
                 stats=ws["st1"], out32=ws["a32"], out16=ws["a16"] if self.bf else None, p_pre=p, off_pre=ws["off"][1],
                 seed_dev=self.seed_dev), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, ws["a16"], H, fl.wop(nm["w1"]), H, T, I, H, out16=ws["f"], ldc=I,
-                                              bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd"), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, ws["f"], I, fl.wop(nm["w2"]), I, T, H, I, out32=ws["y2"], ldc=H,
-                                              bias=fl.w32(nm["b2"]), ksplit=self.ksplit_for(I)), sm)
+            gemm(_gemm_desc(dt, ws["a16"], H, fl.wop(nm["w1"]), H, T, I, H, out16=ws["f"], ldc=I,
+                            bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd"))
+            gemm(_gemm_desc(dt, ws["f"], I, fl.wop(nm["w2"]), I, T, H, I, out32=ws["y2"], ldc=H,
+                            bias=fl.w32(nm["b2"]), ksplit=self.ksplit_for(I)))
             plan.add("univl_layernorm_fwd", ops.layernorm_desc(
                 dt, T, H, x=ws["y2"], residual=ws["a32"], gamma=fl.w32(nm["ln2_g"]), beta=fl.w32(nm["ln2_b"]), y=ws["y2"],
                 stats=ws["st2"], out32=ws["o32"], out16=ws["o16"] if self.bf else None, p_pre=p, off_pre=ws["off"][2],

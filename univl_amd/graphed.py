@@ -58,6 +58,9 @@ class GraphedTrainStep:
         self.pipeline = bool(pipeline_optimizer) or os.environ.get("UNIVL_PIPELINE_OPT", "0") == "1"
         self.adam_blocks = int(os.environ.get("UNIVL_ADAM_BLOCKS", "0"))      # grid cap of the overlapped update (0: none)
         self.async_loss = bool(async_loss) or os.environ.get("UNIVL_ASYNC_LOSS", "0") == "1"
+        # EXPERIMENTAL: the pending update goes out as extra workgroups of the next forward's own launches (engine.Plan.add_gemm_rider)
+        # instead of a second stream with one graph edge per layer
+        self.ride = self.pipeline and os.environ.get("UNIVL_ADAM_RIDE", "0") == "1"
         self._copy_stream = self._loss_host = self._loss_ev = None
         self._g_rest = None
         self.params = [p for p in model.parameters()]
@@ -106,6 +109,8 @@ class GraphedTrainStep:
             on_group("all")
 
     def _forward_pipelined(self, args, kw):
+        if self.ride:
+            return self._forward_riding(args, kw)
         self._launch_pending_update()
         self.model._in_pipelined_call = True
         try:
@@ -113,6 +118,22 @@ class GraphedTrainStep:
         finally:
             self.model._in_pipelined_call = False
             self.model._param_events.clear()
+
+    def _forward_riding(self, args, kw):
+        """The pending BertAdam update is applied BY the forward: UniVL.forward launches what cannot ride, its forward products
+        carry the rest (UniVL._start_riding_update).  Same stream throughout: no event, no graph branch."""
+        opt, model = self.opt, self.model
+        fl = model.flat
+        assert getattr(fl, "shard_reducer", None) is None, "UNIVL_ADAM_RIDE does not combine with the sharded optimizer"
+        model._rider_update = dict(desc=opt._last_desc, groups=opt.chunk_groups(), max_blocks=self.adam_blocks)
+        opt._deferred = False                 # from here on the update counts as applied (launch_deferred's bookkeeping)
+        fl.shadow_valid = True
+        model._in_pipelined_call = True
+        try:
+            return model(*args, **kw)
+        finally:
+            model._in_pipelined_call = False
+            model._rider_update = None
 
     def flush(self):
         """Apply the pending BertAdam update of the last iteration (pipelined mode); no-op otherwise."""

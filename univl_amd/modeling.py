@@ -431,6 +431,8 @@ class UniVL(UniVLPreTrainedModel):
         self._steps = {}
         self._param_events = {}        # filled by a pipelined optimizer update in flight (univl_amd.graphed)
         self._pending_update = None    # the optimizer holding a deferred update, if any
+        self._rider_update = None      # EXPERIMENTAL (UNIVL_ADAM_RIDE): dict(desc, groups, max_blocks) of a prepared BertAdam update
+                                       # that THIS forward applies -- prologue launches + riders of its forward products
         self._in_pipelined_call = False
         self._reducer = None
         self._dp_checked, self._implicit_dp = False, False
@@ -635,7 +637,7 @@ class UniVL(UniVLPreTrainedModel):
         host-issued collectives) and replayed from then on -- the unchanged training loop of main_task_retrieval.py:333-352
         then runs close to the fully captured step of graphed.GraphedTrainStep.  UNIVL_AUTO_GRAPH=0 turns it off; inside
         somebody else's capture the plan is always enqueued directly."""
-        hot = self.auto_graph and st.calls > self.AUTO_GRAPH_AFTER
+        hot = self.auto_graph and st.calls > self.AUTO_GRAPH_AFTER and not plan.rider_keys    # rider plans differ from run to run
         if (self.graph_backward or hot) and not torch.cuda.is_current_stream_capturing():
             plan.run_graphed()
         else:
@@ -695,12 +697,38 @@ class UniVL(UniVLPreTrainedModel):
             st.decoder.load(input_caption_ids, decoder_mask, output_caption_ids)
         anchor = fl.params[self.ANCHOR]
         st.calls += 1
-        if torch.is_grad_enabled() and anchor.requires_grad:
-            out = _StepLossFn.apply(anchor, self, st).as_subclass(_LossTensor)
-            out._univl = (self, st)
-            return out
-        self._run_plan(st.fwd, st)
-        return _loss_out(st)
+        ru = self._rider_update
+        if ru is not None:
+            self._start_riding_update(st, ru)
+        try:
+            if torch.is_grad_enabled() and anchor.requires_grad:
+                out = _StepLossFn.apply(anchor, self, st).as_subclass(_LossTensor)
+                out._univl = (self, st)
+                return out
+            self._run_plan(st.fwd, st)
+            return _loss_out(st)
+        finally:
+            st.fwd.riders = None
+
+    def _start_riding_update(self, st, ru):
+        """EXPERIMENTAL (UNIVL_ADAM_RIDE, univl_amd.graphed): the BertAdam update of the previous iteration is applied BY this
+        forward -- chunk groups the forward plan cannot carry (embedding tables, vectors, the first layer of each stack, the
+        cross encoder / decoder) as ordinary launches on the calling stream right now, the others as extra workgroups of the
+        forward products of the layer before (engine.Plan.add_gemm_rider)."""
+        import ctypes as C
+        from . import _lib
+        L, d = _lib.lib(), ru["desc"]
+        h = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        ranges, first = {}, True
+        for key, c0, n in ru["groups"]:
+            if key in st.fwd.rider_keys and key not in ranges:
+                ranges[key] = (c0, n)
+                continue
+            _lib.check(L.univl_bert_adam_range(C.byref(d), c0, n, 1 if first else 0, 0, h), "bert_adam_range")
+            first = False
+        if first:                     # nothing went out as a prologue launch: the per-tensor scalars still have to be prepared
+            _lib.check(L.univl_bert_adam_range(C.byref(d), 0, 0, 1, 0, h), "bert_adam_range")
+        st.fwd.riders = dict(desc=d, ranges=ranges, max_blocks=int(ru.get("max_blocks", 0)), used=set())
 
     def get_sequence_visual_output(self, input_ids, token_type_ids, attention_mask, video, video_mask, shaped=False):
         """modeling.py:299-313.  `shaped=True` means the caller already flattened the pair dim AND normalised the video
