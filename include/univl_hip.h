@@ -348,6 +348,8 @@ int univl_bert_adam_range(const UnivlAdam* d, int32_t chunk_begin, int32_t chunk
  * the chunk range as its own launch -- same result.  max_blocks > 0 caps the workgroups given to the update. */
 int univl_gemm_rider(const UnivlGemm* gemm, const UnivlAdam* adam, int32_t chunk_begin, int32_t chunk_count, int32_t max_blocks,
                      hipStream_t stream);
+/* Large-LDS opt-in of the rider kernels on the stream's device; call once outside any stream capture before the first captured rider. */
+int univl_gemm_rider_prime(hipStream_t stream);
 /* *ctr += 1 (device word; used for per-replay dropout seeds) */
 int univl_bump_counter(uint64_t* ctr, hipStream_t stream);
 /* p16 <- bf16(p) over n elements */

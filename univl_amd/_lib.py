@@ -95,6 +95,7 @@ def lib():
     L.univl_gemm_group_limited.argtypes = [vp, i32, i32, vp]
     L.univl_gemm_pair.argtypes = [vp, vp, i32, vp]
     L.univl_gemm_rider.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.univl_gemm_rider_prime.argtypes = [vp]
     L.univl_gemm_tile_map.argtypes = [i32, i32, i32, i32, i32, C.POINTER(i32)]
     L.univl_embed_scatter.argtypes = [vp, vp, i64, f32, vp, vp]
     L.univl_rows_zero.argtypes = [vp, i64, vp, vp, vp]
@@ -138,7 +139,7 @@ def lib():
 
 
 EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_device_info", "univl_init", "univl_destroy",
-            "univl_allreduce_bucket", "univl_gemm", "univl_gemm_group_limited", "univl_gemm_group", "univl_gemm_tile_map", "univl_gemm_pair", "univl_gemm_rider",
+            "univl_allreduce_bucket", "univl_gemm", "univl_gemm_group_limited", "univl_gemm_group", "univl_gemm_tile_map", "univl_gemm_pair", "univl_gemm_rider", "univl_gemm_rider_prime",
             "univl_layernorm_fwd", "univl_layernorm_bwd", "univl_attention_fwd", "univl_attention_bwd",
             "univl_embed_text_fwd", "univl_embed_text_bwd", "univl_embed_scatter", "univl_rows_zero", "univl_rows_append",
             "univl_rows_sumsq", "univl_zero_many", "univl_copy_many", "univl_pool_fwd", "univl_pool_bwd",

@@ -890,6 +890,13 @@ extern "C" int univl_gemm_pair(const UnivlGemm* dgrad, const UnivlGemm* wgrad, i
     return cw.nc == 6 ? launch_pair<6>(a, stream) : launch_pair<4>(a, stream);
 }
 
+static const size_t RIDER_SMEM = 4 * (size_t)Tile<__bf16, false, 64, 128, 512>::BYTES;          // two stages of A and B
+static void rider_allow_lds() {
+    static bool done_nt[UNIVL_MAX_DEVICES] = {}, done_t[UNIVL_MAX_DEVICES] = {};
+    univl_allow_lds(gemm_adam_kernel<true>, RIDER_SMEM, done_nt);
+    univl_allow_lds(gemm_adam_kernel<false>, RIDER_SMEM, done_t);
+}
+
 extern "C" int univl_gemm_rider(const UnivlGemm* gemm, const UnivlAdam* adam, int32_t chunk_begin, int32_t chunk_count,
                                 int32_t max_blocks, hipStream_t stream) {
     UNIVL_ON_STREAM_DEVICE(stream);
@@ -912,19 +919,24 @@ extern "C" int univl_gemm_rider(const UnivlGemm* gemm, const UnivlAdam* adam, in
     const int nx = (gemm->N + 63) / 64, ny = (gemm->M + 63) / 64;
     const int nd = nx * ny * ks, nd_pad = (nd + 7) / 8 * 8;
     const int nb = (max_blocks > 0 && max_blocks < chunk_count) ? max_blocks : chunk_count;
-    const size_t smem = 4 * (size_t)Tile<__bf16, false, 64, 128, 512>::BYTES;          // two stages of A and B
     static const int nt = (int)env_long("UNIVL_ADAM_NT", 1L);
-    static bool done_nt[UNIVL_MAX_DEVICES] = {}, done_t[UNIVL_MAX_DEVICES] = {};
+    rider_allow_lds();
     if (nt) {
-        univl_allow_lds(gemm_adam_kernel<true>, smem, done_nt);
-        hipLaunchKernelGGL(gemm_adam_kernel<true>, dim3(nd_pad + nb), dim3(512), smem, stream, a, nd, nd_pad, nx, ny, ks, *adam, chunk_begin,
-                           chunk_begin + chunk_count);
+        hipLaunchKernelGGL(gemm_adam_kernel<true>, dim3(nd_pad + nb), dim3(512), RIDER_SMEM, stream, a, nd, nd_pad, nx, ny, ks, *adam,
+                           chunk_begin, chunk_begin + chunk_count);
     } else {
-        univl_allow_lds(gemm_adam_kernel<false>, smem, done_t);
-        hipLaunchKernelGGL(gemm_adam_kernel<false>, dim3(nd_pad + nb), dim3(512), smem, stream, a, nd, nd_pad, nx, ny, ks, *adam, chunk_begin,
-                           chunk_begin + chunk_count);
+        hipLaunchKernelGGL(gemm_adam_kernel<false>, dim3(nd_pad + nb), dim3(512), RIDER_SMEM, stream, a, nd, nd_pad, nx, ny, ks, *adam,
+                           chunk_begin, chunk_begin + chunk_count);
     }
     UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+// The rider kernels' large-LDS opt-in, outside any stream capture: their first launch happens INSIDE the capture of the pipelined
+// training step (the eager iteration before it has no pending update to carry).
+extern "C" int univl_gemm_rider_prime(hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    rider_allow_lds();
     return UNIVL_OK;
 }
 

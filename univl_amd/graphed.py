@@ -196,6 +196,10 @@ class GraphedTrainStep:
             torch.cuda.current_stream().wait_event(self._loss_ev)     # the previous loss copy reads what this replay overwrites
         if self.mode is None:
             torch.cuda.synchronize()
+            if self.ride:                     # the rider kernels are first launched inside the capture below
+                import ctypes as C
+                from . import _lib
+                _lib.check(_lib.lib().univl_gemm_rider_prime(C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm_rider_prime")
             if getattr(self.model, "_reducer", None) is None and self.async_loss:
                 # two graphs from one memory pool: forward | backward + clip + BertAdam
                 self._g_fwd, self._g_rest = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
