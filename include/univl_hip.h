@@ -123,7 +123,8 @@ int univl_gemm_pair(const UnivlGemm* dgrad, const UnivlGemm* wgrad, int32_t dry_
 /* Host-side evaluation of the kernels' workgroup -> tile maps (no device work; lets a CPU test prove they are bijections):
  * what 0: plain-grid map, in out[0..2] = hardware block index, out = the tile that block computes;
  * what 1: out[0] <- position of linear workgroup out[0] in the XCD-grouped tile list of nx tiles;
- * what 2: out[0..2] <- tile number out[0] of an nx x ny x nz problem (a grouped launch's member). */
+ * what 2: out[0..2] <- tile number out[0] of an nx x ny x nz problem (a grouped launch's member);
+ * what 3: out[0..2] <- the tile local workgroup out[0] of one half of a pair / rider launch computes. */
 int univl_gemm_tile_map(int32_t what, int32_t nx, int32_t ny, int32_t nz, int32_t gm, int32_t* out);
 
 /* ------------------------------------------------------------------------------------------ LayerNorm

@@ -143,6 +143,9 @@ def test_gemm_workgroup_to_tile_maps_are_bijections(gm):
         assert pos == list(range(total)), (total,)
         local = {_tile_map(2, nx, ny, nz, gm, t) for t in range(total)}
         assert len(local) == total and all(0 <= a < nx and 0 <= b < ny and 0 <= c < nz for a, b, c in local), (nx, ny, nz, gm)
+        # either half of a pair / rider launch (gemm_pair_kernel, gemm_adam_kernel): local workgroup -> tile
+        half = {_tile_map(3, nx, ny, nz, gm, t) for t in range(total)}
+        assert len(half) == total and all(0 <= a < nx and 0 <= b < ny and 0 <= c < nz for a, b, c in half), (nx, ny, nz, gm)
     # workgroups dealt to one XCD (linear id % 8) take a CONTIGUOUS run of the list: that is what keeps the row tiles
     # that share a weight tile behind one L2
     total = 108

@@ -608,7 +608,7 @@ struct PairArgs {
     int dnx, dny, dnz, wnx, wny, wnz;
 };
 
-__device__ __forceinline__ void pair_tile(int t, int total, int nx, int ny, int nz, int flags, int gm, int& bx, int& by, int& bz) {
+__host__ __device__ __forceinline__ void pair_tile(int t, int total, int nx, int ny, int nz, int flags, int gm, int& bx, int& by, int& bz) {
     if ((flags & UNIVL_GEMM_XCD_MAP) && total >= 16 && ny > 1) {
         tile_of(xcd_run(t, total), nx, ny, nz, gm, bx, by, bz);
     } else {
@@ -807,15 +807,17 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int 
 
 // Host-side evaluation of the workgroup -> tile maps above (no device work): what = 0, the plain-grid map of gemm_kernel
 // (in: the hardware block index in out[0..2]; out: the tile it computes); what = 1, xcd_run(out[0], nx) -> out[0] (the grouped
-// launch's list position); what = 2, tile_of(out[0], ...) (a group member's local tile).  tests/test_host_cpu.py proves the
+// launch's list position); what = 2, tile_of(out[0], ...) (a group member's local tile); what = 3, the local workgroup -> tile map of
+// one half of gemm_pair_kernel / gemm_adam_kernel.  tests/test_host_cpu.py proves the
 // maps are bijections for every grid shape the plans produce -- a map that is not one would silently skip tiles.
 extern "C" int univl_gemm_tile_map(int32_t what, int32_t nx, int32_t ny, int32_t nz, int32_t gm, int32_t* out) {
-    UNIVL_CHECK_ARG(out != nullptr && nx > 0 && ny > 0 && nz > 0 && what >= 0 && what <= 2, UNIVL_EINVAL,
+    UNIVL_CHECK_ARG(out != nullptr && nx > 0 && ny > 0 && nz > 0 && what >= 0 && what <= 3, UNIVL_EINVAL,
                     "univl_gemm_tile_map: what=%d grid=%dx%dx%d", what, nx, ny, nz);
     int bx = out[0], by = out[1], bz = out[2];
     if (what == 0) xcd_tile_grid(nx, ny, nz, gm, bx, by, bz);
     else if (what == 1) bx = xcd_run(out[0], nx);
-    else tile_of(out[0], nx, ny, nz, gm, bx, by, bz);
+    else if (what == 2) tile_of(out[0], nx, ny, nz, gm, bx, by, bz);
+    else pair_tile(out[0], nx * ny * nz, nx, ny, nz, UNIVL_GEMM_XCD_MAP, gm, bx, by, bz);       // a half of gemm_pair_kernel / gemm_adam_kernel
     out[0] = bx; out[1] = by; out[2] = bz;
     return UNIVL_OK;
 }
