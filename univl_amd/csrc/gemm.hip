@@ -11,6 +11,11 @@
 // Workgroup = 4 waves (2x2), tile BM x BN in {64x64, 128x128}, BK = 2 or 4 chunks; global -> LDS by DMA
 // (global_load_lds_dwordx4) into two XOR-swizzled, unpadded stages, one barrier per K step.  Optional split-K over gridDim.z accumulates with fp32 atomics into a pre-zeroed C.
 //
+// Besides the single and the grouped launch there are two "carrier" launches in which a latency-bound product shares its launch
+// with throughput work that nothing downstream waits for, as extra workgroups behind its own tiles: gemm_pair_kernel (a dgrad
+// product + the weight-gradient product of the same nn.Linear, default) and gemm_adam_kernel (a forward product + BertAdam chunks
+// of the next layer, experimental).
+//
 // Epilogue (all optional, in this order): *alpha, +bias[n], +residual[m,n] (fp32), erf-GELU forward (saving the
 // pre-activation), *gelu'(saved pre-activation), +C_old (accumulate), store fp32 and/or T.  A wgrad launch can
 // also emit the bias gradient (row sums of A_op over the contraction) from the tiles it already staged.
