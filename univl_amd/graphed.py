@@ -66,7 +66,7 @@ class GraphedTrainStep:
         self.params = [p for p in model.parameters()]
         self.calls = 0
         self.mode = None                 # None (not captured) | "whole" | "segmented"
-        self._static_args, self._static_kw = None, None
+        self._static_args, self._static_kw, self._static_key = None, None, None
         self._g_all = self._g_fwd = self._g_opt = None
         self._side = None
         self.loss = None
@@ -161,7 +161,11 @@ class GraphedTrainStep:
             hold = lambda t: t if keep(t) else t.to(dev, copy=True)
             self._static_args = [hold(a) if isinstance(a, torch.Tensor) else a for a in args]
             self._static_kw = {k: (hold(v) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+            # the static objects stay alive here, so an equal id() later means the very same object: nothing to stage
+            self._static_key = tuple(id(a) for a in self._static_args) + tuple((k, id(v)) for k, v in self._static_kw.items())
             return
+        if tuple(id(a) for a in args) + tuple((k, id(v)) for k, v in kw.items()) == self._static_key:
+            return                           # the caller refilled the static buffers in place (or passes them unchanged)
         if len(args) != len(self._static_args) or set(kw) != set(self._static_kw):
             raise RuntimeError("GraphedTrainStep: the call signature changed after capture")
         pairs = list(zip(self._static_args, args)) + [(self._static_kw[k], kw[k]) for k in kw]
