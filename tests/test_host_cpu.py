@@ -241,3 +241,18 @@ def test_adam_rider_plan_builds_on_cpu(monkeypatch):
         assert sorted(r[2] for r in riders if r[1] == key) == [0, 1, 2, 3]
     assert not base.fwd.rider_keys and len(ride.fwd.launches("univl_gemm")) == len(base.fwd.launches("univl_gemm"))
     assert [op[3] for op in ride.backward_plan(True).ops] == [op[3] for op in base.backward_plan(True).ops]
+
+
+def test_stage_inputs_host_logic_on_cpu():
+    """steps.stage_inputs: anything that is not a same-device, same-dtype, contiguous CUDA source takes the plain staging copy
+    (dtype conversion, reshape, strided views, numpy arrays) -- the copy kernel is only ever handed pairs it can move bytewise."""
+    import numpy as np
+    from univl_amd.steps import stage_inputs
+    d_ids, d_vid, d_mask = torch.zeros(2, 4, dtype=torch.int64), torch.zeros(8, 3, dtype=torch.float64), torch.zeros(2, 4, dtype=torch.int64)
+    ids = torch.arange(8, dtype=torch.int32).reshape(2, 1, 4)                  # other dtype, extra pair dimension
+    vid = torch.arange(48, dtype=torch.float64).reshape(2, 4, 6)[:, :, ::2]    # strided view, 24 elements
+    mask = np.ones((2, 4), dtype=np.int64)                                     # numpy array
+    stage_inputs([(d_ids, ids), (d_vid, vid), (d_mask, mask)])
+    assert torch.equal(d_ids, ids.reshape(2, 4).to(torch.int64))
+    assert torch.equal(d_vid, vid.reshape(8, 3))
+    assert torch.equal(d_mask, torch.ones(2, 4, dtype=torch.int64))
