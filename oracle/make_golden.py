@@ -210,6 +210,72 @@ def generate(name):
           f"({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+# ------------------------------------------------------------------------------------------ cotangent goldens
+# The FT-Align loss (hinge / CrossEn over B x B nearly equal cross-encoder scores) turns the backward into a DIFFERENCE of nearly
+# equal per-pair gradients: under bf16 operand rounding the reference's own autocast run differs from its fp32 run by 40-80 % per
+# tensor THROUGH THE LOSS, but only by ~1 % through (sim * W).sum() with a non-negative cotangent W.  These
+# fixtures hold the reference's gradients for three seeded non-negative cotangents, so that the whole FT-Align backward (pooler,
+# similarity_dense, cross encoder on B^2 pairs, both encoders, embeddings) has a WELL-POSED bf16 parity gate.  The reference's
+# loss function for the cross-encoder similarity (modeling.py:209 / :265, `self.loss_fct`) is replaced by sim -> (sim * W).sum();
+# everything else of UniVL.forward runs unchanged (on the pretrain path the other four losses stay in the gradient).
+COT_CASES = ["align_small", "align_full", "pretrain_full"]
+COT_KINDS = ["ones", "onehot", "absrandn"]
+
+
+def cotangent(kind, n, seed=977):
+    """Seeded non-negative [n, n] cotangent of the cross-encoder similarity matrix."""
+    if kind == "ones":
+        return torch.ones(n, n)
+    if kind == "onehot":
+        w = torch.zeros(n, n)
+        w[1 % n, 2 % n] = 1.0
+        return w
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, n, generator=g).abs()
+
+
+def generate_cotangent(name):
+    cfg, rows, dseed = case_config(name)
+    model = H.build_reference_model(_task_ns(cfg), vocab_size=cfg.vocab_size, zero_dropout=True)
+    load_procedural_into_reference(model, cfg, seed=0)
+    batch = O.synthetic_batch(cfg, rows, seed=dseed)
+    model.train()
+    n = rows * cfg.n_pair
+    out = {"kinds": np.array(COT_KINDS)}
+    names = None
+    for kind in COT_KINDS:
+        Wc = cotangent(kind, n)
+        seen = {}
+
+        class Fct(torch.nn.Module):              # `loss_fct` is a registered child module of the reference model
+            def forward(self, sim, Wc=Wc, seen=seen):
+                assert tuple(sim.shape) == tuple(Wc.shape), (sim.shape, Wc.shape)
+                seen["sim"] = sim.detach().clone()
+                return (sim * Wc).sum()
+        model.loss_fct = Fct()
+        model.zero_grad()
+        loss = reference_forward(model, cfg, batch)
+        loss.backward()
+        gd = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+        if names is None:
+            names = list(gd)
+            out["grad_names"] = np.array(names)
+        assert names == list(gd)
+        norms = [float(gd[k].norm()) for k in names]
+        top = sorted(range(len(names)), key=lambda i: -norms[i])[:10]
+        out["W_" + kind] = Wc.numpy().copy()
+        out["sim_" + kind] = seen["sim"].numpy().copy()
+        out["loss_" + kind] = np.array(float(loss), dtype=np.float64)
+        out["grad_norms_" + kind] = np.array(norms, dtype=np.float64)
+        out["grad_samples_" + kind] = np.stack([_pad(sample_exact(gd[k], 256), 256) for k in names]).astype(np.float32)
+        out["grad_top_index_" + kind] = np.array(top, dtype=np.int64)
+        out["grad_top_samples_" + kind] = np.stack([_pad(sample_exact(gd[names[i]], 4096), 4096) for i in top]).astype(np.float32)
+        print(f"[golden] {name} cotangent {kind}: loss={float(loss):.6f} |g|={np.sqrt(np.sum(np.square(norms))):.4e}")
+    path = os.path.join(GOLDEN_DIR, name + "_cot.npz")
+    np.savez_compressed(path, **out)
+    print(f"[golden] {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def dump_param_inventory():
     """Key lists of the reference's named_parameters()/state_dict per stage -> tests/golden/param_inventory.json."""
     inv = {}
@@ -315,9 +381,11 @@ def generate_metrics():
 if __name__ == "__main__":
     assert H.reference_available(), "reference not mounted; golden vectors can only be made in the build container"
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or list(CASES) + ["beam", "metrics"]
+    which = sys.argv[1:] or list(CASES) + ["beam", "metrics"] + [c + "_cot" for c in COT_CASES]
     for nm in which:
-        if nm == "beam":
+        if nm.endswith("_cot"):
+            generate_cotangent(nm[:-4])
+        elif nm == "beam":
             generate_beam()
         elif nm == "metrics":
             generate_metrics()

@@ -15,9 +15,9 @@ lim() { local want=$1 l; l=$(left); if [ $l -lt 5 ]; then echo 0; elif [ $l -lt 
 stamp() { echo "[$(( $(date +%s) - T0 )) s] $*" | tee -a $OUT/timeline.txt; }
 P=$PWD
 t=$(lim 420)
-(timeout $t python -m pytest tests/test_model_gpu.py -m gpu -x -q --durations=8 > $OUT/pytest_model.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_model.log) &
+(timeout $t python -m pytest tests/test_model_gpu.py -m gpu -q --durations=8 > $OUT/pytest_model.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_model.log) &
 P1=$!
-(timeout $t python -m pytest tests -m gpu -x -q --durations=8 --ignore=tests/test_model_gpu.py > $OUT/pytest_rest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_rest.log) &
+(timeout $t python -m pytest tests -m gpu -q --durations=8 --ignore=tests/test_model_gpu.py > $OUT/pytest_rest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_rest.log) &
 P2=$!
 wait $P1 $P2
 cp gpurun_out/parity_errors.json $OUT/ 2>/dev/null
