@@ -12,7 +12,8 @@
  *   - the DEVICE is the one `stream` belongs to (hipStreamGetDevice), not the calling thread's current device: the
  *     reference's evaluation fan-out calls the model from one thread per GPU (util.py:21-60) and autograd's backward
  *     threads carry their own current device.  The null stream means the current device.
- *   - re-entrant; no global mutable state besides the thread-local error string and per-device "large LDS enabled" flags.
+ *   - re-entrant; no global mutable state besides the thread-local error string, per-device "large LDS enabled" flags and the
+ *     deterministic-mode switch below (with its per-device scratch ring -- the one thing the library allocates, and only when asked).
  *   - dtype: UNIVL_F32 (parity mode, exact-fp32 MFMA) or UNIVL_BF16 (production: bf16 operands, fp32
  *     accumulate, fp32 LayerNorm/softmax/residual stream).
  *   - RNG for dropout is (seed, offset) supplied by the caller; offsets distinguish call sites.  The effective
@@ -56,6 +57,17 @@ int univl_zero_many(void* const* ptrs, const int64_t* bytes, int32_t n, hipStrea
  * 16-byte words, others bytewise.  srcs / dsts / bytes are HOST arrays read at call time. */
 int univl_copy_many(const void* const* srcs, void* const* dsts, const int64_t* bytes, int32_t n, hipStream_t stream);
 int univl_destroy(void);
+/* Deterministic mode.  By default every floating-point sum that several workgroups contribute to -- split-K slices, the column sums
+ * behind LayerNorm / bias gradients, embedding and pair-concat scatter-adds, gradient-norm partials, loss accumulators -- is taken
+ * with fp32 atomics, whose order (and therefore the last bits of the result) differs from run to run, as it does for the reference's
+ * own CUDA kernels (index_add_ / embedding backward).  univl_set_deterministic(1) makes every later launch take these sums in a
+ * FIXED order: no split-K, "last workgroup to arrive adds the partials in workgroup order" for column sums, gather-style kernels
+ * ("the first source of a destination row sums all its sources in source order") for the scatters.  Two runs on the same inputs
+ * are then bit-identical, at a cost of a few extra launches -- the parity tests run in this mode, production does not.  The call
+ * allocates a scratch ring on the CURRENT device (UNIVL_DET_ARENA_MB, default 1024) and must therefore be made outside any stream
+ * capture, once per device; plans / graphs built before a switch keep the mode they were built in.  Returns 0 or UNIVL_EINVAL. */
+int univl_set_deterministic(int on);
+int univl_get_deterministic(void);
 /* Data-parallel gradient exchange for hosts that own an RCCL communicator themselves (the Python host goes through
  * torch.distributed's "nccl" backend = RCCL, main_task_retrieval.py:23,197-198, instead): in-place all-reduce of
  * buf[0..n) (dtype UNIVL_DT_F32 / UNIVL_DT_BF16) over `comm` (an ncclComm_t) on the side stream `side`,
@@ -155,9 +167,9 @@ typedef struct UnivlLayerNorm {
     float* dx32;           /* optional: grad wrt the pre-LN sum (= grad of residual / pos inputs)           */
     float* dxd32;          /* optional: grad wrt x (dropout_pre backward applied), fp32                    */
     void* dxd16;           /* optional: same in compute type (operand of the following dgrad/wgrad)        */
-    float* dgamma; float* dbeta;   /* [N], accumulated with atomics                                        */
+    float* dgamma; float* dbeta;   /* [N], accumulated (atomics; fixed order in deterministic mode)        */
     float* dbias;          /* optional [N]: column sums of the grad wrt x (bias grad of the producing GEMM) */
-    float* dpos;           /* optional [period,N], accumulated with atomics                                */
+    float* dpos;           /* optional [period,N], accumulated (atomics; fixed order in deterministic mode)*/
 } UnivlLayerNorm;
 int univl_layernorm_fwd(const UnivlLayerNorm* d, hipStream_t stream);
 int univl_layernorm_bwd(const UnivlLayerNorm* d, hipStream_t stream);

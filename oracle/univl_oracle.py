@@ -554,8 +554,10 @@ def get_sequence_visual_output(P, cfg, input_ids, token_type_ids, attention_mask
     return seq, vis
 
 
-def univl_forward(P, cfg: OracleConfig, batch, training=True, return_parts=False):
-    """modeling.py:188-271 -- returns the scalar training loss (all stages / losses)."""
+def univl_forward(P, cfg: OracleConfig, batch, training=True, return_parts=False, sim_loss_fct=None):
+    """modeling.py:188-271 -- returns the scalar training loss (all stages / losses).  sim_loss_fct: stands in for the reference's
+    `self.loss_fct` (the loss on the similarity matrix, modeling.py:209 / :265) -- the cotangent fixtures of oracle/make_golden.py
+    replace it by sim -> (sim * W).sum()."""
     v = lambda t: t.view(-1, t.shape[-1])
     input_ids, token_type_ids = v(batch["input_ids"]), v(batch["token_type_ids"])
     attention_mask, video_mask = v(batch["attention_mask"]), v(batch["video_mask"])
@@ -564,6 +566,8 @@ def univl_forward(P, cfg: OracleConfig, batch, training=True, return_parts=False
                                           training, shaped=True)
     parts = dict(sequence_output=seq, visual_output=vis)
     loss_fct, pretrain_sim_fct = _loss_fcts(cfg)
+    if sim_loss_fct is not None:
+        loss_fct = sim_loss_fct
     loss = 0.
     if cfg.stage_one:
         sim = similarity_logits(seq, vis, attention_mask, video_mask, P, cfg, training)

@@ -78,12 +78,9 @@ def install_univl_amd():
 
     def clip_grad_norm_(parameters, max_norm, norm_type=2.0, *a, **k):
         params = [parameters] if isinstance(parameters, torch.Tensor) else list(parameters)
-        if params and all(p.is_cuda for p in params):
-            try:
-                return amd_opt.clip_grad_norm_(params, max_norm, norm_type)
-            except RuntimeError:                # not parameters of a univl_amd model
-                pass
-        return stock_clip(params, max_norm, norm_type, *a, **k)
+        if params and all(p.is_cuda for p in params) and amd_opt.owns(params[0]):
+            return amd_opt.clip_grad_norm_(params, max_norm, norm_type)     # device / kernel errors propagate (no silent second clip)
+        return stock_clip(params, max_norm, norm_type, *a, **k)               # not parameters of a univl_amd model
     torch.nn.utils.clip_grad_norm_ = clip_grad_norm_
     return amd_modeling, amd_opt
 

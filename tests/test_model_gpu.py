@@ -24,49 +24,67 @@ DEV = "cuda"
 JOINT_CASES = ["joint_small", "joint_ones", "joint_full"]
 ALL_CASES = JOINT_CASES + ["align_small", "caption_small", "pretrain_small"] + FULL_CASES   # FULL: BASELINE cfg3/FT-Align/cfg4/cfg5
 
+# Every test of this module runs in the library's DETERMINISTIC mode unless it says otherwise (fixture below): fixed-order
+# reductions instead of fp32 atomics, so that a measured error is a property of the code and not of one run.  The default
+# (atomic) mode is held against the deterministic one in test_default_atomic_mode_matches_deterministic.
+#
 # bf16 gates.  north_star: 1e-2 on outputs (similarity logits, decoder logits, loss) and on the relative gradient error;
 # hidden states carry bf16 operand noise that torch's own bf16 autocast of the REFERENCE shows too (measured the same way
 # by oracle/bf16_noise.py -> tests/golden/bf16_autocast_noise.json, quoted in DESIGN.md section 2).  Every measured error
 # is written to gpurun_out/parity_errors.json (copied to profiles/ per round).
+#   gnorm    worst relative error of a per-tensor gradient norm          gsample  worst per-tensor relative error of the 256-sample
+#   gmedian  median of those per-tensor sample errors                     gp95     their 95th percentile
+#   gtop     worst error of the 4096-samples of the ten largest tensors   gglobal  ||all samples - ref|| / ||ref||
+#   gcos     1 - cosine(all samples, ref)
 GATES = {
-    torch.float32: dict(hidden=1e-3, sim=1e-3, logits=1e-3, loss=1e-3, gnorm=1e-3, gsample=2e-3, gtop=2e-3),
-    torch.bfloat16: dict(hidden=5e-2, sim=1e-2, logits=1e-2, loss=1e-2, gnorm=1e-2, gsample=6e-2, gtop=2.5e-2, gmedian=3e-2),
+    torch.float32: dict(hidden=1e-3, sim=1e-3, logits=1e-3, loss=1e-3, gnorm=1e-3, gsample=2e-3, gtop=2e-3, gmedian=1e-3,
+                        gp95=1e-3, gglobal=1e-3, gcos=1e-5),
+    torch.bfloat16: dict(hidden=5e-2, sim=1e-2, logits=1e-2, loss=1e-2, gnorm=1e-2, gsample=4e-2, gtop=2.5e-2, gmedian=2e-2,
+                         gp95=3e-2, gglobal=1.5e-2, gcos=2e-4),
 }
-GATES[torch.float32]["gmedian"] = 1e-3
-# Per-tensor GRADIENT gates of the branches whose losses amplify operand rounding (measured: profiles/r02_parity_errors.json;
-# the reference under torch's own bf16 autocast, measured the same way: tests/golden/bf16_autocast_noise.json -- e.g. FT-Align
-# 48x48: worst tensor 0.57 relative, median 0.10; norms 5.8e-2).  Every gate here is within 1.5x of what the reference's own
-# bf16 run shows for that branch; outputs (sim / logits / loss) stay at 1e-2 everywhere.
-# gsample is the WORST of ~300-430 per-tensor errors and moves from run to run (fp32 atomics order the split-K / bias /
-# LayerNorm-gradient sums differently every time: pretrain_full measured 0.11, 0.20, 0.22 in three runs); gmedian is the
-# median over the same tensors.
+# Branch-specific bf16 GRADIENT gates.
+#  * caption: the 30522-way softmax gradient through the tied table leaves a few small tensors at 3e-2 (measured 3.0-3.4e-2).
+#  * align / pretrain THROUGH THE LOSS: the hinge / CrossEn over B x B nearly equal cross-encoder scores makes the gradient a
+#    DIFFERENCE of nearly equal per-pair gradients -- the reference's own bf16 autocast run differs from its fp32 run by 38 %
+#    (median tensor) / 80 % (worst) there (oracle/bf16_noise.py).  A worst-of-300-tensors statistic has no power in
+#    that regime, so through the loss these branches are gated on the outputs (loss, sim at 1e-2), on the hinge-activity pattern, and
+#    on aggregate gradient statistics (cosine, global error, median); the per-tensor gates at the 1e-2 level are applied where the
+#    problem is well posed: test_backward_vs_reference_cotangent_golden (the reference's gradients of (sim * W).sum(), W >= 0).
 BF16_GRAD_GATES = {
-    "align": dict(gnorm=0.1, gsample=0.8, gtop=0.3, gmedian=0.3),      # all B^2 pairs through the cross encoder, margin loss on differences
-    "caption": dict(gnorm=1e-2, gsample=8e-2, gtop=5e-2, gmedian=3e-2),  # 30522-way softmax gradient through the tied table
-    "pretrain": dict(gnorm=3e-2, gsample=0.45, gtop=4e-2, gmedian=8e-2),  # five losses incl. the FT-Align term
+    "caption": dict(gsample=6e-2, gtop=5e-2, gp95=4e-2),
+    "align": dict(gnorm=0.3, gsample=None, gtop=0.5, gmedian=0.35, gp95=None, gglobal=0.35, gcos=6e-2),
+    "pretrain": dict(gnorm=3e-2, gsample=None, gtop=4e-2, gmedian=4e-2, gp95=0.15, gglobal=3e-2, gcos=1e-3),
 }
-
-
-_NOISE_KEYS = {"gnorm": ("grad_norm_rel_max", 1.0), "gsample": ("grad_sample_rel_max", 1.0),
-               "gmedian": ("grad_sample_rel_median", 1.0), "gtop": ("grad_sample_rel_median", 1.5)}
+# the cotangent form of the same branches (bf16): worst tensor / median / global
+COT_GATES = {
+    "align": dict(gnorm=1e-2, gsample=2.5e-2, gtop=1.5e-2, gmedian=1e-2, gp95=2e-2, gglobal=1e-2, gcos=5e-5, sim=1e-2),
+    "pretrain": dict(gnorm=1.5e-2, gsample=8e-2, gtop=3e-2, gmedian=2e-2, gp95=4e-2, gglobal=1.5e-2, gcos=2e-4, sim=1e-2),
+}
 
 
 def gates_for(name, dtype):
-    """bf16 gradient gates of the loss-amplified branches: the branch floor above, or -- when the case has an entry in
-    tests/golden/bf16_autocast_noise.json -- what the REFERENCE's own bf16 autocast run shows against its fp32 run for the
-    same statistic, whichever is larger (align_full, round 2: ours gnorm 0.13 / gmedian 0.18 / gsample 0.57, the
-    reference's autocast 0.28 / 0.35 / 1.16).  Outputs (hidden / sim / logits / loss) never take this path."""
     g = dict(GATES[dtype])
     branch = name.split("_")[0]
     if dtype == torch.bfloat16 and branch in BF16_GRAD_GATES:
         g.update(BF16_GRAD_GATES[branch])
-        import json
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_autocast_noise.json")
-        ref = json.load(open(path)).get(name)
-        if ref:
-            for k, (rk, f) in _NOISE_KEYS.items():
-                g[k] = max(g[k], f * float(ref[rk]))
     return g
+
+
+@pytest.fixture(autouse=True)
+def _deterministic_mode():
+    univl_amd.set_deterministic(True)
+    yield
+    univl_amd.set_deterministic(True)
+
+
+class atomic_mode:
+    """with atomic_mode(): the library's default mode (fp32 atomics) for the models BUILT inside the block."""
+
+    def __enter__(self):
+        univl_amd.set_deterministic(False)
+
+    def __exit__(self, *a):
+        univl_amd.set_deterministic(True)
 
 
 _ERRORS = {}
@@ -127,8 +145,78 @@ def max_abs(a, b):
     return float((torch.as_tensor(a).double().cpu() - torch.as_tensor(b).double().cpu()).abs().max())
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("name", ALL_CASES)
+def compare_gradients(params, names, ref_norms, ref_samples, top_index, top_samples, G, f32):
+    """Gradient statistics of a model against a golden fixture (per-tensor norms, 256-element strided samples of every tensor,
+    4096-element samples of the ten largest).  Returns (err dict, list of per-tensor violations of the gates that are not None)."""
+    # absolute floor: bf16 operand rounding leaves noise proportional to the LARGEST gradients flowing through the
+    # same kernels (a bias whose true gradient is ~0, e.g. key.bias, only sees that noise); fp32 mode: rounding only
+    gmax = float(np.max(ref_norms))
+    floor = (1e-6 if f32 else 2e-3) * max(gmax, 1.0 if f32 else gmax)
+    worst_norm = 0.0
+    bad, rels, allg, allr, relnames = [], [], [], [], []
+    for i, n in enumerate(names):
+        gr = params[n].grad
+        assert gr is not None, n
+        ref = float(ref_norms[i])
+        got = float(gr.double().norm())
+        # key.bias gradients are mathematically zero (softmax is invariant to a per-query shift): the reference
+        # itself only holds rounding noise (~1e-10) there, hence the absolute floor.
+        significant = ref > 1e-3 * gmax
+        if significant:
+            worst_norm = max(worst_norm, abs(got - ref) / ref)
+        if not abs(got - ref) < G["gnorm"] * ref + floor:
+            bad.append((n, "norm", got, ref))
+        rs = ref_samples[i]
+        gs = sample_exact(gr.float().cpu(), 256)
+        rs = rs[:gs.size]
+        allg.append(gs.astype(np.float64)); allr.append(rs.astype(np.float64))
+        d = float(np.linalg.norm(gs - rs))
+        rn = float(np.linalg.norm(rs))
+        if significant and rn > 0:
+            rels.append(d / rn)
+            relnames.append((d / rn, n, ref / gmax))
+        if G["gsample"] is not None and not d < G["gsample"] * rn + floor * (min(256, gr.numel()) / gr.numel()) ** 0.5 + 1e-9:
+            bad.append((n, "sample", d, rn))
+    worst_top = 0.0
+    for j, i in enumerate(top_index):                 # the ten largest gradients: 4096-element samples
+        rs = top_samples[j]
+        gs = sample_exact(params[names[int(i)]].grad.float().cpu(), 4096)
+        if float(np.linalg.norm(rs)) > 0:              # (a one-hot cotangent leaves whole strided samples of a table at zero)
+            worst_top = max(worst_top, float(np.linalg.norm(gs - rs[:gs.size])) / float(np.linalg.norm(rs)))
+    ag, ar = np.concatenate(allg), np.concatenate(allr)
+    print("[worst tensors: sample error, name, norm / largest norm] " + "; ".join("%.2e %s %.1e" % t for t in sorted(relnames, reverse=True)[:4]))
+    err = dict(gnorm=worst_norm, gsample=float(np.max(rels)), gtop=worst_top, gmedian=float(np.median(rels)),
+               gp95=float(np.percentile(rels, 95)), gglobal=float(np.linalg.norm(ag - ar) / np.linalg.norm(ar)),
+               gcos=float(1.0 - np.dot(ag, ar) / (np.linalg.norm(ag) * np.linalg.norm(ar))))
+    return err, bad
+
+
+def check_gates(tag, err, G):
+    for k, v in err.items():
+        if G.get(k) is not None:
+            assert v < G[k], (tag, k, v, G[k])
+
+
+def hinge_pattern(sim, margin):
+    """Which terms of MaxMarginRankingLoss (until_module.py:245-251) are active: relu(margin + s_ij - s_ii), relu(margin + s_ij - s_jj)."""
+    s = np.asarray(sim, dtype=np.float64)
+    d = np.diag(s)
+    return np.stack([(margin + s - d[:, None]) > 0, (margin + s - d[None, :]) > 0])
+
+
+def _golden_params():
+    """(case, dtype) grid; the through-the-loss bf16 runs of the ill-conditioned branches are marked `statistical` (conftest.py runs
+    those after every deterministic-gate test of the session)."""
+    out = []
+    for name in ALL_CASES:
+        for dtype in (torch.float32, torch.bfloat16):
+            ill = dtype == torch.bfloat16 and name.split("_")[0] in ("align", "pretrain")
+            out.append(pytest.param(name, dtype, marks=[pytest.mark.statistical] if ill else [],
+                                    id="%s-%s" % (name, "bf16" if dtype == torch.bfloat16 else "fp32")))
+    return out
+
+
+@pytest.mark.parametrize("name,dtype", _golden_params())
 def test_forward_backward_vs_reference_golden(golden_dir, name, dtype):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     cfg, rows, dseed = case_config(name)
@@ -157,6 +245,9 @@ def test_forward_backward_vs_reference_golden(golden_dir, name, dtype):
         err["hidden"] = max(float(np.abs(_sample(seq) - g["sequence_output_sample"]).max()),
                             float(np.abs(_sample(vis) - g["visual_output_sample"]).max()))
     err["sim"] = max_abs(sim, g["sim_matrix"]) / max(1.0, float(np.abs(g["sim_matrix"]).max()))
+    if cfg.train_sim_after_cross and not cfg.use_mil:
+        # FT-Align: the same hinges are active as in the reference (the loss is not differentiable where one flips)
+        assert np.array_equal(hinge_pattern(sim.float().cpu().numpy(), cfg.margin), hinge_pattern(g["sim_matrix"], cfg.margin))
     # ---- training step: loss + every parameter gradient (main_task_retrieval.py:333-342)
     model.train()
     loss = call(model, batch)
@@ -167,46 +258,113 @@ def test_forward_backward_vs_reference_golden(golden_dir, name, dtype):
     params = dict(model.named_parameters())
     for n in nograd:
         assert params[n].grad is None, n                      # dead poolers stay grad-less, as in the reference
-    # absolute floor: bf16 operand rounding leaves noise proportional to the LARGEST gradients flowing through the
-    # same kernels (a bias whose true gradient is ~0, e.g. key.bias, only sees that noise); fp32 mode: rounding only
-    gmax = float(np.max(g["grad_norms"]))
-    floor = (1e-6 if f32 else 2e-3) * max(gmax, 1.0 if f32 else gmax)
-    worst_norm = worst_s = 0.0
-    bad, rels = [], []
-    for i, n in enumerate(names):
-        gr = params[n].grad
-        assert gr is not None, n
-        ref = float(g["grad_norms"][i])
-        got = float(gr.double().norm())
-        # key.bias gradients are mathematically zero (softmax is invariant to a per-query shift): the reference
-        # itself only holds rounding noise (~1e-10) there, hence the absolute floor.
-        significant = ref > 1e-3 * gmax
-        if significant:
-            worst_norm = max(worst_norm, abs(got - ref) / ref)
-        if not abs(got - ref) < G["gnorm"] * ref + floor:
-            bad.append((n, "norm", got, ref))
-        # 256-element strided sample of the gradient itself: relative error of the sample vector
-        rs = g["grad_samples"][i]
-        gs = sample_exact(gr.float().cpu(), 256)
-        d = float(np.linalg.norm(gs - rs[:gs.size]))
-        rn = float(np.linalg.norm(rs))
-        if significant and rn > 0:
-            worst_s = max(worst_s, d / rn)
-            rels.append(d / rn)
-        if not d < G["gsample"] * rn + floor * (min(256, gr.numel()) / gr.numel()) ** 0.5 + 1e-9:
-            bad.append((n, "sample", d, rn))
-    worst_top = 0.0
-    for j, i in enumerate(g["grad_top_index"]):      # the ten largest gradients: 4096-element samples
-        rs = g["grad_top_samples"][j]
-        gs = sample_exact(params[names[int(i)]].grad.float().cpu(), 4096)
-        rel = float(np.linalg.norm(gs - rs[:gs.size])) / float(np.linalg.norm(rs))
-        worst_top = max(worst_top, rel)
-    err.update(gnorm=worst_norm, gsample=worst_s, gtop=worst_top, gmedian=float(np.median(rels)))
+    gerr, bad = compare_gradients(params, names, g["grad_norms"], g["grad_samples"], g["grad_top_index"], g["grad_top_samples"], G, f32)
+    err.update(gerr)
     _record(name, dtype, **err)
     print(f"[parity {name} {dtype}] " + " ".join(f"{k}={v:.2e}" for k, v in sorted(err.items())))
     assert not bad, bad[:5]
-    for k, v in err.items():
-        assert v < G[k], (name, k, v, G[k])
+    check_gates(name, err, G)
+
+
+def _pooler_step(model):
+    sts = [st for st in model._steps.values() if getattr(st, "pooler", None) is not None and st.cx.training]
+    assert len(sts) == 1
+    return sts[0]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["align_small", "align_full", "pretrain_full"])
+def test_backward_vs_reference_cotangent_golden(golden_dir, name, dtype):
+    """The WELL-POSED form of the FT-Align backward (modeling.py:341-375 on all B^2 pairs; until_module.py:223-251 is what makes the
+    through-the-loss form ill-conditioned): gradients of (sim * W).sum() for three seeded non-negative cotangents W against the
+    reference's (tests/golden/*_cot.npz, oracle/make_golden.py: `loss_fct` replaced, everything else of UniVL.forward unchanged --
+    on the pretrain path the other four losses stay in the gradient).  The cotangent is fed where the loss kernel leaves d loss /
+    d sim (steps.PoolerSim.dsim, test-only access); everything downstream is the production backward plan."""
+    from make_golden import COT_KINDS
+    g = np.load(os.path.join(golden_dir, name + "_cot.npz"))
+    cfg, rows, dseed = case_config(name)
+    model, P = build(cfg, dtype)
+    batch = O.synthetic_batch(cfg, rows, seed=dseed)
+    f32 = dtype == torch.float32
+    G = dict(GATES[dtype])
+    if not f32:
+        G.update(COT_GATES[name.split("_")[0]])
+    names = [str(s) for s in g["grad_names"]]
+    model.train()
+    for kind in COT_KINDS:
+        model.zero_grad(set_to_none=True)
+        loss = call(model, batch)
+        st = _pooler_step(model)
+        Wc = torch.from_numpy(g["W_" + kind]).to(DEV)
+        err = dict(sim=max_abs(st.pooler.sim.view(Wc.shape), g["sim_" + kind]) / max(1.0, float(np.abs(g["sim_" + kind]).max())))
+        st.pooler.dsim.copy_(Wc.reshape(-1))            # d loss / d sim := W   (the loss kernel had written the hinge's)
+        loss.backward()
+        params = dict(model.named_parameters())
+        gerr, bad = compare_gradients(params, names, g["grad_norms_" + kind], g["grad_samples_" + kind],
+                                      g["grad_top_index_" + kind], g["grad_top_samples_" + kind], G, f32)
+        err.update(gerr)
+        _record(name + "_cot_" + kind, dtype, **err)
+        print(f"[cotangent {name} {kind} {dtype}] " + " ".join(f"{k}={v:.2e}" for k, v in sorted(err.items())))
+        assert not bad, (kind, bad[:5])
+        check_gates((name, kind), err, G)
+
+
+def _grads_and_loss(name, dtype, steps=0):
+    cfg, rows, dseed = case_config(name)
+    model, _ = build(cfg, dtype)
+    batch = O.synthetic_batch(cfg, rows, seed=dseed)
+    model.train()
+    loss = call(model, batch)
+    loss.backward()
+    out = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    out["__loss__"] = loss.detach().clone()
+    if steps:
+        opt = BertAdam(model.parameters(), lr=1e-4, warmup=-1, t_total=-1, weight_decay=0.01, max_grad_norm=1.0)
+        for _ in range(steps):
+            clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+            opt.zero_grad()
+            call(model, batch).backward()
+        out.update({"param:" + n: p.detach().clone() for n, p in model.named_parameters()})
+    return out
+
+
+@pytest.mark.parametrize("name,dtype,steps", [("align_full", torch.bfloat16, 0), ("pretrain_small", torch.bfloat16, 2),
+                                              ("caption_small", torch.bfloat16, 2), ("joint_small", torch.float32, 2)])
+def test_deterministic_mode_is_bit_reproducible(name, dtype, steps):
+    """univl_set_deterministic(1): two independent runs (fresh model, fresh workspaces) of the forward + backward (+ clip + BertAdam
+    steps) give the SAME BITS -- loss, every gradient tensor, every parameter.  This is what makes the measured parity errors of
+    this module properties of the code rather than of one run (the default mode orders its fp32 atomics differently every time)."""
+    a = _grads_and_loss(name, dtype, steps)
+    b = _grads_and_loss(name, dtype, steps)
+    assert a.keys() == b.keys()
+    diff = [k for k in a if not torch.equal(a[k], b[k])]
+    assert not diff, diff[:8]
+
+
+@pytest.mark.parametrize("name,dtype", [("joint_full", torch.float32), ("align_small", torch.float32), ("pretrain_small", torch.float32),
+                                        ("caption_small", torch.float32), ("joint_full", torch.bfloat16), ("caption_small", torch.bfloat16)])
+def test_default_atomic_mode_matches_deterministic(name, dtype):
+    """The production default (fp32 atomics: split-K, column sums, scatter-adds) computes the same sums as the deterministic mode in
+    another order: fp32 compute -> per-tensor differences at rounding level; bf16 compute -> a different summation order flips bf16
+    roundings downstream, so the comparison is the aggregate one."""
+    det = _grads_and_loss(name, dtype)
+    with atomic_mode():
+        atom = _grads_and_loss(name, dtype)
+    assert det.keys() == atom.keys()
+    f32 = dtype == torch.float32
+    gmax = max(float(v.double().norm()) for k, v in det.items() if k != "__loss__")
+    assert abs(float(det["__loss__"]) - float(atom["__loss__"])) < (1e-5 if f32 else 2e-3) * max(1.0, abs(float(det["__loss__"])))
+    num = den = 0.0
+    for k, v in det.items():
+        if k == "__loss__":
+            continue
+        d = float((v.double() - atom[k].double()).norm())
+        n = float(v.double().norm())
+        num += d * d; den += n * n
+        if f32:
+            assert d < 2e-4 * n + 1e-6 * gmax, (k, d, n)
+    assert (num / den) ** 0.5 < (1e-4 if f32 else 2e-2), (name, (num / den) ** 0.5)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -336,6 +494,7 @@ def test_bf16_shadow_follows_optimizer_and_state_dict_roundtrip(tmp_path):
     assert max_abs(a1[0], a2[0]) < 2e-2 and max_abs(a1[1], a2[1]) < 2e-2
 
 
+@pytest.mark.statistical
 def test_dropout_training_runs_and_is_seeded():
     cfg, rows, dseed = case_config("joint_small")
     ns = task_ns(cfg, torch.bfloat16)
@@ -632,17 +791,17 @@ def test_weight_gradient_packaging_matches_golden(golden_dir, name, ride, monkey
         assert kinds.count("univl_gemm_pair") == 0 and kinds.count("univl_gemm_group") >= cfg.text_num_hidden_layers + cfg.visual_num_hidden_layers
 
 
-@pytest.mark.skipif(os.environ.get("UNIVL_EXPERIMENTAL") != "1", reason="UNIVL_ADAM_RIDE is experimental: UNIVL_EXPERIMENTAL=1 runs it")
 @pytest.mark.parametrize("case", ["joint_full", "pretrain_small", "caption_small"])
 def test_adam_update_riding_with_the_next_forward_matches_eager(case, monkeypatch):
     """UNIVL_ADAM_RIDE=1 + GraphedTrainStep(pipeline_optimizer=True): the BertAdam update of iteration t is applied by the forward
     of iteration t + 1 -- embedding tables, vectors and each stack's first layer as launches in front of it, the other layers'
-    chunks as extra workgroups of the forward products of the layer before (univl_gemm_rider).  Same losses and parameters as
-    the eager loop, iteration by iteration; the last update stays pending until flush()."""
+    chunks as extra workgroups of the forward products of the layer before (univl_gemm_rider).  In deterministic mode the losses
+    and the parameters are BIT-IDENTICAL to the eager loop's, iteration by iteration (same arithmetic per element, same gradients);
+    the last update stays pending until flush()."""
     ref_l, ref_p, _ = _train("eager", case, dtype=torch.bfloat16)
     monkeypatch.setenv("UNIVL_ADAM_RIDE", "1")
     l, p, info = _train("graph", case, dtype=torch.bfloat16)
     assert info["mode"] == "whole"
-    np.testing.assert_allclose(l, ref_l, rtol=2e-3, atol=2e-4)
+    assert l == ref_l, (l, ref_l)
     for n in ref_p:
-        assert max_abs(p[n], ref_p[n]) < 2e-5, n
+        assert torch.equal(p[n], ref_p[n]), (n, max_abs(p[n], ref_p[n]))

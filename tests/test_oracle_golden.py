@@ -142,3 +142,31 @@ def test_oracle_metrics_match_reference(golden_dir):
     for n in (7, 60, 333):
         m = O.compute_metrics(g["x%d" % n])
         assert [m["R1"], m["R5"], m["R10"], float(m["MR"])] == list(g["m%d" % n])
+
+
+@pytest.mark.parametrize("name", ["align_small"])
+def test_oracle_matches_reference_cotangent_golden(golden_dir, name):
+    """The cotangent fixtures (oracle/make_golden.py: the reference's gradients of (sim * W).sum() for seeded non-negative W, the
+    well-posed form of the FT-Align backward) against the oracle's autograd."""
+    from make_golden import COT_KINDS, cotangent
+    g = _load(golden_dir, name + "_cot")
+    cfg, rows, dseed = case_config(name)
+    batch = O.synthetic_batch(cfg, rows, seed=dseed)
+    names = [str(s) for s in g["grad_names"]]
+    assert [str(k) for k in g["kinds"]] == COT_KINDS
+    for kind in COT_KINDS:
+        P = {k: v.requires_grad_(True) for k, v in O.procedural_params(cfg, 0).items()}
+        Wc = cotangent(kind, rows * cfg.n_pair)
+        np.testing.assert_array_equal(Wc.numpy(), g["W_" + kind])
+        loss, parts = O.univl_forward(P, cfg, batch, training=True, return_parts=True, sim_loss_fct=lambda s: (s * Wc).sum())
+        loss.backward()
+        np.testing.assert_allclose(parts["sim_matrix"].detach().numpy(), g["sim_" + kind], rtol=2e-4, atol=2e-5)
+        assert abs(float(loss) - float(g["loss_" + kind])) <= 2e-5 * max(1.0, abs(float(g["loss_" + kind])))
+        gmax = float(np.max(g["grad_norms_" + kind]))
+        for i, n in enumerate(names):
+            ref = float(g["grad_norms_" + kind][i])
+            got = float(P[n].grad.double().norm())
+            assert abs(got - ref) <= 2e-4 * ref + 1e-6 * gmax, (kind, n, got, ref)
+            rs = g["grad_samples_" + kind][i]
+            gs = sample_exact(P[n].grad, 256)
+            assert float(np.linalg.norm(gs - rs[:gs.size])) <= 5e-4 * float(np.linalg.norm(rs)) + 1e-6 * gmax, (kind, n)

@@ -4,3 +4,4 @@ Public surface mirrors the reference's modules (`modules.modeling.UniVL`, `modul
 all arithmetic runs in libunivl_hip.so (hand-written HIP kernels), there is no CPU / PyTorch fallback."""
 from .modeling import UniVL  # noqa: F401
 from .optimization import BertAdam, clip_grad_norm_  # noqa: F401
+from ._lib import deterministic, set_deterministic  # noqa: F401

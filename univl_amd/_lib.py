@@ -134,12 +134,26 @@ def lib():
     L.univl_device_info.argtypes = [C.POINTER(i32), C.c_char_p, i32]
     L.univl_init.argtypes = [i32]
     L.univl_allreduce_bucket.argtypes = [vp, C.c_size_t, i32, i32, vp, vp]
+    L.univl_set_deterministic.argtypes = [i32]
     _lib = L
     return L
 
 
+def deterministic():
+    """UNIVL_DETERMINISTIC=1 (read when a model is flattened onto its device) or set_deterministic(True)."""
+    return bool(lib().univl_get_deterministic())
+
+
+def set_deterministic(on=True):
+    """Fixed-order reductions in every kernel launched from now on (include/univl_hip.h: univl_set_deterministic) -- two runs on the
+    same inputs give bit-identical results.  Allocates the library's scratch ring on the CURRENT device: call it outside a stream
+    capture, after torch.cuda.set_device.  Plans / hipGraphs built earlier keep the mode they were built in (a model rebuilds its
+    plans when its _steps are cleared, e.g. by model.to(device))."""
+    check(lib().univl_set_deterministic(1 if on else 0), "set_deterministic")
+
+
 EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_device_info", "univl_init", "univl_destroy",
-            "univl_allreduce_bucket", "univl_gemm", "univl_gemm_group_limited", "univl_gemm_group", "univl_gemm_tile_map", "univl_gemm_pair", "univl_gemm_rider", "univl_gemm_rider_prime",
+            "univl_allreduce_bucket", "univl_set_deterministic", "univl_get_deterministic", "univl_gemm", "univl_gemm_group_limited", "univl_gemm_group", "univl_gemm_tile_map", "univl_gemm_pair", "univl_gemm_rider", "univl_gemm_rider_prime",
             "univl_layernorm_fwd", "univl_layernorm_bwd", "univl_attention_fwd", "univl_attention_bwd",
             "univl_embed_text_fwd", "univl_embed_text_bwd", "univl_embed_scatter", "univl_rows_zero", "univl_rows_append",
             "univl_rows_sumsq", "univl_zero_many", "univl_copy_many", "univl_pool_fwd", "univl_pool_bwd",

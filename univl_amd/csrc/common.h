@@ -82,6 +82,36 @@ static inline void univl_allow_lds(K kernel, size_t bytes, bool (&done)[UNIVL_MA
     if (tracked) done[dev] = true;
 }
 
+// ------------------------------------------------------------------------------------------- deterministic mode
+// univl_set_deterministic(1) (C ABI; UNIVL_DETERMINISTIC=1 on the Python side): every floating-point sum whose ORDER the default
+// kernels leave to the hardware (fp32 atomics: split-K, column sums of LayerNorm / bias gradients, embedding scatter-adds,
+// gradient-norm partials, loss accumulators) is taken in a FIXED order instead, so that two runs on the same inputs are
+// bit-identical.  It is the mode the parity tests run in; the production default keeps the atomics (fire-and-forget, no second pass).
+// Column sums use "the last block to arrive reduces": every block publishes its partial vector in a scratch slice, bumps a counter,
+// and the block that sees the final count adds the partials in block order.  Scatter-adds become gather-style follow-up kernels
+// ("first occurrence of a destination sums all its sources in source order").  Scratch comes from a per-device ring owned by the
+// library (allocated by univl_set_deterministic, never on the hot path of the default mode).
+bool univl_deterministic();
+void* univl_det_alloc(size_t bytes);      // 256-byte aligned slice of the current device's ring; nullptr (+ error string) if unavailable
+int* univl_det_counter();                 // a zero-initialised device int; its user leaves it at zero again
+
+#ifdef __HIPCC__
+// Call from ALL threads of a block after the block's partials were stored: true in exactly one block, the last one to arrive, with
+// every other block's partials visible to it.  The counter is reset by the caller's last block (det_reset).
+__device__ __forceinline__ bool det_last_block(int* counter, int nblocks, int* flag_lds) {
+    __threadfence();                       // agent-scope release of this thread's partial stores (write-back of this XCD's L2)
+    __syncthreads();
+    if (threadIdx.x == 0) *flag_lds = (atomicAdd(counter, 1) == nblocks - 1) ? 1 : 0;
+    __syncthreads();
+    const bool last = *flag_lds != 0;
+    if (last) {
+        __threadfence();                   // agent-scope acquire: the other XCDs' partials are read from memory, not from a stale L2
+        if (threadIdx.x == 0) *counter = 0;   // ready for the next launch / graph replay that uses this counter
+    }
+    return last;
+}
+#endif
+
 // ------------------------------------------------------------------------------------------- small helpers
 __device__ __forceinline__ float bf2f(__bf16 v) { return (float)v; }
 __device__ __forceinline__ __bf16 f2bf(float v) { return (__bf16)v; }   // RNE on gfx950 (v_cvt_pk_bf16_f32)

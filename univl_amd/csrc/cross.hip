@@ -56,6 +56,40 @@ __global__ __launch_bounds__(256) void pair_concat_bwd_kernel(const float* dout,
     }
 }
 
+// Deterministic form (common.h): output row (p, s) owns its destination row iff no earlier pair p' < p points at the same source
+// row; the owner adds the rows (p'', s) of ALL pairs with that source row in pair order, then adds the total to the destination.
+__global__ __launch_bounds__(256) void pair_concat_bwd_det_kernel(const float* dout, const int32_t* tidx, const int32_t* vidx,
+                                                                  int P, int W, int F, float* dseq, float* dvis) {
+    const int S = W + F;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)P * S) return;
+    const int p = (int)(row / S), s = (int)(row % S);
+    const int32_t* idx = (s < W) ? tidx : vidx;
+    const int mine = idx[p];
+    int dup = 0;
+    for (int j = lane; j < p; j += 64) dup |= (idx[j] == mine) ? 1 : 0;
+    if (__any(dup)) return;                                    // wave-uniform
+    float4 acc[3] = {float4{0.f, 0.f, 0.f, 0.f}, float4{0.f, 0.f, 0.f, 0.f}, float4{0.f, 0.f, 0.f, 0.f}};
+    for (int u = p; u < P; ++u) {
+        if (idx[u] != mine) continue;
+        const float* src = dout + ((long)u * S + s) * N;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(src + 4 * lane + 256 * j);
+            acc[j].x += v.x; acc[j].y += v.y; acc[j].z += v.z; acc[j].w += v.w;
+        }
+    }
+    float* dst = (s < W) ? dseq + ((long)mine * W + s) * N : dvis + ((long)mine * F + (s - W)) * N;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float4* d = reinterpret_cast<float4*>(dst + 4 * lane + 256 * j);
+        float4 o = *d;
+        o.x += acc[j].x; o.y += acc[j].y; o.z += acc[j].z; o.w += acc[j].w;
+        *d = o;
+    }
+}
+
 __global__ __launch_bounds__(256) void postype_fwd_kernel(const float* pos, const float* type, int W, int S, float* out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)S * N) return;
@@ -63,13 +97,19 @@ __global__ __launch_bounds__(256) void postype_fwd_kernel(const float* pos, cons
     out[i] = pos[i] + type[(s >= W ? N : 0) + c];
 }
 
+// dpos[s] += dpt[s] (one writer per element); dtype[0] += sum_{s < W} dpt[s], dtype[1] += sum_{s >= W} dpt[s]: the threads of
+// positions 0 and W walk their half in position order (a fixed order: no atomics, the same bits every run)
 __global__ __launch_bounds__(256) void postype_bwd_kernel(const float* dpt, int W, int S, float* dpos, float* dtype) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)S * N) return;
     const int s = (int)(i / N), c = (int)(i % N);
-    const float g = dpt[i];
-    unsafeAtomicAdd(dpos + i, g);
-    unsafeAtomicAdd(dtype + (s >= W ? N : 0) + c, g);
+    dpos[i] += dpt[i];
+    if (s == 0 || s == W) {
+        const int s1 = (s == 0 && W > 0) ? W : S;            // W == 0: position 0 is already the second half
+        float acc = 0.f;
+        for (int u = s; u < s1; ++u) acc += dpt[(long)u * N + c];
+        dtype[((s >= W) ? N : 0) + c] += acc;
+    }
 }
 
 __global__ __launch_bounds__(256) void tanh_fwd_kernel(const float* x, float* y, long n) {
@@ -91,13 +131,14 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* dg, const T*
 
 // out[c] += sum_r x[r, c]   (bias gradient of a projection whose weight gradient is produced transposed)
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* x, long ld, int rows, int n, float* out) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, long ld, int rows, int n, float* out, int rows_per_block) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= n) return;
     float acc = 0.f;
-    const int r0 = blockIdx.y * 64, r1 = min(rows, r0 + 64);
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     for (int r = r0; r < r1; ++r) acc += to_f32<T>(x[(long)r * ld + c]);
-    unsafeAtomicAdd(out + c, acc);
+    if (gridDim.y == 1) out[c] += acc;                       // deterministic mode: one block walks every row in order
+    else unsafeAtomicAdd(out + c, acc);
 }
 
 template <typename T>
@@ -181,9 +222,11 @@ __global__ __launch_bounds__(256) void ce_count_kernel(const int64_t* labels, in
 }
 
 // one workgroup per row: log-softmax over V, loss += (lse - x[label]) / n_valid, d = (softmax - onehot) / n_valid
+// rowloss != nullptr (deterministic mode): the row's loss term goes to rowloss[row] and ce_finish_kernel adds the slots in row
+// order; otherwise it is added to scal[1] with an fp32 atomic.
 template <typename T>
 __global__ __launch_bounds__(256) void ce_row_kernel(const float* logits, long ld, const int64_t* labels, int V, int ignore,
-                                                     float* scal, T* dl, long lddl) {
+                                                     float* scal, T* dl, long lddl, float* rowloss) {
     __shared__ float red[4];
     const int row = blockIdx.x;
     const float* x = logits + (long)row * ld;
@@ -192,6 +235,7 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const float* logits, long l
     const float nvalid = scal[0];
     if (lab == ignore || nvalid == 0.0f) {
         for (int j = threadIdx.x; j < V; j += 256) d[j] = from_f32<T>(0.0f);
+        if (rowloss && threadIdx.x == 0) rowloss[row] = 0.0f;
         return;
     }
     float mx = -INFINITY;
@@ -204,15 +248,27 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const float* logits, long l
     const float inv = 1.0f / nvalid;
     for (int j = threadIdx.x; j < V; j += 256)
         d[j] = from_f32<T>((expf(x[j] - lse) - (j == lab ? 1.0f : 0.0f)) * inv);
-    if (threadIdx.x == 0) unsafeAtomicAdd(scal + 1, (lse - x[lab]) * inv);
+    if (threadIdx.x == 0) {
+        if (rowloss) rowloss[row] = (lse - x[lab]) * inv;
+        else unsafeAtomicAdd(scal + 1, (lse - x[lab]) * inv);
+    }
 }
 
-__global__ void ce_finish_kernel(const float* scal, float* loss) { loss[0] = scal[0] > 0.f ? scal[1] : NAN; }
+__global__ __launch_bounds__(256) void ce_finish_kernel(const float* scal, float* loss, const float* rowloss, int rows) {
+    __shared__ float red[4];
+    float total = scal[1];
+    if (rowloss) {
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < rows; i += 256) acc += rowloss[i];
+        total = block_sum(acc, red);
+    }
+    if (threadIdx.x == 0) loss[0] = scal[0] > 0.f ? total : NAN;
+}
 
 // MFM NCE (modeling.py:285-297): row i of the [n,n] logits is masked with (1 - m_i m_j) * -1e8, the loss is the mean over
 // rows with label != -1 of  -(log_softmax(row)[i]).  Writes d logits (fp32, in place allowed) for an upstream grad of 1.
 __global__ __launch_bounds__(256) void mfm_kernel(const float* logits, long ld, const int64_t* vmask, const int64_t* labels,
-                                                  int n, float* scal, float* dl, long lddl) {
+                                                  int n, float* scal, float* dl, long lddl, float* rowloss) {
     __shared__ float red[4];
     const int i = blockIdx.x;
     const float* x = logits + (long)i * ld;
@@ -221,6 +277,7 @@ __global__ __launch_bounds__(256) void mfm_kernel(const float* logits, long ld, 
     const bool sel = labels[i] != -1;
     if (!sel || nvalid == 0.0f) {
         for (int j = threadIdx.x; j < n; j += 256) d[j] = 0.0f;
+        if (rowloss && threadIdx.x == 0) rowloss[i] = 0.0f;
         return;
     }
     const float mi = (float)vmask[i];
@@ -239,7 +296,8 @@ __global__ __launch_bounds__(256) void mfm_kernel(const float* logits, long ld, 
     }
     if (threadIdx.x == 0) {
         const float vii = xii + (1.0f - mi * mi) * -1e8f;
-        unsafeAtomicAdd(scal + 1, (lse - vii) * inv);
+        if (rowloss) rowloss[i] = (lse - vii) * inv;
+        else unsafeAtomicAdd(scal + 1, (lse - vii) * inv);
     }
 }
 
@@ -263,8 +321,12 @@ extern "C" int univl_pair_concat_bwd(const float* dout, const int32_t* tidx, con
     UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(dout && tidx && vidx && dseq && dvis && P > 0 && W > 0 && F > 0, UNIVL_EINVAL, "univl_pair_concat_bwd: bad argument");
     const long rows = (long)P * (W + F);
-    hipLaunchKernelGGL(pair_concat_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, dout, tidx, vidx, P, W, F,
-                       dseq, dvis);
+    if (univl_deterministic())
+        hipLaunchKernelGGL(pair_concat_bwd_det_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, dout, tidx, vidx, P, W, F,
+                           dseq, dvis);
+    else
+        hipLaunchKernelGGL(pair_concat_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, dout, tidx, vidx, P, W, F,
+                           dseq, dvis);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
@@ -323,11 +385,12 @@ extern "C" int univl_gelu_bwd(int32_t dtype, const float* dg, const void* u, voi
 extern "C" int univl_colsum(int32_t dtype, const void* x, int64_t ld, int32_t rows, int32_t n, float* out, hipStream_t stream) {
     UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(x && out && rows > 0 && n > 0, UNIVL_EINVAL, "univl_colsum: bad argument");
-    dim3 grid((n + 255) / 256, (rows + 63) / 64);
+    const int rpb = univl_deterministic() ? rows : 64;
+    dim3 grid((n + 255) / 256, (rows + rpb - 1) / rpb);
     if (dtype == UNIVL_DT_BF16)
-        hipLaunchKernelGGL((colsum_kernel<__bf16>), grid, dim3(256), 0, stream, reinterpret_cast<const __bf16*>(x), (long)ld, rows, n, out);
+        hipLaunchKernelGGL((colsum_kernel<__bf16>), grid, dim3(256), 0, stream, reinterpret_cast<const __bf16*>(x), (long)ld, rows, n, out, rpb);
     else
-        hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, stream, reinterpret_cast<const float*>(x), (long)ld, rows, n, out);
+        hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, stream, reinterpret_cast<const float*>(x), (long)ld, rows, n, out, rpb);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
@@ -420,14 +483,19 @@ extern "C" int univl_ce_loss(int32_t dtype, const float* logits, int64_t ld, con
     UNIVL_CHECK_ARG(logits && labels && scratch2 && loss && dlogits && rows > 0 && V > 0 && ld >= V && lddl >= V, UNIVL_EINVAL,
                     "univl_ce_loss: bad argument");
     UNIVL_CHECK_ARG(dtype == UNIVL_DT_F32 || dtype == UNIVL_DT_BF16, UNIVL_EUNSUPPORTED, "univl_ce_loss: dtype %d", dtype);
+    float* rowloss = nullptr;
+    if (univl_deterministic()) {
+        rowloss = static_cast<float*>(univl_det_alloc((size_t)rows * sizeof(float)));
+        if (!rowloss) return UNIVL_EINVAL;
+    }
     hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, stream, labels, rows, ignore_index, scratch2);
     if (dtype == UNIVL_DT_BF16)
         hipLaunchKernelGGL((ce_row_kernel<__bf16>), dim3(rows), dim3(256), 0, stream, logits, (long)ld, labels, V, ignore_index,
-                           scratch2, reinterpret_cast<__bf16*>(dlogits), (long)lddl);
+                           scratch2, reinterpret_cast<__bf16*>(dlogits), (long)lddl, rowloss);
     else
         hipLaunchKernelGGL((ce_row_kernel<float>), dim3(rows), dim3(256), 0, stream, logits, (long)ld, labels, V, ignore_index,
-                           scratch2, reinterpret_cast<float*>(dlogits), (long)lddl);
-    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(1), 0, stream, scratch2, loss);
+                           scratch2, reinterpret_cast<float*>(dlogits), (long)lddl, rowloss);
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, stream, scratch2, loss, rowloss, rows);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
@@ -437,9 +505,14 @@ extern "C" int univl_mfm_nce_loss(const float* logits, int64_t ld, const int64_t
     UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(logits && vmask && labels && scratch2 && loss && dlogits && n > 0 && ld >= n && lddl >= n, UNIVL_EINVAL,
                     "univl_mfm_nce_loss: bad argument");
+    float* rowloss = nullptr;
+    if (univl_deterministic()) {
+        rowloss = static_cast<float*>(univl_det_alloc((size_t)n * sizeof(float)));
+        if (!rowloss) return UNIVL_EINVAL;
+    }
     hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, stream, labels, n, -1, scratch2);
-    hipLaunchKernelGGL(mfm_kernel, dim3(n), dim3(256), 0, stream, logits, (long)ld, vmask, labels, n, scratch2, dlogits, (long)lddl);
-    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(1), 0, stream, scratch2, loss);
+    hipLaunchKernelGGL(mfm_kernel, dim3(n), dim3(256), 0, stream, logits, (long)ld, vmask, labels, n, scratch2, dlogits, (long)lddl, rowloss);
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, stream, scratch2, loss, rowloss, n);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }

@@ -76,7 +76,12 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(UnivlEmbedText p) {
     }
 }
 
-__global__ __launch_bounds__(256) void embed_bwd_kernel(UnivlEmbedText p) {
+// DET (deterministic mode, common.h): nothing is scattered from here.  Every token's table-gradient row goes to p.drows (scratch
+// when the caller gave none); the word / position / token-type tables are then filled by the gather kernels below, each
+// destination row summing its source rows in token order.  dgamma / dbeta: per-block partials in det_part[2][gridDim.x][N], added
+// in block order by the last block to arrive.
+template <bool DET = false>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(UnivlEmbedText p, float* det_part = nullptr, int* det_counter = nullptr) {
     __shared__ float red[4][N];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(UnivlEmbedText p) {
                 const float dx = rstd * (dy[j][e] * ga[j][e] - s1 - xh[j][e] * s2);
                 if (p.drows) p.drows[(long)row * N + col + e] = dx;
                 else unsafeAtomicAdd(p.dword + id * N + col + e, dx);
-                unsafeAtomicAdd(p.dpos + (long)s * N + col + e, dx);
+                if (!DET) unsafeAtomicAdd(p.dpos + (long)s * N + col + e, dx);
                 // token types 0 / 1 (every row of a batch hits the same one or two table rows) are combined per
                 // block below; anything else goes straight to the table
                 if (p.dtype_emb && tt > 1) unsafeAtomicAdd(p.dtype_emb + tt * N + col + e, dx);
@@ -136,6 +141,34 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(UnivlEmbedText p) {
             }
         }
         row_type = (int)tt;
+    }
+    if constexpr (DET) {
+        __shared__ int last_flag;
+        const long nb = gridDim.x;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[wave][4 * lane + 256 * j + e] = t == 0 ? dgm[j][e] : dbt[j][e];
+            __syncthreads();
+            float* slot = det_part + ((long)t * nb + blockIdx.x) * N;
+            for (int c = threadIdx.x; c < N; c += 256) slot[c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        }
+        if (det_last_block(det_counter, (int)nb, &last_flag)) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float* dst = t == 0 ? p.dgamma : p.dbeta;
+                for (int c = threadIdx.x; c < N; c += 256) {
+                    const float* q = det_part + (long)t * nb * N + c;
+                    float acc = 0.f;
+                    for (long b = 0; b < nb; ++b) acc += q[b * N];
+                    dst[c] += acc;
+                }
+            }
+        }
+        return;
     }
     // dgamma / dbeta / token-type rows 0 and 1: combine the 4 rows of the block, one atomic per column per block
 #pragma unroll
@@ -172,6 +205,45 @@ extern "C" int univl_embed_text_fwd(const UnivlEmbedText* d, hipStream_t stream)
 }
 
 namespace {
+// Deterministic scatter: token t owns destination row ids[t] iff no earlier token has the same id; the owner adds the rows of ALL
+// tokens with that id in token order, then adds the total to the table (one writer per table row and launch).
+__global__ __launch_bounds__(256) void embed_scatter_det_kernel(const int64_t* ids, const float* rows, long n, float scale, float* dword) {
+    const long t = blockIdx.x;
+    const int64_t id = ids[t];
+    int dup = 0;
+    for (long j = threadIdx.x; j < t; j += 256) dup |= (ids[j] == id) ? 1 : 0;
+    if (__syncthreads_or(dup)) return;
+    float acc[NV] = {0.f, 0.f, 0.f};
+    for (long u = t; u < n; ++u) {
+        if (ids[u] != id) continue;                       // block-uniform
+#pragma unroll
+        for (int j = 0; j < NV; ++j) acc[j] += rows[u * N + threadIdx.x + 256 * j] * scale;
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) dword[id * N + threadIdx.x + 256 * j] += acc[j];
+}
+
+// dpos[s, c] += sum_b rows[b * S + s, c]   (b ascending)
+__global__ __launch_bounds__(256) void embed_dpos_gather_kernel(const float* rows, int B, int S, float* dpos) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)S * N) return;
+    const int s = (int)(i / N), c = (int)(i % N);
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += rows[((long)b * S + s) * N + c];
+    dpos[i] += acc;
+}
+
+// token-type rows 0 and 1: dtype[k, c] += sum over the tokens of type k of rows[t, c]   (t ascending); blockIdx.y = k
+__global__ __launch_bounds__(256) void embed_dtype_gather_kernel(const int64_t* type_ids, const float* rows, long n, float* dtype_emb) {
+    const int c = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    float acc = 0.f;
+    for (long t = 0; t < n; ++t) {
+        const int64_t tt = type_ids ? type_ids[t] : 0;    // uniform
+        if (tt == k) acc += rows[t * N + c];
+    }
+    if (acc != 0.0f) dtype_emb[(long)k * N + c] += acc;
+}
+
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* ids, const float* rows, float scale, float* dword) {
     const long t = blockIdx.x;
     const long id = ids[t];
@@ -182,7 +254,8 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* ids, 
 extern "C" int univl_embed_scatter(const int64_t* ids, const float* rows, int64_t n, float scale, float* dword, hipStream_t stream) {
     UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(ids && rows && dword && n > 0, UNIVL_EINVAL, "univl_embed_scatter: bad argument");
-    hipLaunchKernelGGL(embed_scatter_kernel, dim3((unsigned)n), dim3(256), 0, stream, ids, rows, scale, dword);
+    if (univl_deterministic()) hipLaunchKernelGGL(embed_scatter_det_kernel, dim3((unsigned)n), dim3(256), 0, stream, ids, rows, (long)n, scale, dword);
+    else hipLaunchKernelGGL(embed_scatter_kernel, dim3((unsigned)n), dim3(256), 0, stream, ids, rows, scale, dword);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
@@ -220,10 +293,10 @@ __global__ __launch_bounds__(256) void rows_append_kernel(const int64_t* ids, in
 }
 
 __global__ __launch_bounds__(256) void rows_sumsq_kernel(const float* table, long rows_total, const int64_t* list, const int* meta,
-                                                         float* out) {
+                                                         float* out, float* det_part) {
     __shared__ float red[4];
     const int n = meta[0], over = meta[1];
-    if (!over && (int)blockIdx.x >= n) return;
+    if (!over && (int)blockIdx.x >= n) { if (det_part && threadIdx.x == 0) det_part[blockIdx.x] = 0.f; return; }
     float acc = 0.f;
     if (over) {
         for (long r = blockIdx.x; r < rows_total; r += ROWS_GRID) {
@@ -234,14 +307,28 @@ __global__ __launch_bounds__(256) void rows_sumsq_kernel(const float* table, lon
         const int64_t r = list[blockIdx.x];
         int dup = 0;                                   // a row listed twice is counted by its first occurrence only
         for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) dup |= (list[j] == r) ? 1 : 0;
-        if (__syncthreads_or(dup)) return;
+        if (__syncthreads_or(dup)) { if (det_part && threadIdx.x == 0) det_part[blockIdx.x] = 0.f; return; }
         const float4* p = reinterpret_cast<const float4*>(table + r * N);
         for (int c = threadIdx.x; c < N / 4; c += 256) { const float4 v = p[c]; acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) {
+        const float s = (red[0] + red[1]) + (red[2] + red[3]);
+        if (det_part) det_part[blockIdx.x] = s;          // deterministic mode: rows_sumsq_finish_kernel adds the slots in block order
+        else unsafeAtomicAdd(out, s);
+    }
+}
+
+__global__ __launch_bounds__(256) void rows_sumsq_finish_kernel(const float* part, int n, float* out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] += (red[0] + red[1]) + (red[2] + red[3]);
 }
 }  // namespace
 
@@ -266,7 +353,13 @@ extern "C" int univl_rows_sumsq(const float* table, int64_t rows_total, const in
                                 hipStream_t stream) {
     UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(table && list && meta && out && rows_total > 0 && aligned16(table), UNIVL_EINVAL, "univl_rows_sumsq: bad argument");
-    hipLaunchKernelGGL(rows_sumsq_kernel, dim3(ROWS_GRID), dim3(256), 0, stream, table, (long)rows_total, list, meta, out);
+    float* part = nullptr;
+    if (univl_deterministic()) {
+        part = static_cast<float*>(univl_det_alloc(ROWS_GRID * sizeof(float)));
+        if (!part) return UNIVL_EINVAL;
+    }
+    hipLaunchKernelGGL(rows_sumsq_kernel, dim3(ROWS_GRID), dim3(256), 0, stream, table, (long)rows_total, list, meta, out, part);
+    if (part) hipLaunchKernelGGL(rows_sumsq_finish_kernel, dim3(1), dim3(256), 0, stream, part, ROWS_GRID, out);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
@@ -279,7 +372,26 @@ extern "C" int univl_embed_text_bwd(const UnivlEmbedText* d, hipStream_t stream)
                         d->dgamma && d->dbeta,
                     UNIVL_EINVAL, "univl_embed_text_bwd: null / empty argument");
     dim3 grid((d->B * d->S + 3) / 4), block(256);
-    hipLaunchKernelGGL(embed_bwd_kernel, grid, block, 0, stream, *d);
+    if (univl_deterministic()) {
+        UnivlEmbedText q = *d;
+        const long T = (long)d->B * d->S;
+        float* part = static_cast<float*>(univl_det_alloc((size_t)2 * grid.x * N * sizeof(float)));
+        int* counter = univl_det_counter();
+        if (!part || !counter) return UNIVL_EINVAL;
+        if (!q.drows) {
+            q.drows = static_cast<float*>(univl_det_alloc((size_t)T * N * sizeof(float)));
+            if (!q.drows) return UNIVL_EINVAL;
+        }
+        hipLaunchKernelGGL(embed_bwd_kernel<true>, grid, block, 0, stream, q, part, counter);
+        if (!d->drows)       // the caller wants the table gradient itself, not the per-token rows
+            hipLaunchKernelGGL(embed_scatter_det_kernel, dim3((unsigned)T), block, 0, stream, d->ids, q.drows, T, 1.0f, d->dword);
+        hipLaunchKernelGGL(embed_dpos_gather_kernel, dim3((unsigned)(((long)d->S * N + 255) / 256)), block, 0, stream, q.drows, d->B, d->S, d->dpos);
+        if (d->dtype_emb)
+            hipLaunchKernelGGL(embed_dtype_gather_kernel, dim3(N / 256, 2), block, 0, stream, d->type_ids, q.drows, T, d->dtype_emb);
+        UNIVL_LAUNCH_CHECK();
+        return UNIVL_OK;
+    }
+    hipLaunchKernelGGL(embed_bwd_kernel<false>, grid, block, 0, stream, *d);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }

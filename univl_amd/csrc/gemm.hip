@@ -752,7 +752,7 @@ static Choice choose(const UnivlGemm* d, int forced_tile) {
     if (bf16 && (want == 256 || (want == 0 && c.tile == 128 && t256_min > 0 && tiles256 >= t256_min))) c.tile = 256;
     if (c.tile == 256 && d->sumsq && d->sumsq_rows % 256 != 0) c.tile = 128;     // a tile must not straddle two tensors
     c.nc = c.tile == 64 ? 4 : 2;
-    const int ksplit = d->ksplit < 1 ? 1 : d->ksplit;
+    const int ksplit = (d->ksplit < 1 || univl_deterministic()) ? 1 : d->ksplit;
     // weight gradients at 4 pairs x 48 tokens contract over exactly 192 rows: one 192-deep stage = ONE DMA round trip
     // per workgroup, no partial tile through registers (the 128-deep stage needs a 128-step plus a masked 64-tail)
     if (one_step && c.tile == 64 && bf16 && d->trans_a && d->trans_b && d->K == 192 && ksplit == 1) c.nc = 6;
@@ -786,7 +786,9 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int 
     // 64x64 for parallelism.  The small tile stages 4 chunks (128 bf16 / 64 f32) per barrier: at M <= a few hundred the kernel
     // is a latency chain of K steps (DMA -> barrier -> ds_read -> MFMA), so fewer, deeper steps win.
     c = choose(d, forced_tile);
-    ksplit = d->ksplit < 1 ? 1 : d->ksplit;
+    // deterministic mode (common.h): no split-K -- the slices of a split product meet in fp32 atomics whose order is the hardware's;
+    // one workgroup per output tile walks the whole contraction in order (the pre-zeroed arena is simply overwritten)
+    ksplit = (d->ksplit < 1 || univl_deterministic()) ? 1 : d->ksplit;
     const int BK = (d->dtype == UNIVL_BF16 ? 32 : 16) * c.nc;
     int klen = ((d->K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
     ksplit = (d->K + klen - 1) / klen;

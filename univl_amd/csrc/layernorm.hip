@@ -125,8 +125,23 @@ __device__ __forceinline__ void block_colsum(float (*red)[N], const float (&part
     }
 }
 
-template <int N, typename TO>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(UnivlLayerNorm p, int rpw) {
+// Deterministic form (common.h): the block's column sums go to its slot of a scratch array instead of an atomic.
+template <int N>
+__device__ __forceinline__ void block_colsum_store(float (*red)[N], const float (&part)[N / 256][4], float* slot, int lane, int wave) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < N / 256; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave][4 * lane + 256 * j + e] = part[j][e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < N; c += 256) slot[c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// DET: dgamma / dbeta / dbias partials per block in det_part[3][gridDim.x][N], the last block to arrive adds them in block order;
+// position-row gradients are not scattered here: the fp32 dx rows (p.dx32, which the host points at scratch when the caller gave
+// none) are summed per position by ln_dpos_gather_kernel afterwards.
+template <int N, typename TO, bool DET = false>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(UnivlLayerNorm p, int rpw, float* det_part = nullptr, int* det_counter = nullptr) {
     constexpr int NV = N / 256;
     __shared__ float red[4][N];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -195,17 +210,48 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(UnivlLayerNorm p, int rpw) 
                     *reinterpret_cast<float4*>(d) = make_float4(dd[0], dd[1], dd[2], dd[3]);
                 }
             }
-            if (p.dpos) {
+            if (!DET && p.dpos) {
                 float* dp = p.dpos + (long)(row % p.pos_period) * N + col;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dp + e, dx[e]);
             }
         }
     }
+    if constexpr (DET) {
+        __shared__ int last_flag;
+        const long nb = gridDim.x;
+        block_colsum_store<N>(red, dg, det_part + (0 * nb + blockIdx.x) * N, lane, wave);
+        block_colsum_store<N>(red, db, det_part + (1 * nb + blockIdx.x) * N, lane, wave);
+        block_colsum_store<N>(red, dbi, det_part + (2 * nb + blockIdx.x) * N, lane, wave);
+        if (det_last_block(det_counter, (int)nb, &last_flag)) {
+            float* dst[3] = {p.dgamma, p.dbeta, p.dbias};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (dst[k] == nullptr) continue;
+                for (int c = threadIdx.x; c < N; c += 256) {
+                    const float* q = det_part + (long)k * nb * N + c;
+                    float acc = 0.f;
+                    for (long b = 0; b < nb; ++b) acc += q[b * N];
+                    dst[k][c] += acc;
+                }
+            }
+        }
+    } else {
     // block reduction of the three column sums, one LDS pass each (pointers are block-uniform)
     block_colsum<N>(red, dg, p.dgamma, lane, wave);
     block_colsum<N>(red, db, p.dbeta, lane, wave);
     block_colsum<N>(red, dbi, p.dbias, lane, wave);
+    }
+}
+
+// dpos[s, c] += sum over the rows r with r % period == s of dx[r, c], in row order (deterministic form of the scatter above)
+__global__ __launch_bounds__(256) void ln_dpos_gather_kernel(const float* dx, int rows, int period, int n, float* dpos) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)period * n) return;
+    const int s = (int)(i / n), c = (int)(i % n);
+    float acc = 0.f;
+    for (long r = s; r < rows; r += period) acc += dx[r * n + c];
+    dpos[i] += acc;
 }
 
 int check_common(const UnivlLayerNorm* d, const char* who) {
@@ -257,6 +303,28 @@ extern "C" int univl_layernorm_bwd(const UnivlLayerNorm* d, hipStream_t stream) 
     rpw = rpw < 1 ? 1 : (rpw > LN_RPW ? LN_RPW : rpw);
     dim3 grid((d->rows + 4 * rpw - 1) / (4 * rpw)), block(256);
     const bool bf = d->dtype == UNIVL_DT_BF16;
+    if (univl_deterministic()) {
+        UnivlLayerNorm q = *d;
+        float* part = static_cast<float*>(univl_det_alloc((size_t)3 * grid.x * d->N * sizeof(float)));
+        int* counter = univl_det_counter();
+        if (!part || !counter) return UNIVL_EINVAL;
+        if (q.dpos && !q.dx32) {
+            q.dx32 = static_cast<float*>(univl_det_alloc((size_t)d->rows * d->N * sizeof(float)));
+            if (!q.dx32) return UNIVL_EINVAL;
+        }
+        if (d->N == 768) {
+            if (bf) hipLaunchKernelGGL((ln_bwd_kernel<768, __bf16, true>), grid, block, 0, stream, q, rpw, part, counter);
+            else hipLaunchKernelGGL((ln_bwd_kernel<768, float, true>), grid, block, 0, stream, q, rpw, part, counter);
+        } else {
+            if (bf) hipLaunchKernelGGL((ln_bwd_kernel<1024, __bf16, true>), grid, block, 0, stream, q, rpw, part, counter);
+            else hipLaunchKernelGGL((ln_bwd_kernel<1024, float, true>), grid, block, 0, stream, q, rpw, part, counter);
+        }
+        if (q.dpos)
+            hipLaunchKernelGGL(ln_dpos_gather_kernel, dim3((unsigned)(((long)q.pos_period * d->N + 255) / 256)), block, 0, stream,
+                               q.dx32, d->rows, q.pos_period, d->N, q.dpos);
+        UNIVL_LAUNCH_CHECK();
+        return UNIVL_OK;
+    }
     if (d->N == 768) {
         if (bf) hipLaunchKernelGGL((ln_bwd_kernel<768, __bf16>), grid, block, 0, stream, *d, rpw);
         else hipLaunchKernelGGL((ln_bwd_kernel<768, float>), grid, block, 0, stream, *d, rpw);

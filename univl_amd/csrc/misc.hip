@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <dlfcn.h>
+#include <stdlib.h>
 #include "common.h"
 #include "univl_hip.h"
 
@@ -44,6 +45,74 @@ extern "C" int univl_device_info(int* cu_count, char* name, int name_len) {
     if (name && name_len > 0) { strncpy(name, prop.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
     return 0;
 }
+
+// ---- deterministic mode (common.h): flag, per-device scratch ring and counter pool
+#include <mutex>
+namespace {
+struct DetArena { unsigned char* base = nullptr; size_t size = 0, head = 0; int* counters = nullptr; int next_counter = 0; };
+constexpr int DET_COUNTERS = 1 << 16;
+DetArena g_det[UNIVL_MAX_DEVICES];
+std::mutex g_det_mutex;
+int g_deterministic = 0;
+
+DetArena* det_arena() {          // the current device's arena, created on first use (NOT inside a stream capture: hipMalloc)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= UNIVL_MAX_DEVICES) return nullptr;
+    DetArena& a = g_det[dev];
+    if (a.base == nullptr) {
+        const char* e = getenv("UNIVL_DET_ARENA_MB");
+        const size_t mb = e ? (size_t)atol(e) : 1024;
+        void* p = nullptr;
+        void* c = nullptr;
+        if (hipMalloc(&p, mb << 20) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMalloc(&c, DET_COUNTERS * sizeof(int)) != hipSuccess || hipMemset(c, 0, DET_COUNTERS * sizeof(int)) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError(); (void)hipFree(p); if (c) (void)hipFree(c); return nullptr;
+        }
+        a.base = static_cast<unsigned char*>(p); a.size = mb << 20; a.head = 0;
+        a.counters = static_cast<int*>(c); a.next_counter = 0;
+    }
+    return &a;
+}
+}  // namespace
+
+bool univl_deterministic() { return g_deterministic != 0; }
+
+void* univl_det_alloc(size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_det_mutex);
+    DetArena* a = det_arena();
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (a == nullptr || bytes > a->size / 4) {
+        univl_set_error("deterministic mode: no scratch ring on this device (call univl_set_deterministic(1) on it outside a stream "
+                        "capture; a single request must fit a quarter of UNIVL_DET_ARENA_MB), %zu bytes asked", bytes);
+        return nullptr;
+    }
+    if (a->head + bytes > a->size) a->head = 0;      // ring: a slice is reused only after the whole ring went by
+    void* p = a->base + a->head;
+    a->head += bytes;
+    return p;
+}
+
+int* univl_det_counter() {
+    std::lock_guard<std::mutex> lock(g_det_mutex);
+    DetArena* a = det_arena();
+    if (a == nullptr) { univl_set_error("deterministic mode: no counter pool on this device"); return nullptr; }
+    int* c = a->counters + a->next_counter;
+    a->next_counter = (a->next_counter + 1) % DET_COUNTERS;
+    return c;
+}
+
+extern "C" int univl_set_deterministic(int on) {
+    std::lock_guard<std::mutex> lock(g_det_mutex);
+    g_deterministic = on ? 1 : 0;
+    if (on && det_arena() == nullptr) {
+        univl_set_error("univl_set_deterministic: cannot allocate the scratch ring (UNIVL_DET_ARENA_MB) on the current device");
+        return UNIVL_EINVAL;
+    }
+    return UNIVL_OK;
+}
+
+extern "C" int univl_get_deterministic(void) { return g_deterministic; }
 
 // ---- several buffers cleared by ONE launch (a backward starts by zeroing ~8 accumulation buffers: one graph node, not 8)
 namespace {
@@ -132,6 +201,14 @@ static void* g_rccl_handle = nullptr;
 static nccl_allreduce_fn g_allreduce = nullptr;
 
 extern "C" int univl_destroy(void) {
+    {
+        std::lock_guard<std::mutex> lock(g_det_mutex);
+        for (DetArena& a : g_det) {
+            if (a.base) (void)hipFree(a.base);
+            if (a.counters) (void)hipFree(a.counters);
+            a = DetArena();
+        }
+    }
     g_allreduce = nullptr;
     if (g_rccl_handle) { dlclose(g_rccl_handle); g_rccl_handle = nullptr; }
     return UNIVL_OK;

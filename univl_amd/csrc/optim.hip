@@ -26,11 +26,13 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// det_part != nullptr (deterministic mode, common.h): the chunk's sum goes to det_part[chunk] and sumsq_seg_finish_kernel adds a
+// tensor's chunks in chunk order; otherwise one fp32 atomic per chunk into the tensor's slot.
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, const UnivlSeg* segs, const int32_t* chunk_seg,
-                                                    const int64_t* chunk_off, const int32_t* chunk_len, float* sumsq) {
+                                                    const int64_t* chunk_off, const int32_t* chunk_len, float* sumsq, float* det_part) {
     __shared__ float red[4];
     const int c = blockIdx.x, seg = chunk_seg[c];
-    if (!segs[seg].active) return;
+    if (!segs[seg].active) { if (det_part && threadIdx.x == 0) det_part[c] = 0.f; return; }
     const float* p = g + chunk_off[c];
     const int len = chunk_len[c];
     float acc = 0.f;
@@ -51,7 +53,23 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, const UnivlS
     }
     for (int j = nv * 4 + threadIdx.x; j < len; j += 256) acc += p[j] * p[j];
     const float s = block_sum256(acc, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(sumsq + seg, s);
+    if (threadIdx.x == 0) {
+        if (det_part) det_part[c] = s;
+        else unsafeAtomicAdd(sumsq + seg, s);
+    }
+}
+
+// one thread per chunk; the FIRST chunk of a tensor walks the tensor's run of chunks (the host lists them contiguously)
+__global__ __launch_bounds__(256) void sumsq_seg_finish_kernel(const float* part, const UnivlSeg* segs, const int32_t* chunk_seg, int nchunk,
+                                                               float* sumsq) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= nchunk) return;
+    const int seg = chunk_seg[c];
+    if (c > 0 && chunk_seg[c - 1] == seg) return;
+    if (!segs[seg].active) return;
+    float acc = 0.f;
+    for (int u = c; u < nchunk && chunk_seg[u] == seg; ++u) acc += part[u];
+    sumsq[seg] += acc;
 }
 
 __global__ __launch_bounds__(256) void clip_coef_kernel(const float* sumsq, const UnivlSeg* segs, int nseg, float max_norm,
@@ -204,7 +222,13 @@ extern "C" int univl_grad_sumsq(const float* g, const UnivlSeg* segs, int32_t ns
     UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(g && segs && chunk_seg && chunk_off && chunk_len && sumsq && nseg > 0 && nchunk > 0, UNIVL_EINVAL,
                     "univl_grad_sumsq: bad argument");
-    hipLaunchKernelGGL(sumsq_kernel, dim3(nchunk), dim3(256), 0, stream, g, segs, chunk_seg, chunk_off, chunk_len, sumsq);
+    float* part = nullptr;
+    if (univl_deterministic()) {
+        part = static_cast<float*>(univl_det_alloc((size_t)nchunk * sizeof(float)));
+        if (!part) return UNIVL_EINVAL;
+    }
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nchunk), dim3(256), 0, stream, g, segs, chunk_seg, chunk_off, chunk_len, sumsq, part);
+    if (part) hipLaunchKernelGGL(sumsq_seg_finish_kernel, dim3((nchunk + 255) / 256), dim3(256), 0, stream, part, segs, chunk_seg, nchunk, sumsq);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }

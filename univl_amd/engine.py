@@ -148,8 +148,11 @@ class FlatParams:
         """(list, meta) device buffers of the sparse word-table bookkeeping (univl_rows_zero / _append / _sumsq): the table
         rows written by the backward passes since the last clear."""
         if getattr(self, "_word_rows", None) is None:
-            self._word_rows = (torch.zeros(self.WORD_ROWS_CAP, dtype=torch.int64, device=self.device),
-                               torch.zeros(2, dtype=torch.int32, device=self.device))
+            # created lazily by the first backward that uses the bookkeeping -- earlier backwards (a batch above WORD_ROWS_CAP, the
+            # dense path) may have written any row of the table: start in the "every row counts as listed" state
+            meta = torch.zeros(2, dtype=torch.int32, device=self.device)
+            meta[1] = 1
+            self._word_rows = (torch.zeros(self.WORD_ROWS_CAP, dtype=torch.int64, device=self.device), meta)
             self.word_rows_version = -1
         return self._word_rows
 
@@ -201,6 +204,9 @@ class FlatParams:
 
     def refresh_shadow(self, force=False):
         if self.p16 is not None and (force or not self.shadow_valid):
+            if getattr(self, "shard_reducer", None) is not None and not getattr(self, "master_complete", True):
+                raise RuntimeError("FlatParams.refresh_shadow: the fp32 master weights are sharded over the ranks and this rank's copy of "
+                                   "the other ranks' pieces is stale -- call model.consolidate_parameters() (a collective) first")
             ops.cast_bf16(self.p32, self.p16)
         self.shadow_valid = True
 

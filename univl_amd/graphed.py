@@ -47,10 +47,12 @@ from .steps import stage_input
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, max_grad_norm=1.0, warmup=3, persistent_inputs=True, pipeline_optimizer=False, async_loss=False):
-        """persistent_inputs=True: the tensors of the first captured call ARE the static input buffers when they live on
-        the model's device (later calls may pass the same tensors refilled in place -- no copy -- or other tensors, e.g.
-        the loader's host batch, which are copied in)."""
+    def __init__(self, model, optimizer, max_grad_norm=1.0, warmup=3, persistent_inputs=False, pipeline_optimizer=False, async_loss=False):
+        """persistent_inputs=False (default): the graphs read PRIVATE static copies of the batch; every call copies its arguments in
+        (one copy kernel for device tensors) and never touches the caller's tensors.  persistent_inputs=True (opt-in, what bench.py
+        uses for its HBM-resident batch): the device tensors of the first captured call BECOME the static input buffers -- later
+        calls may pass the same tensors refilled in place (no copy at all), and any OTHER batch passed later is copied INTO them,
+        i.e. the caller's first batch is overwritten; a caller that keeps or mutates that batch must not use this mode."""
         self.model, self.opt = model, optimizer
         self.max_grad_norm = max_grad_norm
         self.warmup = int(warmup)

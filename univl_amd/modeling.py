@@ -544,6 +544,9 @@ class UniVL(UniVLPreTrainedModel):
             if not p0.is_cuda:
                 raise RuntimeError("univl_amd.UniVL runs only on a HIP device (call model.to('cuda')); no CPU fallback")
             _lib.lib()
+            if os.environ.get("UNIVL_DETERMINISTIC", "0") == "1" and not _lib.deterministic():
+                with torch.cuda.device(p0.device):         # fixed-order reductions (bit-reproducible runs): include/univl_hip.h
+                    _lib.set_deterministic(True)
             self._flat = FlatParams(named, p0.device, self.compute_dtype)
             self._seed_dev = torch.zeros(1, device=p0.device, dtype=torch.int64)
             self._steps = {}
@@ -562,6 +565,7 @@ class UniVL(UniVLPreTrainedModel):
         if not self._reducer.active:
             self._reducer = None
         fl.owned, fl.shard_reducer, fl.master_complete = None, None, True
+        fl.partition_version = getattr(fl, "partition_version", 0) + 1      # chunk-table caches of the optimizer are keyed on it
         if shard_optimizer is None:
             shard_optimizer = os.environ.get("UNIVL_SHARD_OPT", "0") == "1"
         if shard_optimizer and self._reducer is not None and not loopback:

@@ -50,6 +50,15 @@ def _find_flat(p):
                        "(call the model once, or access model.flat, after model.to('cuda')); there is no CPU fallback")
 
 
+def owns(p):
+    """True when `p` is a parameter of a univl_amd model that lives in a flat buffer on a HIP device."""
+    try:
+        _find_flat(p)
+        return True
+    except RuntimeError:
+        return False
+
+
 class _Tables:
     """Device-side segment / chunk tables for one FlatParams and one (lr, wd, max_norm, active) assignment."""
 
@@ -96,7 +105,7 @@ class _Tables:
         self.coef = torch.ones(2, device=dev)
         self.scalars = torch.zeros(2 * nseg, device=dev)
         self.key = tuple(sorted(seg_cfg.items()))
-        self.owned_id = id(owned)
+        self.owned_id = getattr(fl, "partition_version", 0)     # bumped by every enable_data_parallel(): id(list) can be recycled
 
 
 def _stream():
@@ -201,7 +210,7 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, deferred=True):
         apply_pending_clip(fl)
     cfg = _active_cfg(fl, [(p, (0.0, 0.0, 0.0)) for p in params])
     key = tuple(sorted(cfg))
-    ckey = key + (id(getattr(fl, "owned", None)),)
+    ckey = key + (getattr(fl, "partition_version", 0),)
     tb = fl._clip[1] if (fl._clip is not None and fl._clip[0] == ckey) else None
     if tb is None:
         tb = _Tables(fl, cfg)
@@ -451,7 +460,7 @@ class BertAdam(Optimizer):
                 pw.append((p, (group['lr'], group['weight_decay'], group['max_grad_norm'])))
         cfg = _active_cfg(fl, pw)
         key = tuple(sorted(cfg.items()))
-        if self._tb is None or self._tb.key != key or self._tb.owned_id != id(getattr(fl, "owned", None)):
+        if self._tb is None or self._tb.key != key or self._tb.owned_id != getattr(fl, "partition_version", 0):
             self._tb = _Tables(fl, cfg)
         tb = self._tb
         pend = getattr(fl, "_pending", None)
