@@ -44,8 +44,10 @@ def get_args():
     ap.add_argument("--batch", type=int, default=4, help="pairs per GPU per step (configs[1]: bs=4)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="BertAdam as the last kernels of its own step instead of riding with the next forward (graphed.GraphedTrainStep)")
     ap.add_argument("--pipeline", action="store_true",
-                    help="overlap BertAdam of step t with the forward of step t+1 (univl_amd.graphed; measured slower, off by default)")
+                    help="force the pipelined optimizer (default already on for one bf16 process: the update rides with the next forward)")
     ap.add_argument("--host-inputs", action="store_true",
                     help="time the MAIN loop with the batch handed over as pageable HOST tensors every step")
     ap.add_argument("--loopback", action="store_true",
@@ -269,7 +271,9 @@ def main():
     gstep, mode = None, ("per-plan graphs (UniVL._run_plan)" if model.auto_graph else "eager")
     if not args.no_graph:
         from univl_amd.graphed import GraphedTrainStep
-        gstep = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=0, pipeline_optimizer=args.pipeline,
+        # one process, bf16: the BertAdam update of iteration t rides with the forward of iteration t + 1 (default; --no-pipeline)
+        pipe = args.pipeline or (not args.no_pipeline and model._reducer is None and args.dtype == "bf16")
+        gstep = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=0, pipeline_optimizer=pipe,
                                  persistent_inputs=True)     # the bench contract: the batch is resident in HBM, refilled in place
         ok = 1
         try:
@@ -310,6 +314,9 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             last = one_step(src)
+        if gstep is not None:
+            gstep.flush()            # a riding optimizer update is still pending: it belongs to the timed steps (conservative: the region
+                                     # then holds steps + 1 updates, the first one left over by the warm-up)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -404,9 +411,34 @@ def main():
         stp = [v for v in model._steps.values() if hasattr(v, "exchange_points")]
         if stp:
             pts = stp[0].exchange_points
+            red = model._reducer
             exchange = dict(points=len(pts), dense_mb=round(sum(e - s for c in pts for s, e in c) * 4 / 2 ** 20, 1),
                             sparse_word_embedding=getattr(stp[0], "sparse_exchange", None),
-                            backend="loopback" if model._reducer.loopback else "rccl")
+                            backend="loopback" if red.loopback else "rccl",
+                            captured_in_step_graph=bool(red.capturable and gstep is not None and gstep.mode == "whole"))
+            if red.capturable:
+                # Where the step's time goes once gradients cross xGMI: a few EAGER iterations (events cannot be timed inside a
+                # graph) with HIP events around every collective on the communication stream and around the join that precedes the
+                # clip.  exposed_ms = what the compute stream waits for after its last backward kernel; algbw_gbs = exchanged
+                # bytes / time the collectives themselves took (the all-reduce algorithm bandwidth the ring delivers at this size).
+                try:
+                    from univl_amd.parallel import collect_timings
+                    if gstep is not None:
+                        gstep.flush()
+                    auto, model.auto_graph, model.graph_backward = model.auto_graph, False, False
+                    red.measure = True
+                    for _ in range(5):
+                        float(step_body())
+                    tm = collect_timings(red)
+                    red.measure, model.auto_graph = False, auto
+                    n = max(1, tm["steps"])
+                    exchange.update(exposed_ms=round(tm["exposed_ms"] / n, 4), collective_ms=round(tm["collective_ms"] / n, 4),
+                                    algbw_gbs=round(tm["bytes"] / max(tm["collective_ms"], 1e-9) / 1e6, 1),
+                                    measured_on="5 eager iterations after the timed region (HIP events; eager launches are host-bound, so "
+                                                "the backward these collectives hide behind is LONGER than in the graph replay: exposed_ms "
+                                                "is a lower bound for the replayed step)")
+                except Exception as ex:      # noqa: BLE001
+                    exchange["timing_error"] = "%s: %s" % (type(ex).__name__, ex)
     if rank == 0:
         out = dict(metric="video-text pairs/sec (retrieval finetune, 48x48)", value=round(pairs_per_s, 2), unit="pairs/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
@@ -418,6 +450,7 @@ def main():
                                parallelism="dp%d" % world, hip_graph=gstep is not None,
                                graph_mode=(gstep.mode if gstep is not None else mode),
                                optimizer_pipelined=bool(gstep is not None and gstep.pipeline),
+                               optimizer_riding=bool(gstep is not None and gstep.ride),
                                host_inputs=bool(args.host_inputs), exchange=exchange, params=n_params,
                                last_loss=round(last, 6)),
                    pcie_inclusive=pcie, roofline=roofline, cpu_baseline=cpu_base)

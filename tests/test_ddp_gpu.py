@@ -187,9 +187,10 @@ def test_stock_ddp_wrapper_and_graphed_data_parallel_two_ranks():
 
 # ------------------------------------------------------------------------------------------------ RCCL on one GPU
 def _worker_nccl(port, q):
-    """World-size-1 process group on backend "nccl" (= RCCL): the reducer is forced active, so ReduceOp.AVG,
-    all_gather_into_tensor, the thread-local capture mode and the segmented hipGraphs run against the real library --
-    the branch `bench.py --gpus N` takes (main_task_retrieval.py:23,197-198)."""
+    """World-size-1 process group on backend "nccl" (= RCCL): the reducer is forced active, so every collective of the N > 1 path runs
+    against the real library -- the branch `bench.py --gpus N` takes (main_task_retrieval.py:23,197-198) -- in both forms: through
+    a communicator of our own, captured into the step's hipGraph (default), and through torch's process group (ReduceOp.AVG,
+    all_gather_into_tensor, thread-local capture mode, segmented hipGraphs)."""
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -200,11 +201,13 @@ def _worker_nccl(port, q):
         from univl_amd.graphed import GraphedTrainStep
         out = {}
 
-        def train(dp, graphed):
+        def train(dp, graphed, capture=True):
             model, args, kw = _model_and_batch(0, ROWS)
             if dp:
+                os.environ["UNIVL_DP_CAPTURE"] = "1" if capture else "0"
                 model.enable_data_parallel(force=True)
                 assert model._reducer is not None and model._reducer._avg and model._reducer.world == 1
+                assert model._reducer.capturable == capture
             opt = BertAdam(model.parameters(), lr=1e-4, warmup=-1, t_total=-1, weight_decay=0.01, max_grad_norm=1.0)
             losses = []
             if graphed:
@@ -233,6 +236,8 @@ def _worker_nccl(port, q):
         out["backend"] = dist.get_backend()
         out["eager"] = train(True, False)
         out["graph"] = train(True, True)
+        out["eager_pg"] = train(True, False, capture=False)
+        out["graph_pg"] = train(True, True, capture=False)
         torch.cuda.synchronize()
         dist.destroy_process_group()
         q.put(("ok", out))
@@ -251,13 +256,15 @@ def test_reducer_on_rccl_world_size_one():
     assert status == "ok", out
     assert out["backend"] == "nccl"
     ref = out["ref"]
-    for kind in ("eager", "graph"):
+    for kind in ("eager", "graph", "eager_pg", "graph_pg"):
         r = out[kind]
         assert r["calls"] > 0 and r["bytes"] > 0, kind                 # collectives really went through RCCL
         assert max(abs(a - b) for a, b in zip(r["losses"], ref["losses"])) < 2e-4, (kind, r["losses"], ref["losses"])
         for n in ref["final"]:
             assert float(abs(r["final"][n] - ref["final"][n]).max()) < 5e-5, (kind, n)
-    assert out["graph"]["mode"] == "segmented"
+    # a library-held RCCL communicator (univl_amd.rccl): the exchange is part of the plan and the whole data-parallel iteration is ONE
+    # hipGraph; through torch's process group (UNIVL_DP_CAPTURE=0): captured segments with host-issued collectives between them
+    assert out["graph"]["mode"] == "whole" and out["graph_pg"]["mode"] == "segmented"
 
 
 def _worker_cabi(q):

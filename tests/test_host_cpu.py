@@ -256,3 +256,16 @@ def test_stage_inputs_host_logic_on_cpu():
     assert torch.equal(d_ids, ids.reshape(2, 4).to(torch.int64))
     assert torch.equal(d_vid, vid.reshape(8, 3))
     assert torch.equal(d_mask, torch.ones(2, 4, dtype=torch.int64))
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus 2` without a launcher starts the ranks itself -- and fails loudly (exit code 2, the stated message)
+    when fewer GPUs are visible than asked for; it never runs N ranks on fewer devices."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-400:])
+    assert "--gpus 2 requested but only" in r.stderr

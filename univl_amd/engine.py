@@ -286,7 +286,7 @@ class Plan:
         self.riders = None           # set for the duration of one run: dict(desc=UnivlAdam, ranges={key: (first, count)}, max_blocks=int)
 
     def add_gemm_rider(self, desc, key, slot, nslots, stream=0):
-        """EXPERIMENTAL (UNIVL_ADAM_RIDE): a forward product that, while self.riders names a chunk range for `key`, also carries
+        """A forward product that, while self.riders names a chunk range for `key`, also carries
         the slot-th of nslots parts of that range of a prepared BertAdam update (univl_gemm_rider); otherwise a plain univl_gemm."""
         self.keep.append(desc)
         self.descs[len(self.ops)] = [desc]
@@ -329,11 +329,14 @@ class Plan:
         if ts:
             self.add_callable(lambda: ops.zero_many(ts), stream)
 
-    def add_callable(self, f, stream=0, eager=False):
-        """eager=True marks host-driven work that must never be captured into a hipGraph (RCCL collectives): run()
-        treats it like any callable, run_graphed() replays the captured kernels on either side of it and calls it
-        in between, on the calling stream."""
-        self.ops.append(("eager" if eager else "py", f, None, getattr(f, "__name__", "callable"), stream))
+    def add_callable(self, f, stream=0, eager=False, with_streams=False):
+        """eager=True marks host-driven work that must never be captured into a hipGraph (collectives of torch's process group):
+        run() treats it like any callable, run_graphed() replays the captured kernels on either side of it and calls it
+        in between, on the calling stream.  with_streams=True (capturable): f is called as f(streams) with every stream the plan
+        has enqueued work on so far (the calling stream first) -- a gradient exchange on a communication stream of its own waits for
+        exactly those, without joining them into the main chain."""
+        kind = "eager" if eager else ("pys" if with_streams else "py")
+        self.ops.append((kind, f, None, getattr(f, "__name__", "callable"), stream))
 
     def wait_point(self, key, stream=0):
         """If an event is registered under `key` in self.external when the plan runs, `stream` waits for it; otherwise a
@@ -364,8 +367,9 @@ class Plan:
             self._side[idx] = st
         return st
 
-    def _run_ops(self, ops_, cur):
+    def _run_ops(self, ops_, cur, forked=None):
         handles, events = {}, {}
+        forked = set() if forked is None else set(forked)       # side-stream indices ordered behind `cur` in this run
         for op in ops_:
             kind, a, b, name, sidx = op
             if kind == "call":
@@ -421,6 +425,10 @@ class Plan:
                     if sd.device == cur.device:
                         cur.wait_stream(sd)
                 a()
+            elif kind == "pys":
+                # only the side streams THIS run has forked so far (the last "dep" into a stream orders it behind the calling
+                # stream; under capture a stream that has not joined the capture yet must not be waited for)
+                a([cur] + [self._stream(i, cur) for i in sorted(forked)])
             elif kind == "py":
                 if sidx == 0:
                     a()
@@ -429,6 +437,8 @@ class Plan:
                         a()
             else:
                 self._stream(b, cur).wait_stream(self._stream(a, cur))
+                if b != 0:
+                    forked.add(b)
 
     def run(self, upto=None):
         self._run_ops(self.ops if upto is None else self.ops[:upto], torch.cuda.current_stream())
@@ -475,7 +485,7 @@ class Plan:
                     sides = [self._stream(i, cur) for i in seg[3]]
                     for sd in sides:
                         sd.wait_stream(cur)
-                    self._run_ops(seg[1], cur)
+                    self._run_ops(seg[1], cur, forked=seg[3])
                     for sd in sides:
                         cur.wait_stream(sd)
                 seg[2] = g
@@ -577,11 +587,12 @@ class EncoderStack:
         # and those weight gradients stay in the grouped launch.  UNIVL_WGRAD_RIDE=0: the grouped launch for all of them.
         self.ride = (os.environ.get("UNIVL_WGRAD_RIDE", "1") == "1" and flat.compute_dtype == torch.bfloat16
                      and self.sw is None and self.s_off is None)
-        # EXPERIMENTAL, off: the forward products of layer l can carry the BertAdam chunks of layer l + 1 (Plan.add_gemm_rider)
+        # The forward products of layer l can carry the BertAdam chunks of layer l + 1 (Plan.add_gemm_rider): switched on per model by
+        # graphed.GraphedTrainStep(pipeline_optimizer=True) (flat.adam_ride), or for every model by UNIVL_ADAM_RIDE=1.
         # Only the text / video stacks: all their passes of one forward run one after the other on the stack's own stream, so a
         # layer's update (carried by the FIRST pass through the layer before it) is complete before anybody reads the layer.
-        self.adam_ride = (os.environ.get("UNIVL_ADAM_RIDE", "0") == "1" and flat.compute_dtype == torch.bfloat16
-                          and prefix in ("bert", "visual"))
+        self.adam_ride = ((getattr(flat, "adam_ride", False) or os.environ.get("UNIVL_ADAM_RIDE", "") == "1")
+                          and flat.compute_dtype == torch.bfloat16 and prefix in ("bert", "visual"))
         self.T = B * S
         self.key_mask = key_mask            # int64 [B,S] device tensor (static buffer)
         self.p = float(p_drop)

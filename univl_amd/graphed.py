@@ -10,7 +10,10 @@ bottleneck (~10 us per ctypes call).  `GraphedTrainStep` captures the iteration 
     the all-reduces issued from the host between the replays (they run on RCCL's own stream and overlap the
     following segments), and clip + BertAdam are a last graph that is replayed after the reducer's join.
 
-Pipelined optimizer (pipeline_optimizer=True; OFF by default -- measured slower on MI355X, see the end of this paragraph).
+Pipelined optimizer (pipeline_optimizer=True).  Two forms: the RIDING form (default where it applies: bf16, one process -- the
+pending update goes out as extra workgroups of the next forward's own GEMM launches, engine.Plan.add_gemm_rider; -8 % per step at 4
+pairs, -10 % at 16, profiles/r03b_ab_adam_ride.txt) and the SIDE-STREAM form described next (fp32 / data parallel / UNIVL_ADAM_RIDE=0;
+measured slower than no pipelining on MI355X, see the end of this paragraph).
 At small per-GPU batch the forward/backward is a chain of
 short latency-bound kernels that leaves most of the HBM bandwidth idle, while the BertAdam update is one long HBM-bound
 stream (30 B per parameter) that needs nothing but bandwidth.  The global clip (main_task_retrieval.py:347) needs every
@@ -60,9 +63,17 @@ class GraphedTrainStep:
         self.pipeline = bool(pipeline_optimizer) or os.environ.get("UNIVL_PIPELINE_OPT", "0") == "1"
         self.adam_blocks = int(os.environ.get("UNIVL_ADAM_BLOCKS", "0"))      # grid cap of the overlapped update (0: none)
         self.async_loss = bool(async_loss) or os.environ.get("UNIVL_ASYNC_LOSS", "0") == "1"
-        # EXPERIMENTAL: the pending update goes out as extra workgroups of the next forward's own launches (engine.Plan.add_gemm_rider)
-        # instead of a second stream with one graph edge per layer
-        self.ride = self.pipeline and os.environ.get("UNIVL_ADAM_RIDE", "0") == "1"
+        # The pending update goes out as extra workgroups of the next forward's own launches (engine.Plan.add_gemm_rider) instead of a
+        # second stream with one graph edge per layer: bf16, one process (the update of a data-parallel step stays sequential until the
+        # riding form has been run on more than one GPU).  UNIVL_ADAM_RIDE=0: the side-stream form.  Measured on one MI355X
+        # (profiles/r03b_ab_adam_ride.txt): 2.53 vs 2.74 ms per step at 4 pairs, 3.79 vs 4.23 at 16; bit-identical parameters
+        # (tests/test_model_gpu.py::test_adam_update_riding_with_the_next_forward_matches_eager).
+        fl = model.flat
+        self.ride = (self.pipeline and os.environ.get("UNIVL_ADAM_RIDE", "1") != "0" and fl.compute_dtype == torch.bfloat16
+                     and getattr(model, "_reducer", None) is None and getattr(fl, "shard_reducer", None) is None)
+        if self.ride and not getattr(fl, "adam_ride", False):
+            fl.adam_ride = True
+            model._steps = {}            # the forward plans are rebuilt with rider slots (engine.EncoderStack.build_forward)
         self._copy_stream = self._loss_host = self._loss_ev = None
         self._g_rest = None
         self.params = [p for p in model.parameters()]
@@ -206,7 +217,9 @@ class GraphedTrainStep:
                 import ctypes as C
                 from . import _lib
                 _lib.check(_lib.lib().univl_gemm_rider_prime(C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm_rider_prime")
-            if getattr(self.model, "_reducer", None) is None and self.async_loss:
+            red0 = getattr(self.model, "_reducer", None)
+            one_graph = red0 is None or red0.capturable      # no exchange, or an exchange that is part of the plan (univl_amd.rccl)
+            if one_graph and self.async_loss:
                 # two graphs from one memory pool: forward | backward + clip + BertAdam
                 self._g_fwd, self._g_rest = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with no_gc(), torch.cuda.graph(self._g_fwd):
@@ -218,9 +231,9 @@ class GraphedTrainStep:
                         self.model._pending_update = self.opt
                     self.opt.zero_grad()
                 self.mode = "whole"
-            elif getattr(self.model, "_reducer", None) is None:
+            elif one_graph:
                 self._g_all = torch.cuda.CUDAGraph()
-                with no_gc(), torch.cuda.graph(self._g_all):
+                with no_gc(), torch.cuda.graph(self._g_all, capture_error_mode="thread_local"):
                     if self.pipeline:
                         self.loss = self._forward_pipelined(sa, sk)
                         self.loss.backward()

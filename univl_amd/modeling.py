@@ -564,6 +564,15 @@ class UniVL(UniVLPreTrainedModel):
         self._reducer = BucketReducer(fl.g32, process_group, loopback=loopback, force=force)
         if not self._reducer.active:
             self._reducer = None
+        elif os.environ.get("UNIVL_DP_CAPTURE", "1") != "0" and not loopback and fl.device.type == "cuda":
+            # RCCL: a communicator of our own, so that the exchange is captured into the step's hipGraph (univl_amd.rccl)
+            try:
+                with torch.cuda.device(fl.device):
+                    self._reducer.enable_capture()
+            except Exception as ex:      # noqa: BLE001 -- the process-group path below does the same exchange from the host
+                import sys
+                print("[univl_amd] RCCL communicator for captured gradient exchange unavailable (%s: %s); using torch.distributed "
+                      "collectives between captured segments" % (type(ex).__name__, ex), file=sys.stderr)
         fl.owned, fl.shard_reducer, fl.master_complete = None, None, True
         fl.partition_version = getattr(fl, "partition_version", 0) + 1      # chunk-table caches of the optimizer are keyed on it
         if shard_optimizer is None:

@@ -45,12 +45,44 @@ class BucketReducer:
         backend = dist.get_backend(process_group) if (dist.is_initialized() and not loopback) else "none"
         self._avg = backend == "nccl"
         self._comm = None
+        # enable_capture(): collectives go through a library-held RCCL communicator on a stream of ours (univl_amd.rccl) -- plain
+        # kernel enqueues that a hipGraph capture records like any other node -- instead of torch's ProcessGroupNCCL
+        self.rccl = None
+        self.capturable = False
+        self._cstream = None
+        self._inflight = False
+        # measure=True (bench.py, eager iterations only -- events cannot be timed inside a graph): HIP events around every
+        # collective on the communication stream and around the join on the compute stream
+        # UNIVL_DP_DRYRUN=1 (measurement only, bench.py --force-dp on one GPU): every stream fork / join, exchange point and
+        # bookkeeping of the data-parallel schedule, but the collective itself is not enqueued -- separates what the SCHEDULE costs
+        # from what RCCL's kernels cost (at world size 1 they still stream every bucket through HBM)
+        self.dryrun = os.environ.get("UNIVL_DP_DRYRUN", "0") == "1"
+        self.measure = False
+        self.timings = dict(collective_ms=0.0, exposed_ms=0.0, bytes=0, steps=0)
+        self._ev = []
+
+    def enable_capture(self):
+        """RCCL backend only.  Collective over the group (creates the communicator)."""
+        from .rccl import RcclComm
+        if not self._avg or self.loopback or self.bf16 or self.partition is not None:
+            return False
+        self.rccl = RcclComm(self.pg)
+        self._cstream = torch.cuda.Stream()
+        self.capturable = True
+        return True
+
+    def _fork(self, after=None):
+        """The communication stream picks up behind everything enqueued so far on the current stream (and on the streams in
+        `after`: the plan's side streams -- the video stack's weight gradients are produced there)."""
+        for st in (after or [torch.cuda.current_stream()]):
+            self._cstream.wait_stream(st)
+        self._inflight = True
 
     @property
     def active(self):
         return self.world > 1 or self.loopback or (self.force and dist.is_initialized())
 
-    def reduce_slice(self, start, end):
+    def reduce_slice(self, start, end, after=None):
         """Launch the all-reduce of g[start:end]; returns immediately (the collective is stream-/thread-async)."""
         if not self.active or end <= start:
             return
@@ -69,6 +101,18 @@ class BucketReducer:
                     ev.record()
                 self.pending.append((ev, t, None))
             return
+        if self.capturable:
+            self._fork(after)
+            timed = self.measure and not torch.cuda.is_current_stream_capturing()
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self._cstream)
+            if not self.dryrun:
+                self.rccl.all_reduce(t, True, self._cstream)
+            if timed:
+                e1.record(self._cstream)
+                self._ev.append(("c", e0, e1, t.numel() * t.element_size()))
+            return
         if self.bf16:
             if self._g16 is None:
                 self._g16 = torch.empty_like(self.g, dtype=torch.bfloat16)
@@ -83,7 +127,7 @@ class BucketReducer:
             w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self.pending.append((w, t, None))
 
-    def gather(self, t, out):
+    def gather(self, t, out, after=None):
         """out[r] <- rank r's t (all-gather), asynchronously like reduce_slice; out: [world, *t.shape]."""
         self.calls += 1
         self.bytes_reduced += out.numel() * out.element_size()
@@ -97,17 +141,25 @@ class BucketReducer:
                 ev.record()
             self.pending.append((ev, None, None))
             return
+        if self.capturable:
+            self._fork(after)
+            if not self.dryrun:
+                self.rccl.all_gather(t, out, self._cstream)
+            else:
+                with torch.cuda.stream(self._cstream):
+                    out[self.rank].copy_(t)
+            return
         if self._avg:          # RCCL: one contiguous output, no per-rank staging copies
             w = dist.all_gather_into_tensor(out.view(-1, *t.shape[1:]), t, group=self.pg, async_op=True)
         else:
             w = dist.all_gather([out[r] for r in range(self.world)], t, group=self.pg, async_op=True)
         self.pending.append((w, None, None))
 
-    def reduce_ranges(self, ranges):
+    def reduce_ranges(self, ranges, after=None):
         if self.partition is not None:
             return self.reduce_scatter_ranges(ranges)
         for s0, e0 in ranges:
-            self.reduce_slice(s0, e0)
+            self.reduce_slice(s0, e0, after)
 
     # ------------------------------------------------------------------------------- sharded optimizer (ZeRO-1 style)
     # With `partition` set (shard_partition below) every exchanged range is REDUCE-SCATTERED instead of all-reduced: rank r
@@ -116,6 +168,8 @@ class BucketReducer:
     # ALL-GATHERED.  Bytes over xGMI per step: (W-1)/W x (4 + 2) B/param instead of 2 (W-1)/W x 4 B/param for the
     # all-reduce, and the 30 B/param optimizer stream shrinks by the world size.
     def set_partition(self, partition):
+        if partition is not None:
+            self.capturable = False          # the sharded path issues host-synchronous collectives (norm all-reduce): segmented graphs
         self.partition = list(partition) if partition is not None else None
         self.owned = owned_ranges(self.partition, self.world, self.rank) if partition is not None else None
 
@@ -170,6 +224,17 @@ class BucketReducer:
 
     def join(self):
         """Make the current stream (or thread, for gloo) wait for every outstanding bucket."""
+        if self._inflight:
+            cur = torch.cuda.current_stream()
+            timed = self.measure and not torch.cuda.is_current_stream_capturing()
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+            cur.wait_stream(self._cstream)
+            if timed:
+                e1.record(cur)
+                self._ev.append(("j", e0, e1, 0))
+            self._inflight = False
         for w, t, t16 in self.pending:
             if self.loopback:
                 torch.cuda.current_stream().wait_event(w)
@@ -180,6 +245,21 @@ class BucketReducer:
             if not self._avg and t is not None:
                 t.div_(self.world)
         self.pending = []
+
+
+def collect_timings(red):
+    """Fold the events of BucketReducer(measure=True) into red.timings (synchronises the device)."""
+    torch.cuda.synchronize()
+    for kind, e0, e1, nbytes in red._ev:
+        ms = e0.elapsed_time(e1)
+        if kind == "c":
+            red.timings["collective_ms"] += ms
+            red.timings["bytes"] += nbytes
+        else:
+            red.timings["exposed_ms"] += ms
+            red.timings["steps"] += 1
+    red._ev = []
+    return red.timings
 
 
 def merge_ranges(ranges):

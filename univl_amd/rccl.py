@@ -76,7 +76,7 @@ class RcclComm:
         uid = _Uid()
         if self.rank == 0:
             _check(G.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        box = [bytes(uid.internal) if self.rank == 0 else None]
+        box = [C.string_at(C.byref(uid), 128) if self.rank == 0 else None]      # all 128 bytes (a c_char array field reads as a C string)
         if self.world > 1:
             dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
                                        group=process_group)

@@ -616,7 +616,12 @@ def _ddp_hook(cx, fl, model, kind):
     def emit(plan):
         ranges = sched.take()
         if ranges:
-            plan.add_callable(lambda: red.reduce_ranges(ranges), eager=True)
+            # host-issued between captured segments (torch's process group), or -- with a library-held RCCL communicator
+            # (parallel.BucketReducer.enable_capture) -- an ordinary, capturable part of the plan
+            if red.capturable:
+                plan.add_callable(lambda streams: red.reduce_ranges(ranges, after=streams), with_streams=True)
+            else:
+                plan.add_callable(lambda: red.reduce_ranges(ranges), eager=True)
 
     def hook(plan, prefix, l, stream):
         key = (prefix, l)
@@ -765,11 +770,15 @@ def build_step(model, kind, B, W, F, training):
                 def gather_tokens():
                     red.gather(enc.ids.view(-1), ids_all)
                     red.gather(enc.drows, rows_all)
-                bwd.add_callable(gather_tokens, eager=True)
+                if red.capturable:
+                    bwd.add_callable(lambda streams: (red.gather(enc.ids.view(-1), ids_all, after=streams),
+                                                      red.gather(enc.drows, rows_all)), with_streams=True)
+                else:
+                    bwd.add_callable(gather_tokens, eager=True)
             for (s0, e0) in tail:
                 sched[0].add(s0, e0)
             sched[1](bwd)                                  # whatever is still pending + the tail
-            bwd.add_callable(red.join, eager=True)
+            bwd.add_callable(red.join, eager=not red.capturable)
             if sparse:                                     # rebuild the dense table gradient: mean over ranks
                 bwd.add_callable(lambda: ops.embed_scatter(ids_all.view(-1), rows_all.view(-1, H), 1.0 / world, fl.g(wname)))
                 if rows_mode:
