@@ -119,7 +119,12 @@ def cpu_baseline(batch_rows, budget_s=20.0):
         times.append(time.time() - t0)
     times.sort()
     med = times[len(times) // 2]
-    out = dict(value=round(batch_rows / med, 3), unit="pairs/s", cores=best, kind="port",
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False)
+    except Exception:   # noqa: BLE001
+        phys = None
+    out = dict(value=round(batch_rows / med, 3), unit="pairs/s", cores=best, host_logical_cpus=host, host_physical_cores=phys, kind="port",
                sample="%d full training steps (fwd+bwd+clip+BertAdam, bs=%d, 48x48, 12+6 layers, fp32, dropout 0.1) "
                       "of oracle/cpu_step.py on %d OpenMP threads (best of 8/16/32/64; host has %d logical CPUs), "
                       "median step %.3f s" % (len(times), batch_rows, best, host, med))
@@ -272,7 +277,7 @@ def main():
     if not args.no_graph:
         from univl_amd.graphed import GraphedTrainStep
         # one process, bf16: the BertAdam update of iteration t rides with the forward of iteration t + 1 (default; --no-pipeline)
-        pipe = args.pipeline or (not args.no_pipeline and model._reducer is None and args.dtype == "bf16")
+        pipe = args.pipeline or (not args.no_pipeline and args.dtype == "bf16" and model._reducer is None)
         gstep = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=0, pipeline_optimizer=pipe,
                                  persistent_inputs=True)     # the bench contract: the batch is resident in HBM, refilled in place
         ok = 1
@@ -370,14 +375,23 @@ def main():
         fam_s = fam["family_ms_per_step"] * 1e-3
         hbm_frac = fam["algorithmic_bytes_per_step"] / fam_s / 8.0e12
         mfma_frac = fam["flops_per_step"] / fam_s / 2.5e15
-        traffic = None
-        for cand in ("r02_gemm_pmc.json",):
-            pmc = os.path.join(ROOT, "profiles", cand)
-            if os.path.exists(pmc) and args.batch == 4:
-                try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                except Exception:   # noqa: BLE001
-                    traffic = None
+        # HBM bytes per launch / per step from the PMC passes (FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes of
+        # scripts/pmc_step.py, both calibrated on cast_kernel's exactly known traffic) -- only while the file was produced by THESE
+        # kernel sources (stamp written by scripts/pmc_step_parse.py) and for this batch; otherwise null, never a stale constant
+        traffic = traffic_step = None
+        pmc = os.path.join(ROOT, "profiles", "r03_gemm_pmc.json")
+        if os.path.exists(pmc) and args.batch == 4:
+            try:
+                import hashlib
+                hs = hashlib.sha256()
+                for name in ("gemm.hip", "common.h"):
+                    hs.update(open(os.path.join(ROOT, "univl_amd", "csrc", name), "rb").read())
+                pj = json.load(open(pmc))
+                if pj.get("kernel_source_sha16") == hs.hexdigest()[:16]:
+                    traffic_step = pj["gemm"]["hbm_read_bytes_per_step"] + pj["gemm"]["hbm_write_bytes_per_step"]
+                    traffic = traffic_step / fam["launches"]
+            except Exception:   # noqa: BLE001
+                traffic = traffic_step = None
         step_bytes = int((8 + bpp) * n_params + 1.0e8)
         roofline = dict(
             kernel="gemm_kernel / gemm_pair_kernel / gemm_group_kernel family (univl_amd/csrc/gemm.hip): every dense contraction of one step",
@@ -385,7 +399,7 @@ def main():
             achieved=round(fam["algorithmic_bytes_per_step"] / fam_s / 1e9, 1) if hbm_frac >= mfma_frac
             else round(fam["flops_per_step"] / fam_s / 1e12, 1),
             peak=8000.0 if hbm_frac >= mfma_frac else 2500.0, unit="GB/s" if hbm_frac >= mfma_frac else "TFLOP/s",
-            frac=round(max(hbm_frac, mfma_frac), 4), traffic=traffic,
+            frac=round(max(hbm_frac, mfma_frac), 4), traffic=traffic, traffic_per_step=traffic_step,
             hbm=dict(achieved_gbs=round(fam["algorithmic_bytes_per_step"] / fam_s / 1e9, 1), frac=round(hbm_frac, 4)),
             mfma=dict(achieved_tflops=round(fam["flops_per_step"] / fam_s / 1e12, 2), frac=round(mfma_frac, 4)),
             launches_per_step=fam["launches"], gemms_per_step=fam["gemms"], family_ms_per_step=fam["family_ms_per_step"],

@@ -229,9 +229,11 @@ int univl_embed_text_bwd(const UnivlEmbedText* d, hipStream_t stream);
  * last clear; meta[1] != 0 means "treat every row as listed" (list overflow, or a dense writer).  univl_rows_zero clears
  * the listed rows (instead of a 94 MB memset), univl_rows_append records the rows of a backward (reset != 0 starts a new
  * list), univl_rows_sumsq adds the sum of squares of the listed rows (each row once) to *out (instead of streaming the
- * whole table for its gradient norm).  cap <= 8192. */
+ * whole table for its gradient norm).  cap <= 8192.  `ever` (optional, [rows_total] bytes): sticky "this row has been written at
+ * least once" flags for UnivlAdam.row_flags -- univl_rows_append sets the flag of every id it is given (all flags on overflow). */
 int univl_rows_zero(float* table, int64_t rows_total, const int64_t* list, const int32_t* meta, hipStream_t stream);
-int univl_rows_append(const int64_t* ids, int32_t n, int64_t* list, int32_t cap, int32_t* meta, int32_t reset, hipStream_t stream);
+int univl_rows_append(const int64_t* ids, int32_t n, int64_t* list, int32_t cap, int32_t* meta, int32_t reset, uint8_t* ever,
+                      int64_t rows_total, hipStream_t stream);
 int univl_rows_sumsq(const float* table, int64_t rows_total, const int64_t* list, const int32_t* meta, float* out, hipStream_t stream);
 /* dword[ids[t]] += scale * rows[t] for t < n (fp32 atomics; rows [n, 768]): the second half of the sparse exchange */
 int univl_embed_scatter(const int64_t* ids, const float* rows, int64_t n, float scale, float* dword, hipStream_t stream);
@@ -347,6 +349,13 @@ typedef struct UnivlAdam {
     float warmup; int32_t t_total;   /* warmup_linear schedule (optimization.py:38-43), t_total -1: constant */
     float* seg_scalars;          /* scratch [nseg*2]                                                       */
     int32_t schedule;            /* 0 warmup_linear, 1 warmup_cosine, 2 warmup_constant (optimization.py:26-50) */
+    /* Optional "rows nobody ever touched" shortcut for ONE row-structured tensor (the 30522 x 768 word table: at most B*W of its
+     * rows receive a gradient per step, 15 % of all parameters).  row_flags[r] != 0 <=> row r of segment flag_seg has ever held a
+     * non-zero gradient, moment or second moment (kept by univl_rows_append; the host sets every flag where it cannot know).  A
+     * chunk of that segment whose rows are all unflagged has g = m = v = 0 exactly, so its BertAdam update is p -= lr * (wd * p)
+     * -- the same bits the full formula gives (0 / (sqrt(0) + e) = 0) at 10 instead of 30 bytes per parameter.  The segment's
+     * chunks must start on row boundaries.  NULL: off. */
+    const uint8_t* row_flags; int32_t flag_seg; int32_t row_len;
 } UnivlAdam;
 int univl_bert_adam(const UnivlAdam* d, hipStream_t stream);
 /* The same update over chunks [chunk_begin, chunk_begin + chunk_count) of the chunk table only; do_prep != 0 first runs the

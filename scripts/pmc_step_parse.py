@@ -66,6 +66,13 @@ def main(fetch_dir, write_dir, mfma_dir, elements, steps, out):
             if n["gemm"]:
                 m[c] = dict(gemm_per_step=t["gemm"] / steps, all_kernels_per_step=sum(t.values()) / steps)
         res["mfma_counters"] = m
+    # stamp: the kernel sources these counters belong to -- bench.py reports roofline.traffic from this file only while they match
+    import hashlib, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for name in ("gemm.hip", "common.h"):
+        h.update(open(os.path.join(root, "univl_amd", "csrc", name), "rb").read())
+    res["kernel_source_sha16"] = h.hexdigest()[:16]
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

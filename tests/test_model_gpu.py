@@ -820,3 +820,42 @@ def test_adam_update_riding_with_the_next_forward_matches_eager(case, monkeypatc
     assert l == ref_l, (l, ref_l)
     for n in ref_p:
         assert torch.equal(p[n], ref_p[n]), (n, max_abs(p[n], ref_p[n]))
+
+
+def test_lazy_word_rows_update_is_bit_identical(monkeypatch):
+    """UnivlAdam.row_flags (UNIVL_ADAM_LAZY_ROWS, default on): chunks of word-table rows that never held a gradient take the
+    weight-decay-only form of the BertAdam update (10 instead of 30 bytes per parameter).  Same bits as the full update, over
+    changing batches (the set of touched rows grows), gradient accumulation and a foreign write to the table's gradient."""
+    cfg, rows, dseed = case_config("joint_small")
+    batches = [O.synthetic_batch(cfg, rows, seed=dseed + k) for k in range(4)]
+    wname = "bert.embeddings.word_embeddings.weight"
+
+    def run(lazy):
+        monkeypatch.setenv("UNIVL_ADAM_LAZY_ROWS", "1" if lazy else "0")
+        model, _ = build(cfg, torch.bfloat16)
+        model.train()
+        opt = BertAdam(model.parameters(), lr=1e-3, warmup=-1, t_total=-1, weight_decay=0.01, max_grad_norm=1.0)
+        flagged = []
+        for k, b in enumerate(batches):
+            call(model, b).backward()
+            if k == 1:
+                call(model, batches[0]).backward()
+            if k == 3:
+                dict(model.named_parameters())[wname].grad[123].add_(1.0)
+            clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+            opt.zero_grad()
+            fl = model.flat
+            flagged.append(None if fl.word_ever is None else int(fl.word_ever.sum()))
+        fl = model.flat
+        return fl.w32(wname).detach().clone(), fl.wop(wname).detach().clone(), opt.state[dict(model.named_parameters())[wname]]["next_v"].clone(), flagged
+
+    w1, s1, v1, f1 = run(True)
+    w0, s0, v0, f0 = run(False)
+    assert f0 == [None] * 4
+    tokens = [int(torch.unique(b["input_ids"]).numel()) for b in batches]
+    assert f1[0] == tokens[0] and f1[0] <= f1[1] <= f1[2] < cfg.vocab_size      # only the touched rows are flagged ...
+    assert f1[3] == cfg.vocab_size                                               # ... until somebody edits the gradient behind our back
+    assert torch.equal(w1, w0) and torch.equal(s1, s0) and torch.equal(v1, v0)
+    untouched = (v1.abs().sum(1) == 0)
+    assert int(untouched.sum()) > cfg.vocab_size // 2                            # most rows took the shortcut at least until step 3

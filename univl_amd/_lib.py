@@ -59,7 +59,7 @@ class Adam(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("p16", vp), ("segs", vp), ("nseg", i32),
                 ("chunk_seg", vp), ("chunk_off", vp), ("chunk_len", vp), ("nchunk", i32), ("sumsq", vp),
                 ("coef", vp), ("step", vp), ("b1", f32), ("b2", f32), ("eps", f32), ("warmup", f32),
-                ("t_total", i32), ("seg_scalars", vp), ("schedule", i32)]
+                ("t_total", i32), ("seg_scalars", vp), ("schedule", i32), ("row_flags", vp), ("flag_seg", i32), ("row_len", i32)]
 
 
 _STRUCTS = [Gemm, LayerNorm, Attention, EmbedText, Pool, Seg, Adam]
@@ -99,7 +99,7 @@ def lib():
     L.univl_gemm_tile_map.argtypes = [i32, i32, i32, i32, i32, C.POINTER(i32)]
     L.univl_embed_scatter.argtypes = [vp, vp, i64, f32, vp, vp]
     L.univl_rows_zero.argtypes = [vp, i64, vp, vp, vp]
-    L.univl_rows_append.argtypes = [vp, i32, vp, i32, vp, i32, vp]
+    L.univl_rows_append.argtypes = [vp, i32, vp, i32, vp, i32, vp, i64, vp]
     L.univl_rows_sumsq.argtypes = [vp, i64, vp, vp, vp, vp]
     L.univl_zero_many.argtypes = [vp, vp, i32, vp]
     L.univl_copy_many.argtypes = [vp, vp, vp, i32, vp]

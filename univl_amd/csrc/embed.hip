@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256) void rows_zero_kernel(float* table, long rows_
     }
 }
 
-__global__ __launch_bounds__(256) void rows_append_kernel(const int64_t* ids, int n, int64_t* list, int cap, int* meta, int reset) {
+__global__ __launch_bounds__(256) void rows_append_kernel(const int64_t* ids, int n, int64_t* list, int cap, int* meta, int reset,
+                                                          uint8_t* ever, long rows_total) {
     __shared__ int base, over;
     if (threadIdx.x == 0) {
         const int cur = reset ? 0 : meta[0];
@@ -290,6 +291,10 @@ __global__ __launch_bounds__(256) void rows_append_kernel(const int64_t* ids, in
     }
     __syncthreads();
     if (!over) for (int i = threadIdx.x; i < n; i += 256) list[base + i] = ids[i];
+    if (ever) {          // sticky "ever written" flags (UnivlAdam.row_flags); an overflowing list means any row may have been written
+        if (over) for (long r = threadIdx.x; r < rows_total; r += 256) ever[r] = 1;
+        else for (int i = threadIdx.x; i < n; i += 256) ever[ids[i]] = 1;
+    }
 }
 
 __global__ __launch_bounds__(256) void rows_sumsq_kernel(const float* table, long rows_total, const int64_t* list, const int* meta,
@@ -341,10 +346,11 @@ extern "C" int univl_rows_zero(float* table, int64_t rows_total, const int64_t* 
 }
 
 extern "C" int univl_rows_append(const int64_t* ids, int32_t n, int64_t* list, int32_t cap, int32_t* meta, int32_t reset,
-                                 hipStream_t stream) {
+                                 uint8_t* ever, int64_t rows_total, hipStream_t stream) {
     UNIVL_ON_STREAM_DEVICE(stream);
-    UNIVL_CHECK_ARG(ids && list && meta && n > 0 && cap > 0 && cap <= ROWS_GRID, UNIVL_EINVAL, "univl_rows_append: bad argument (cap <= %d)", ROWS_GRID);
-    hipLaunchKernelGGL(rows_append_kernel, dim3(1), dim3(256), 0, stream, ids, n, list, cap, meta, reset);
+    UNIVL_CHECK_ARG(ids && list && meta && n > 0 && cap > 0 && cap <= ROWS_GRID && (!ever || rows_total > 0), UNIVL_EINVAL,
+                    "univl_rows_append: bad argument (cap <= %d)", ROWS_GRID);
+    hipLaunchKernelGGL(rows_append_kernel, dim3(1), dim3(256), 0, stream, ids, n, list, cap, meta, reset, ever, (long)rows_total);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }

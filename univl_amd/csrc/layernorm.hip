@@ -3,6 +3,7 @@
 // float64 -> float32 cast of NormalizeVideo, modeling.py:88-92).  HBM-bound: one wave per row, the row lives in
 // registers (N/64 = 12 or 16 floats per lane), 16-byte coalesced accesses, wave-shuffle reductions, two-pass
 // (mean, then centred variance) exactly as the reference computes it.
+#include <stdlib.h>
 #include "common.h"
 #include "univl_hip.h"
 
@@ -299,7 +300,8 @@ extern "C" int univl_layernorm_bwd(const UnivlLayerNorm* d, hipStream_t stream) 
                     UNIVL_EALIGN, "univl_layernorm_bwd: pointers must be 16-byte aligned");
     // rows per wave: 1 while the grid is small (parallelism first), up to LN_RPW once it fills the chip (fewer
     // column-sum atomics per row)
-    int rpw = d->rows / 2048;
+    static const int rpw_env = [] { const char* e = getenv("UNIVL_LN_RPW"); return e ? atoi(e) : 0; }();     // A/B switch (0: heuristic)
+    int rpw = rpw_env > 0 ? rpw_env : d->rows / 2048;
     rpw = rpw < 1 ? 1 : (rpw > LN_RPW ? LN_RPW : rpw);
     dim3 grid((d->rows + 4 * rpw - 1) / (4 * rpw)), block(256);
     const bool bf = d->dtype == UNIVL_DT_BF16;

@@ -156,6 +156,31 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(UnivlAdam a, int c0, in
     float* p = a.p + off; const float* g = a.g + off; float* m = a.m + off; float* v = a.v + off;
     __bf16* p16 = a.p16 ? reinterpret_cast<__bf16*>(a.p16) + off : nullptr;
     const int nv = ((off & 3) == 0) ? len / 4 : 0;
+    if (a.row_flags != nullptr && seg == a.flag_seg) {
+        // rows nobody ever touched (UnivlAdam.row_flags): g = m = v = 0 exactly, the update is the weight decay alone
+        const long r0 = (off - sg.offset) / a.row_len, r1 = (off - sg.offset + len + a.row_len - 1) / a.row_len;
+        int touched = 0;
+        for (long r = r0 + threadIdx.x; r < r1; r += 256) touched |= a.row_flags[r];
+        if (!__syncthreads_or(touched)) {
+            for (int i = threadIdx.x; i < nv; i += 256) {
+                f32x4_t pp = ld4<NT>(p, i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float upd = wd * pp[e]; pp[e] -= lr * upd; }
+                st4<NT>(p, i, pp);
+                if (p16) {
+                    bf16x4_t w;
+                    w[0] = (__bf16)pp[0]; w[1] = (__bf16)pp[1]; w[2] = (__bf16)pp[2]; w[3] = (__bf16)pp[3];
+                    reinterpret_cast<bf16x4_t*>(p16)[i] = w;
+                }
+            }
+            for (int i = nv * 4 + threadIdx.x; i < len; i += 256) {
+                const float pi = p[i] - lr * (wd * p[i]);
+                p[i] = pi;
+                if (p16) p16[i] = (__bf16)pi;
+            }
+            continue;
+        }
+    }
     auto update = [&](int i, f32x4_t pp, const f32x4_t gg, f32x4_t mm, f32x4_t vv) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

@@ -134,6 +134,15 @@ class FlatParams:
         m_elems = self.total - self.v_end
         self.partials = torch.zeros(m_elems // 1024 + 8 * len(self.order) + 64, device=self.device, dtype=torch.float32)
         self.fused = None            # dict(version=grad_version, names=frozenset) once a backward produced them
+        # Word-table rows that have EVER held a non-zero gradient / moment (uint8 per row, sticky): the fused BertAdam update takes
+        # the weight-decay-only shortcut on chunks of rows that never did (UnivlAdam.row_flags, optim.hip) -- at most B*W of the
+        # 30522 rows are touched per step, the table is 15 % of all parameters.  Valid from here on because g32 (and the moments of
+        # any optimizer created later) start at zero; every event after which a row's g / m / v can be non-zero without having gone
+        # through univl_rows_append marks ALL rows (mark_all_word_rows).
+        self.word_ever = None
+        if self.WORD in self.index and os.environ.get("UNIVL_ADAM_LAZY_ROWS", "1") != "0":
+            self.word_ever = torch.zeros(self.index[self.WORD][2][0], dtype=torch.uint8, device=self.device)
+        self.word_ever_all = False
         self._gviews = {}
         self.name_of = {id(p): n for n, p in self.params.items()}
         FLAT_REGISTRY.add(self)
@@ -155,6 +164,12 @@ class FlatParams:
             self._word_rows = (torch.zeros(self.WORD_ROWS_CAP, dtype=torch.int64, device=self.device), meta)
             self.word_rows_version = -1
         return self._word_rows
+
+    def mark_all_word_rows(self):
+        """Somebody wrote the word table's gradient (or its moments) without listing the rows: no row may take the shortcut."""
+        if self.word_ever is not None and not self.word_ever_all:
+            self.word_ever.fill_(1)
+            self.word_ever_all = True
 
     def v_region_without_word_table(self):
         """Slices of g32 covering the atomic region except the word-embedding table."""
@@ -751,9 +766,16 @@ class EncoderStack:
                                 out32=fl.g(nm["w2"]), ldc=I, accumulate=gs.acc(nm["w2"]), nt_out=self.nt_wgrad, **gs.sumsq_args(nm["w2"], H, I))
             emit(_gemm_desc(dt, s_dxd, H, fl.wop(nm["w2"]), I, T, I, H, trans_b=1, out16=s_du,
                             ldc=I, aux=ws["u"], ldaux=I, gelu="bwd"), w_ffn2)
+            # Bias gradients of the two projections whose upstream gradient no LayerNorm kernel sees (FFN1, QKV): column sums of
+            # du / dqkv, taken by the weight-gradient GEMM from the operand tiles it stages anyway.  UNIVL_DBIAS_COLSUM_MIN = n:
+            # from n tokens on a separate column-sum kernel instead (measured at 6144 tokens, round 3: 13.88 / 13.93 vs 13.92 ms
+            # per step -- the per-thread LDS walk of the column-0 workgroups is not what bounds that product; off).
+            sep_dbias = T >= int(os.environ.get("UNIVL_DBIAS_COLSUM_MIN", "1000000000"))
             w_ffn1 = _gemm_desc(dt, s_du, I, ws["a16"], H, I, H, T, trans_a=1, trans_b=1,
-                                out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=fl.g(nm["b1"]), nt_out=self.nt_wgrad,
-                                **gs.sumsq_args(nm["w1"], I, H))
+                                out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=None if sep_dbias else fl.g(nm["b1"]),
+                                nt_out=self.nt_wgrad, **gs.sumsq_args(nm["w1"], I, H))
+            if sep_dbias:
+                plan.add_callable(lambda _du=s_du, _g=fl.g(nm["b1"]): ops.colsum(_du, _g), sm)
             emit(_gemm_desc(dt, s_du, I, fl.wop(nm["w1"]), H, T, H, I, trans_b=1, out32=da, ldc=H,
                             residual=dz, ldr=H, ksplit=self.ksplit_for(I)), w_ffn1)
             # attention-output LayerNorm / dropout backward (BertSelfOutput, module_bert.py:207-211)
@@ -772,7 +794,10 @@ class EncoderStack:
                 dq=(dqkv, 0), lddq=3 * H, dk=(dqkv, H), lddk=3 * H, dv=(dqkv, 2 * H), lddv=3 * H), sm)
             w_qkv = _gemm_desc(dt, dqkv, 3 * H, xin16, H, 3 * H, H, T, trans_a=1, trans_b=1,
                                out32=fl.g_fused(nm["qkv_w"]), ldc=H, accumulate=gs.acc(nm["qkv_w"][0]),
-                               dbias=fl.g_fused(nm["qkv_b"]), nt_out=self.nt_wgrad, **gs.sumsq_args(nm["qkv_w"], H, H))
+                               dbias=None if sep_dbias else fl.g_fused(nm["qkv_b"]), nt_out=self.nt_wgrad,
+                               **gs.sumsq_args(nm["qkv_w"], H, H))
+            if sep_dbias:
+                plan.add_callable(lambda _d=dqkv, _g=fl.g_fused(nm["qkv_b"]): ops.colsum(_d, _g.view(-1)), sm)
             dx = self.garena[l, 1]
             emit(_gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["qkv_w"]), H, T, H, 3 * H, trans_b=1,
                             out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ksplit_for(3 * H)), w_qkv)

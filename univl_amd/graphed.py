@@ -64,13 +64,17 @@ class GraphedTrainStep:
         self.adam_blocks = int(os.environ.get("UNIVL_ADAM_BLOCKS", "0"))      # grid cap of the overlapped update (0: none)
         self.async_loss = bool(async_loss) or os.environ.get("UNIVL_ASYNC_LOSS", "0") == "1"
         # The pending update goes out as extra workgroups of the next forward's own launches (engine.Plan.add_gemm_rider) instead of a
-        # second stream with one graph edge per layer: bf16, one process (the update of a data-parallel step stays sequential until the
-        # riding form has been run on more than one GPU).  UNIVL_ADAM_RIDE=0: the side-stream form.  Measured on one MI355X
+        # second stream with one graph edge per layer: bf16, one process.  UNIVL_ADAM_RIDE=0: the side-stream form.  Measured on one MI355X
         # (profiles/r03b_ab_adam_ride.txt): 2.53 vs 2.74 ms per step at 4 pairs, 3.79 vs 4.23 at 16; bit-identical parameters
         # (tests/test_model_gpu.py::test_adam_update_riding_with_the_next_forward_matches_eager).
         fl = model.flat
-        self.ride = (self.pipeline and os.environ.get("UNIVL_ADAM_RIDE", "1") != "0" and fl.compute_dtype == torch.bfloat16
-                     and getattr(model, "_reducer", None) is None and getattr(fl, "shard_reducer", None) is None)
+        # Not with a gradient exchange: rider launches and captured RCCL nodes in ONE graph pass the world-size-1 test on a small model
+        # but crash hipGraphLaunch at the benchmark shape (profiles/r03g: segmentation fault inside replay; with the collectives
+        # left out -- UNIVL_DP_DRYRUN=1 -- the same graph runs at 2.61 ms per step): UNIVL_ADAM_RIDE=force tries it anyway.
+        red = getattr(model, "_reducer", None)
+        env = os.environ.get("UNIVL_ADAM_RIDE", "1")
+        self.ride = (self.pipeline and env != "0" and fl.compute_dtype == torch.bfloat16
+                     and (red is None or (env == "force" and red.capturable)) and getattr(fl, "shard_reducer", None) is None)
         if self.ride and not getattr(fl, "adam_ride", False):
             fl.adam_ride = True
             model._steps = {}            # the forward plans are rebuilt with rider slots (engine.EncoderStack.build_forward)

@@ -665,8 +665,10 @@ class UniVL(UniVLPreTrainedModel):
         if fl._pending is not None:          # a deferred clip nobody consumed: it scales the OLD gradients, as torch's did
             from .optimization import apply_pending_clip
             apply_pending_clip(fl)
-        if getattr(fl, "_word_rows", None) is not None and fl.g32._version != getattr(fl, "_g32_tv", fl.g32._version):
-            fl._word_rows[1][1] = 1          # the gradients were edited through torch since the last backward: rows unknown
+        if fl.g32._version != getattr(fl, "_g32_tv", fl.g32._version):
+            fl.mark_all_word_rows()          # the gradients were edited through torch since the last backward: rows unknown
+            if getattr(fl, "_word_rows", None) is not None:
+                fl._word_rows[1][1] = 1
         fl.grad_version += 1
         self._run_plan(st.backward_plan(fresh), st)
         plan = st.backward_plan(fresh)
@@ -675,8 +677,10 @@ class UniVL(UniVLPreTrainedModel):
         fl._g32_tv = fl.g32._version
         if getattr(plan, "rows_mode", False):
             fl.word_rows_version = fl.grad_version            # the row list describes exactly these gradients
-        elif getattr(fl, "_word_rows", None) is not None:
-            fl._word_rows[1][1] = 1                            # a dense writer ran: every row counts as listed from now on
+        else:
+            fl.mark_all_word_rows()                            # a writer that lists no rows (tied heads, token gather above the cap)
+            if getattr(fl, "_word_rows", None) is not None:
+                fl._word_rows[1][1] = 1                        # a dense writer ran: every row counts as listed from now on
         fl.attach_grads(used)
         if gout is not None:
             st.gout.fill_(1.0)

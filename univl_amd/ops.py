@@ -252,8 +252,10 @@ def rows_zero(table, lst, meta):
     _lib.check(_lib.lib().univl_rows_zero(_p(table), table.shape[0], _p(lst), _p(meta), _stream()), "rows_zero")
 
 
-def rows_append(ids, lst, meta, reset):
-    _lib.check(_lib.lib().univl_rows_append(_p(ids), ids.numel(), _p(lst), lst.numel(), _p(meta), int(bool(reset)), _stream()), "rows_append")
+def rows_append(ids, lst, meta, reset, ever=None):
+    """ever: optional uint8 [rows] sticky "row has been written" flags (engine.FlatParams.word_ever)."""
+    _lib.check(_lib.lib().univl_rows_append(_p(ids), ids.numel(), _p(lst), lst.numel(), _p(meta), int(bool(reset)), _p(ever),
+                                            0 if ever is None else ever.numel(), _stream()), "rows_append")
 
 
 def rows_sumsq(table, lst, meta, out):

@@ -89,11 +89,16 @@ class _Tables:
                     if hi > lo:
                         pieces.append((lo, hi))
                     j += 1
+            # the word table's chunks start on row boundaries (10 rows of 768): UnivlAdam.row_flags works on whole rows
+            step = CHUNK
+            if n == fl.WORD and owned is None:
+                row = fl.index[n][2][1]
+                step = max(1, CHUNK // row) * row
             for lo, hi in pieces:
-                for o in range(lo, hi, CHUNK):
+                for o in range(lo, hi, step):
                     c_seg.append(s)
                     c_off.append(o)
-                    c_len.append(min(CHUNK, hi - o))
+                    c_len.append(min(step, hi - o))
         raw = bytes(segs)
         self.segs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self.chunk_seg_host = c_seg
@@ -173,8 +178,10 @@ def _active_cfg(fl, params_with_cfg):
             if gr.data_ptr() != gv.data_ptr():
                 gv.copy_(gr)               # a foreign gradient tensor: bring it into the flat buffer
                 fl.fused = None            # ... whose norm nobody has measured
-                if n == fl.WORD and getattr(fl, "_word_rows", None) is not None:
-                    fl._word_rows[1][1] = 1                 # ... and whose non-zero rows nobody listed
+                if n == fl.WORD:
+                    fl.mark_all_word_rows()                 # ... and whose non-zero rows nobody listed
+                    if getattr(fl, "_word_rows", None) is not None:
+                        fl._word_rows[1][1] = 1
             p.grad = gv
         cfg[n] = (lr, wd, mgn, 1)
     return cfg
@@ -328,6 +335,7 @@ class BertAdam(Optimizer):
                 self._v[o:o + k].copy_(st['next_v'].reshape(-1))
             self._step_dev[fl.seg_of[name]] = int(step)
             self._link(fl, p, name, step)
+            fl.mark_all_word_rows()         # migrated moments: no row of the word table is known to be at m = v = 0 in THIS buffer set
         return fl
 
     def _sync_steps(self):
@@ -367,6 +375,7 @@ class BertAdam(Optimizer):
             self._fl = None                 # force a fresh bind that migrates from the loaded tensors
             self._bind()
             return
+        fl.mark_all_word_rows()             # loaded moments: no row of the word table is known to be at m = v = 0
         for p, st in self.state.items():
             name = fl.name_of.get(id(p))
             if name is None or 'next_m' not in st:
@@ -484,6 +493,13 @@ class BertAdam(Optimizer):
         d.warmup, d.t_total = float(g0['warmup']), int(g0['t_total'])
         d.schedule = _SCHEDULE_CODE[g0['schedule']]
         d.seg_scalars = tb.scalars.data_ptr()
+        if getattr(fl, "word_ever", None) is not None and fl.g32._version != getattr(fl, "_g32_tv", fl.g32._version):
+            fl.mark_all_word_rows()         # the gradients were edited through torch after the backward: any row may hold one now
+        if getattr(fl, "word_ever", None) is not None and getattr(fl, "owned", None) is None and fl.WORD in cfg:
+            # rows of the word table nobody ever touched: weight decay only, 10 instead of 30 bytes per parameter (bit-identical)
+            d.row_flags, d.flag_seg, d.row_len = fl.word_ever.data_ptr(), fl.seg_of[fl.WORD], fl.index[fl.WORD][2][1]
+        else:
+            d.row_flags, d.flag_seg, d.row_len = None, -1, 1
         self._last_desc = d
         if defer:
             self._deferred = True

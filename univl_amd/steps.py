@@ -201,7 +201,7 @@ class EncoderPass:
         rows = getattr(self, "word_rows", None)
         if rows is not None and not sparse:            # remember which table rows this backward wrote (engine.FlatParams.word_rows)
             lst, meta, reset = rows
-            bwd.add_callable(lambda: ops.rows_append(self.ids.view(-1), lst, meta, reset), ST)
+            bwd.add_callable(lambda: ops.rows_append(self.ids.view(-1), lst, meta, reset, cx.fl.word_ever), ST)
 
 
 class SimLoss:
@@ -782,7 +782,7 @@ def build_step(model, kind, B, W, F, training):
             if sparse:                                     # rebuild the dense table gradient: mean over ranks
                 bwd.add_callable(lambda: ops.embed_scatter(ids_all.view(-1), rows_all.view(-1, H), 1.0 / world, fl.g(wname)))
                 if rows_mode:
-                    bwd.add_callable(lambda: ops.rows_append(ids_all.view(-1), lst, meta, fresh))
+                    bwd.add_callable(lambda: ops.rows_append(ids_all.view(-1), lst, meta, fresh, fl.word_ever))
             st.exchange_points = list(sched[0].cuts)
         gs.finish(bwd)
         bwd.fused_names = frozenset(gs.covered)
