@@ -87,6 +87,7 @@ int univl_allreduce_bucket(void* buf, size_t n, int dtype, int average, void* co
 #define UNIVL_GEMM_ATOMIC 8       /* internal: split-K atomics                                             */
 #define UNIVL_GEMM_DBIAS_ATOMIC 16 /* dbias accumulated with atomics (several row tiles share a bias)       */
 #define UNIVL_GEMM_XCD_MAP 64      /* internal: XCD-aware workgroup -> tile map (UNIVL_GEMM_XCD=0 turns it off)              */
+#define UNIVL_GEMM_PROBE_NOSTORE 128 /* internal, measurement only (UNIVL_GEMM_PROBE=1): the epilogue computes but does not store -- bounds what a faster epilogue could buy; results are garbage */
 #define UNIVL_GEMM_NT_OUT 32       /* fp32 output written with non-temporal stores: a weight gradient is read next by the optimizer, a whole backward later */
 typedef struct UnivlGemm {
     int32_t dtype, trans_a, trans_b;

@@ -379,7 +379,11 @@ def test_default_atomic_mode_matches_deterministic(name, dtype):
         num += d * d; den += n * n
         if f32:
             assert d < 2e-4 * n + 1e-6 * gmax, (k, d, n)
-    assert (num / den) ** 0.5 < (1e-4 if f32 else 2e-2), (name, (num / den) ** 0.5)
+    rel = (num / den) ** 0.5
+    print("[atomic vs deterministic %s %s] global relative difference %.3e" % (name, dtype, rel))
+    # bf16: both modes sit ~1e-2 (global) from the fp32 reference with independent rounding patterns; a missing or doubled
+    # contribution in either would show up at O(1)
+    assert rel < (1e-4 if f32 else 4e-2), (name, rel)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -429,6 +429,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (!(vrow[a][r] && vcol[b])) continue;
+                if ((p.flags & UNIVL_GEMM_PROBE_NOSTORE) && ev[b][r] != 12345.678f) continue;      // measurement probe: no stores
                 const long o = orow[a][r] * p.ldc + ocol[b];
                 if (atomic) {
                     unsafeAtomicAdd(p.C32 + o, ev[b][r]);
@@ -779,7 +780,7 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int 
     UNIVL_CHECK_ARG(aligned16(d->A) && aligned16(d->B) && d->lda % epc == 0 && d->ldb % epc == 0, UNIVL_EALIGN,
                     "univl_gemm: operands must be 16-byte aligned with leading dims a multiple of %d (lda=%ld ldb=%ld)",
                     epc, d->lda, d->ldb);
-    const int flags = d->flags;
+    const int flags = d->flags & ~(UNIVL_GEMM_ATOMIC | UNIVL_GEMM_XCD_MAP | UNIVL_GEMM_PROBE_NOSTORE);     // internal bits are the library's
     UNIVL_CHECK_ARG(!((flags & (UNIVL_GEMM_GELU_FWD | UNIVL_GEMM_GELU_BWD)) && !d->aux), UNIVL_EINVAL,
                     "univl_gemm: GELU epilogue needs aux");
     // tile choice: 128x128 once the grid fills the chip (>= 256 tiles, measured: +6 % at bs 128 over 384, same at bs 16), else
@@ -804,7 +805,8 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int 
     a.C32 = d->C32; a.C16 = d->C16; a.ldc = d->ldc; a.bias = d->bias; a.R = d->R; a.ldr = d->ldr;
     a.aux = d->aux; a.ldaux = d->ldaux; a.dbias = d->dbias; a.alpha = d->alpha;
     static const int xcd_map = (int)env_long("UNIVL_GEMM_XCD", 1L);
-    a.flags = flags | (ksplit > 1 ? UNIVL_GEMM_ATOMIC : 0) | (xcd_map ? UNIVL_GEMM_XCD_MAP : 0);
+    static const int probe = (int)env_long("UNIVL_GEMM_PROBE", 0L);
+    a.flags = flags | (ksplit > 1 ? UNIVL_GEMM_ATOMIC : 0) | (xcd_map ? UNIVL_GEMM_XCD_MAP : 0) | ((probe & 1) ? UNIVL_GEMM_PROBE_NOSTORE : 0);
     a.ksplit_len = klen;
     a.sumsq = d->sumsq; a.sumsq_rows = d->sumsq_rows; a.sumsq_stride = d->sumsq_stride;
     static const int gm = (int)env_long("UNIVL_GEMM_GM", 8L);
