@@ -738,7 +738,7 @@ struct Choice { int tile, nc, stages, waves; };
 
 static inline long env_long(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
 
-static Choice choose(const UnivlGemm* d, int forced_tile) {
+static Choice choose(const UnivlGemm* d, int forced_tile, int forced_nc = 0) {
     static const long big_min = env_long("UNIVL_GEMM_BIG_MIN", 256L);
     static const long t256_min = env_long("UNIVL_GEMM_T256_MIN", 0L);              // 0: never picked automatically
     static const int stages_dflt = (int)env_long("UNIVL_GEMM_STAGES", 2L);         // tiles 64 / 128
@@ -753,6 +753,11 @@ static Choice choose(const UnivlGemm* d, int forced_tile) {
     if (bf16 && (want == 256 || (want == 0 && c.tile == 128 && t256_min > 0 && tiles256 >= t256_min))) c.tile = 256;
     if (c.tile == 256 && d->sumsq && d->sumsq_rows % 256 != 0) c.tile = 128;     // a tile must not straddle two tensors
     c.nc = c.tile == 64 ? 4 : 2;
+    // forced_nc = 2 (the grouped launch of deep weight-gradient products, univl_gemm_group_limited): 64-deep K steps instead of
+    // 128-deep ones -- half the LDS per workgroup (32 KB), i.e. four workgroups per compute unit instead of two to hide the DMA
+    // waits the stall counters show (profiles/r03z_pmc_stall_b128.txt: 63 % of that kernel's wave cycles are spent parked at the
+    // wait / barrier)
+    if (forced_nc == 2 && c.tile == 64 && bf16) c.nc = 2;
     const int ksplit = (d->ksplit < 1 || univl_deterministic()) ? 1 : d->ksplit;
     // weight gradients at 4 pairs x 48 tokens contract over exactly 192 rows: one 192-deep stage = ONE DMA round trip
     // per workgroup, no partial tile through registers (the 128-deep stage needs a 128-step plus a masked 64-tail)
@@ -768,7 +773,7 @@ static Choice choose(const UnivlGemm* d, int forced_tile) {
     return c;
 }
 
-static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int forced_tile = 0) {
+static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int forced_tile = 0, int forced_nc = 0) {
     UNIVL_CHECK_ARG(d != nullptr, UNIVL_EINVAL, "univl_gemm: null descriptor");
     UNIVL_CHECK_ARG(d->dtype == UNIVL_F32 || d->dtype == UNIVL_BF16, UNIVL_EUNSUPPORTED, "univl_gemm: dtype %d", d->dtype);
     UNIVL_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, UNIVL_EINVAL, "univl_gemm: empty problem %dx%dx%d", d->M, d->N, d->K);
@@ -786,7 +791,7 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int 
     // tile choice: 128x128 once the grid fills the chip (>= 256 tiles, measured: +6 % at bs 128 over 384, same at bs 16), else
     // 64x64 for parallelism.  The small tile stages 4 chunks (128 bf16 / 64 f32) per barrier: at M <= a few hundred the kernel
     // is a latency chain of K steps (DMA -> barrier -> ds_read -> MFMA), so fewer, deeper steps win.
-    c = choose(d, forced_tile);
+    c = choose(d, forced_tile, forced_nc);
     // deterministic mode (common.h): no split-K -- the slices of a split product meet in fp32 atomics whose order is the hardware's;
     // one workgroup per output tile walks the whole contraction in order (the pre-zeroed arena is simply overwritten)
     ksplit = (d->ksplit < 1 || univl_deterministic()) ? 1 : d->ksplit;
@@ -866,6 +871,10 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
         if (burst && d->tile == 0 && !d->trans_a && a.ksplit_len <= 6 * 128 && !d->sumsq) {
             if (!d->trans_b) return launch_burst<__bf16, false, false, 64, 32, 4, 6>(a, ksplit, stream);
             return launch_burst<__bf16, false, true, 32, 64, 4, 6>(a, ksplit, stream);
+        }
+        if (c.nc == 2) {
+            if (c.waves == 8) return dispatch_trans<__bf16, 64, 64, 2, 2, 2, 4>(a, ta, tb, ksplit, stream);
+            return dispatch_trans<__bf16, 64, 64, 2, 2>(a, ta, tb, ksplit, stream);
         }
         if (c.waves == 8) {
             if (c.stages == 3) return dispatch_trans<__bf16, 64, 64, 3, 4, 2, 4>(a, ta, tb, ksplit, stream);
@@ -991,6 +1000,15 @@ extern "C" int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_block
             }
         }
     }
+    // Weight gradients over thousands of tokens on the 64 tile (the members are too small for the 128 tile): 64-deep K steps, four
+    // workgroups per compute unit.  Measured at 128 pairs x 48 tokens (profiles/r03i_ab_summary.txt): 13.55 / 13.49 vs 14.01 / 14.04 ms
+    // per step.  UNIVL_GEMM_NC64_MIN: contraction length from which it applies (0: never).
+    static const long nc64_min = env_long("UNIVL_GEMM_NC64_MIN", 1024L);
+    int forced_nc = 0;
+    if (nc64_min > 0 && tile_all == 64 && d[0].dtype == UNIVL_BF16 && d[0].trans_a && d[0].trans_b) {
+        forced_nc = 2;
+        for (int i = 0; i < n; ++i) if (d[i].K < nc64_min || (d[i].ksplit > 1)) forced_nc = 0;
+    }
     int total = 0, nc_all = 0;
     const int bm = tile_all, bn = tile_all == 256 ? 128 : tile_all;
     for (int i = 0; i < UNIVL_GEMM_GROUP_MAX; ++i) {
@@ -998,7 +1016,7 @@ extern "C" int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_block
         if (i >= n) { g.p[i] = g.p[0]; g.nx[i] = g.nxy[i] = g.nz[i] = 1; continue; }
         int ksplit;
         Choice ci;
-        const int rc = prepare(&d[i], g.p[i], ksplit, ci, tile_all);
+        const int rc = prepare(&d[i], g.p[i], ksplit, ci, tile_all, forced_nc);
         if (rc != UNIVL_OK) return rc;
         UNIVL_CHECK_ARG(ci.tile == tile_all, UNIVL_EINVAL, "univl_gemm_group: member %d cannot run the group's %d tile (sumsq_rows %d)", i, tile_all, d[i].sumsq_rows);
         nc_all = (i == 0) ? ci.nc : (nc_all == ci.nc ? ci.nc : -1);
@@ -1024,6 +1042,7 @@ extern "C" int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_block
         if (tile_all == 128 && w8) { if (D == 3) UNIVL_GROUP_CASE(__bf16, 128, 128, 3, 2, 2, 4); UNIVL_GROUP_CASE(__bf16, 128, 128, 2, 2, 2, 4); }
         if (tile_all == 128) { if (D == 3) UNIVL_GROUP_CASE(__bf16, 128, 128, 3, 2, 2, 2); UNIVL_GROUP_CASE(__bf16, 128, 128, 2, 2, 2, 2); }
         if (nc_all == 6) return launch_group<__bf16, true, true, 64, 64, 2, 6>(g, max_blocks, stream);
+        if (nc_all == 2 && tile_all == 64) { if (w8) UNIVL_GROUP_CASE(__bf16, 64, 64, 2, 2, 2, 4); UNIVL_GROUP_CASE(__bf16, 64, 64, 2, 2, 2, 2); }
         if (w8) { if (D == 3) UNIVL_GROUP_CASE(__bf16, 64, 64, 3, 4, 2, 4); UNIVL_GROUP_CASE(__bf16, 64, 64, 2, 4, 2, 4); }
         if (D == 3) UNIVL_GROUP_CASE(__bf16, 64, 64, 3, 4, 2, 2);
         UNIVL_GROUP_CASE(__bf16, 64, 64, 2, 4, 2, 2);

@@ -68,8 +68,53 @@ class BucketReducer:
             return False
         self.rccl = RcclComm(self.pg)
         self._cstream = torch.cuda.Stream()
+        ok = 1
+        try:
+            self._capture_selftest()
+        except Exception as ex:      # noqa: BLE001 -- an RCCL build that refuses stream capture reports it here, before any training step
+            import sys
+            print("[univl_amd] rank %d: captured RCCL all-reduce self-test failed (%s: %s)" % (self.rank, type(ex).__name__, ex), file=sys.stderr)
+            ok = 0
+        if self.world > 1:           # every rank takes the same path
+            flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+            ok = int(flag)
+        if not ok:
+            self.rccl.destroy()
+            self.rccl, self._cstream = None, None
+            raise RuntimeError("captured RCCL all-reduce self-test failed on at least one rank")
         self.capturable = True
         return True
+
+    def _capture_selftest(self):
+        """A small all-reduce through the new communicator: once eagerly (connection set-up happens outside any capture), once
+        captured into a hipGraph and replayed twice -- on every rank, with the result checked."""
+        s = self._cstream
+        want = float(self.world * (self.world + 1) // 2)
+        x = torch.empty(4096, device="cuda", dtype=torch.float32)
+
+        def check(tag):
+            torch.cuda.synchronize()
+            if not bool((x == want).all()):
+                raise RuntimeError("%s all-reduce returned %r, expected %r" % (tag, float(x[0]), want))
+
+        x.fill_(float(self.rank + 1))
+        s.wait_stream(torch.cuda.current_stream())
+        self.rccl.all_reduce(x, False, s)
+        check("eager")
+        g = torch.cuda.CUDAGraph()
+        src = torch.full_like(x, float(self.rank + 1))
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            cur = torch.cuda.current_stream()
+            x.copy_(src)
+            s.wait_stream(cur)
+            self.rccl.all_reduce(x, False, s)
+            cur.wait_stream(s)
+        for _ in range(2):
+            x.zero_()
+            g.replay()
+            check("captured")
 
     def _fork(self, after=None):
         """The communication stream picks up behind everything enqueued so far on the current stream (and on the streams in
