@@ -639,7 +639,8 @@ class EncoderStack:
                     for _ in range(2 if self.sw is not None else 1 + self.n_off)]
         # split-K for the N=768 products when the grid would not fill the chip: ~3 K-steps of 128 per workgroup
         self.tiles = ((T + 63) // 64) * (H // 64)
-        self.splitk = splitk and self.tiles < 128
+        # UNIVL_SPLITK_TILES: split the contraction of the N = 768 products while the 64 x 64 output grid has fewer tiles than this
+        self.splitk = splitk and self.tiles < int(os.environ.get("UNIVL_SPLITK_TILES", "128"))
         self.ks_h = self.ksplit_for(H) if self.splitk else 1      # >1 <=> the zero-once arenas are needed
 
     def ksplit_for(self, K):
@@ -647,7 +648,8 @@ class EncoderStack:
             return 1
         per = int(os.environ.get("UNIVL_SPLITK_LEN", "384"))
         ks = max(1, (K + per - 1) // per)
-        while ks > 1 and self.tiles * ks > 512:
+        cap = int(os.environ.get("UNIVL_SPLITK_MAXWG", "512"))
+        while ks > 1 and self.tiles * ks > cap:
             ks -= 1
         return ks
 
