@@ -43,6 +43,10 @@ def get_args():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="pairs per GPU per step (configs[1]: bs=4)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--kind", default="joint", choices=["joint", "align", "caption", "pretrain"],
+                    help="which UniVL.forward branch to time.  joint (default, the headline): BASELINE cfg1-3, retrieval FT-Joint 48x48; "
+                         "align: FT-Align (--train_sim_after_cross) 48x48; caption: cfg4, stage two, 128x96, 3 decoder layers (--batch 4); "
+                         "pretrain: cfg5, stage two, five losses, 48x64, n_pair 3 (--batch = rows = videos x 3, use 6)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="BertAdam as the last kernels of its own step instead of riding with the next forward (graphed.GraphedTrainStep)")
@@ -65,13 +69,28 @@ def get_args():
     return ap.parse_args()
 
 
+# per --kind: (max_words, max_frames, task-config overrides, algorithmic fwd+bwd GFLOP per row -- SURVEY section 8d / BASELINE.md section 2,
+# FlopCounterMode on the reference)
+KINDS = {
+    "joint": (48, 48, dict(), 37.30),
+    "align": (48, 48, dict(train_sim_after_cross=True), 70.61),            # at 4 rows: every one of the 16 pairs through the cross encoder
+    "caption": (128, 96, dict(stage_two=True, task_type="caption"), 155.90),
+    "pretrain": (48, 64, dict(stage_two=True, do_pretrain=True, use_mil=True, n_pair=3), 185.33),
+}
+
+
 def task_config(args, world):
-    return argparse.Namespace(
-        max_words=48, max_frames=48, video_dim=1024, batch_size=args.batch * world, n_gpu=world, n_pair=1, margin=0.1,
+    kind = getattr(args, "kind", "joint")
+    W, F, over, _ = KINDS[kind]
+    tc = argparse.Namespace(
+        max_words=W, max_frames=F, video_dim=1024, batch_size=args.batch * world, n_gpu=world, n_pair=1, margin=0.1,
         negative_weighting=1, hard_negative_rate=0.5, use_mil=False, do_pretrain=False, task_type="retrieval",
         stage_two=False, train_sim_after_cross=False, text_num_hidden_layers=12, visual_num_hidden_layers=6,
         cross_num_hidden_layers=2, decoder_num_hidden_layers=3, local_rank=int(os.environ.get("LOCAL_RANK", 0)),
         dropout_prob=args.dropout, compute_dtype=args.dtype, seed=42)
+    for k, v in over.items():
+        setattr(tc, k, v)
+    return tc
 
 
 def make_optimizer(model, BertAdam, lr=3e-5, coef_lr=0.1):
@@ -158,7 +177,7 @@ def gemm_family(model, dev, reps=10):
     """Replays ONLY the GEMM launches of one training step (forward + backward plan of the compiled step), in plan order on
     one stream, as a hipGraph; HIP events around `reps` replays.  Algorithmic work comes from the launch descriptors."""
     from univl_amd import _lib
-    st = next(v for v in model._steps.values() if getattr(v, "kind", None) == "joint" and v.cx.training)
+    st = next(v for v in model._steps.values() if getattr(v, "kind", None) in ("joint", "align", "caption", "pretrain") and v.cx.training)
     items = st.fwd.launches("univl_gemm") + st.backward_plan(True).launches("univl_gemm")
     flops = nbytes = wbytes = 0
     ndesc = 0
@@ -224,7 +243,7 @@ def main():
     torch.cuda.set_device(dev)
 
     cpu_base = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.kind == "joint":
         cpu_base = cpu_baseline(args.batch)
 
     from univl_amd import _lib as _ulib
@@ -241,9 +260,10 @@ def main():
     elif args.loopback:
         model.enable_data_parallel(loopback=True)
     opt = make_optimizer(model, BertAdam)
-    n_params = sum(p.numel() for n, p in model.named_parameters() if ".pooler." not in n)
+    used = set(model.used_parameter_names(model.step_kind(args.kind in ("caption", "pretrain"))))      # parameters that receive a gradient
+    n_params = sum(p.numel() for n, p in model.named_parameters() if n in used)
 
-    B, W, F = args.batch, 48, 48
+    B, (W, F, _, gflop_row) = args.batch, KINDS[args.kind]
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     ids = torch.randint(1000, 30522, (B, 1, W), generator=g)
     ids[..., 0] = 101
@@ -251,13 +271,22 @@ def main():
                        attention_mask=torch.ones(B, 1, W, dtype=torch.int64),
                        video=torch.randn(B, 1, F, 1024, generator=g, dtype=torch.float64),
                        video_mask=torch.ones(B, 1, F, dtype=torch.int64))
+    if args.kind == "pretrain":      # masked-token / masked-frame labels (15 %), as the pretrain loader builds them
+        host_inputs["pairs_token_labels"] = torch.where(torch.rand(B, 1, W, generator=g) < 0.15, ids, torch.full_like(ids, -1))
+        host_inputs["video_labels_index"] = torch.where(torch.rand(B, 1, F, generator=g) < 0.15, torch.zeros(B, 1, F, dtype=torch.int64),
+                                                        torch.full((B, 1, F), -1, dtype=torch.int64))
+    if args.kind in ("caption", "pretrain"):
+        cap = torch.randint(1000, 30522, (B, 1, W), generator=g)
+        host_inputs.update(input_caption_ids=cap, decoder_mask=torch.ones_like(cap), output_caption_ids=cap.clone())
     inputs = {k: v.to(dev) for k, v in host_inputs.items()}
     params = list(model.parameters())
 
     def call_args(src):
-        return ((src["input_ids"], src["token_type_ids"], src["attention_mask"], src["video"], src["video_mask"]),
-                dict(pairs_masked_text=src["input_ids"], pairs_token_labels=None, masked_video=src["video"],
-                     video_labels_index=None))
+        kw = dict(pairs_masked_text=src["input_ids"], pairs_token_labels=src.get("pairs_token_labels"), masked_video=src["video"],
+                  video_labels_index=src.get("video_labels_index"))
+        if "input_caption_ids" in src:
+            kw.update(input_caption_ids=src["input_caption_ids"], decoder_mask=src["decoder_mask"], output_caption_ids=src["output_caption_ids"])
+        return ((src["input_ids"], src["token_type_ids"], src["attention_mask"], src["video"], src["video_mask"]), kw)
 
     def step_body():
         a, kw = call_args(inputs)
@@ -380,7 +409,7 @@ def main():
         # kernel sources (stamp written by scripts/pmc_step_parse.py) and for this batch; otherwise null, never a stale constant
         traffic = traffic_step = None
         pmc = os.path.join(ROOT, "profiles", "r03_gemm_pmc.json")
-        if os.path.exists(pmc) and args.batch == 4:
+        if os.path.exists(pmc) and args.batch == 4 and args.kind == "joint":
             try:
                 import hashlib
                 hs = hashlib.sha256()
@@ -408,8 +437,8 @@ def main():
             how="the step's GEMM launches replayed alone, in plan order on one stream, as a hipGraph; HIP events; includes the "
                 "dependent-launch gaps between them (the rocprofv3 kernel-trace sum under profiles/ excludes them)",
             adam=adam,
-            step=dict(flops_per_pair=37.30e9, achieved_tflops=round(pairs_per_s * 37.30e9 / 1e12 / world, 2),
-                      mfma_frac=round(pairs_per_s * 37.30e9 / world / 2.5e15, 4), hbm_bytes_per_step=step_bytes,
+            step=dict(flops_per_pair=gflop_row * 1e9, achieved_tflops=round(pairs_per_s * gflop_row * 1e9 / 1e12 / world, 2),
+                      mfma_frac=round(pairs_per_s * gflop_row * 1e9 / world / 2.5e15, 4), hbm_bytes_per_step=step_bytes,
                       achieved_gbs=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                       hbm_frac=round(step_bytes / 8.0e12 / (ms_per_step * 1e-3), 4)))
         return roofline
@@ -454,13 +483,20 @@ def main():
                 except Exception as ex:      # noqa: BLE001
                     exchange["timing_error"] = "%s: %s" % (type(ex).__name__, ex)
     if rank == 0:
-        out = dict(metric="video-text pairs/sec (retrieval finetune, 48x48)", value=round(pairs_per_s, 2), unit="pairs/s",
+        names = dict(joint=("video-text pairs/sec (retrieval finetune, 48x48)", "YouCookII-shape retrieval finetune (FT-Joint) training step: BERT-base text "
+                            "encoder (12 L) + 6-layer visual encoder"),
+                     align=("video-text pairs/sec (retrieval finetune FT-Align, 48x48)", "retrieval finetune with --train_sim_after_cross: both "
+                            "encoders + all B^2 (text, video) pairs through the 2-layer cross encoder"),
+                     caption=("video-caption rows/sec (caption finetune stage two, 128x96)", "BASELINE cfg4 shape: both encoders + 2-layer cross "
+                              "encoder + 3-layer decoder + tied 30522-way classifier"),
+                     pretrain=("rows/sec (pretrain stage two, 48x64, five losses)", "BASELINE cfg5 shape: clean + masked encoder passes, cross "
+                               "encoder x3, MLM + MFM heads, decoder, alignment"))[args.kind]
+        out = dict(metric=names[0], value=round(pairs_per_s, 2), unit="pairs/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
-                   config=dict(workload="YouCookII-shape retrieval finetune (FT-Joint) training step: BERT-base text "
-                                        "encoder (12 L) + 6-layer visual encoder, max_words=48, max_frames=48, bs=%d per GPU, "
-                                        "fwd+bwd+clip+BertAdam, dropout %.2f, random-init weights" % (args.batch, args.dropout),
-                               per_gpu_batch=args.batch, global_batch=args.batch * world, max_words=48, max_frames=48,
+                   config=dict(workload="%s, max_words=%d, max_frames=%d, bs=%d per GPU, "
+                                        "fwd+bwd+clip+BertAdam, dropout %.2f, random-init weights" % (names[1], W, F, args.batch, args.dropout),
+                               kind=args.kind, per_gpu_batch=args.batch, global_batch=args.batch * world, max_words=W, max_frames=F,
                                parallelism="dp%d" % world, hip_graph=gstep is not None,
                                graph_mode=(gstep.mode if gstep is not None else mode),
                                optimizer_pipelined=bool(gstep is not None and gstep.pipeline),
