@@ -927,10 +927,24 @@ class DecoderStack:
 
     def build_backward(self, plan, gin, x0_32, x0_16, enc16, denc32, gs, training):
         """gin: grad wrt the last layer output [Tq,H] fp32.  denc32 [Tkv,H] fp32 is ACCUMULATED into (every layer's
-        encoder-attention K/V projections read the same cross-encoder output).  Returns the grad wrt the stack input."""
+        encoder-attention K/V projections read the same cross-encoder output).  Returns the grad wrt the stack input.
+
+        Every weight-gradient product goes out in the launch of the dgrad product fed by the same upstream gradient
+        (Plan.add_gemm_pair, as in EncoderStack: the weight-gradient tiles fill the compute units the latency-bound dgrad leaves
+        idle) where the C side takes the pair (bf16, 64 x 64 tiles); otherwise the two launches one after the other."""
         fl, dt, H, I, B, Wd, Sk, Tq, Tkv, sm = self.flat, self.flat.dt, self.H, self.I, self.B, self.Wd, self.Sk, self.Tq, self.Tkv, self.sm
         p = self.p if training else 0.0
         G = fl.g
+        ride = (os.environ.get("UNIVL_WGRAD_RIDE", "1") == "1" and os.environ.get("UNIVL_DECODER_PAIR", "1") != "0"
+                and fl.compute_dtype == torch.bfloat16)
+
+        def emit(wgrad, dgrad):
+            if ride and _lib.lib().univl_gemm_pair(C.byref(dgrad), C.byref(wgrad), 1, None) == 0:
+                plan.add_gemm_pair(dgrad, wgrad, sm)
+            else:
+                plan.add("univl_gemm", wgrad, sm)
+                plan.add("univl_gemm", dgrad, sm)
+
         for l in range(self.L - 1, -1, -1):
             ws, nm = self.layers[l], self._names(l)
             off = ws["off"]
@@ -940,56 +954,56 @@ class DecoderStack:
             plan.add("univl_layernorm_bwd", ops.layernorm_desc(
                 dt, Tq, H, gamma=fl.w32(nm["ln_g"]), y=ws["y3"], stats=ws["st3"], dout=gin, dx32=dz, dxd16=self.dxd,
                 dgamma=G(nm["ln_g"]), dbeta=G(nm["ln_b"]), dbias=G(nm["b2"]), p_pre=p, off_pre=off[4], seed_dev=self.seed_dev), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, ws["f"], I, H, I, Tq, trans_a=1, trans_b=1, out32=G(nm["w2"]), ldc=I,
-                                              accumulate=gs.acc(nm["w2"])), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, fl.wop(nm["w2"]), I, Tq, I, H, trans_b=1, out16=self.du, ldc=I,
-                                              aux=ws["u"], ldaux=I, gelu="bwd"), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, self.du, I, ws["d16"], H, I, H, Tq, trans_a=1, trans_b=1, out32=G(nm["w1"]), ldc=H,
-                                              accumulate=gs.acc(nm["w1"]), dbias=G(nm["b1"])), sm)
+            emit(_gemm_desc(dt, self.dxd, H, ws["f"], I, H, I, Tq, trans_a=1, trans_b=1, out32=G(nm["w2"]), ldc=I,
+                            accumulate=gs.acc(nm["w2"])),
+                 _gemm_desc(dt, self.dxd, H, fl.wop(nm["w2"]), I, Tq, I, H, trans_b=1, out16=self.du, ldc=I,
+                            aux=ws["u"], ldaux=I, gelu="bwd"))
             dd = self.g2
-            plan.add("univl_gemm", _gemm_desc(dt, self.du, I, fl.wop(nm["w1"]), H, Tq, H, I, trans_b=1, out32=dd, ldc=H,
-                                              residual=dz, ldr=H), sm)
+            emit(_gemm_desc(dt, self.du, I, ws["d16"], H, I, H, Tq, trans_a=1, trans_b=1, out32=G(nm["w1"]), ldc=H,
+                            accumulate=gs.acc(nm["w1"]), dbias=G(nm["b1"])),
+                 _gemm_desc(dt, self.du, I, fl.wop(nm["w1"]), H, Tq, H, I, trans_b=1, out32=dd, ldc=H,
+                            residual=dz, ldr=H))
             # encoder-attention block
             dy2 = self.g1
             plan.add("univl_layernorm_bwd", ops.layernorm_desc(
                 dt, Tq, H, gamma=fl.w32(nm["c_ln_g"]), y=ws["y2"], stats=ws["st2"], dout=dd, dx32=dy2, dxd16=self.dxd,
                 dgamma=G(nm["c_ln_g"]), dbeta=G(nm["c_ln_b"]), dbias=G(nm["c_o_b"]), p_pre=p, off_pre=off[3], seed_dev=self.seed_dev), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, ws["ctx2"], H, H, H, Tq, trans_a=1, trans_b=1, out32=G(nm["c_o_w"]),
-                                              ldc=H, accumulate=gs.acc(nm["c_o_w"])), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, fl.wop(nm["c_o_w"]), H, Tq, H, H, trans_b=1, out16=self.dctx, ldc=H), sm)
+            emit(_gemm_desc(dt, self.dxd, H, ws["ctx2"], H, H, H, Tq, trans_a=1, trans_b=1, out32=G(nm["c_o_w"]),
+                            ldc=H, accumulate=gs.acc(nm["c_o_w"])),
+                 _gemm_desc(dt, self.dxd, H, fl.wop(nm["c_o_w"]), H, Tq, H, H, trans_b=1, out16=self.dctx, ldc=H))
             kv, dkv = ws["kv2"], self.dkv2
             plan.add("univl_attention_bwd", ops.attention_desc(
                 dt, B, self.NH, Wd, Sk, ws["q2"], H, (kv, 0), 2 * H, (kv, H), 2 * H, ws["ctx2"], H, ws["lse2"],
                 key_mask=self.enc_mask, p_drop=p, offset=off[2], seed_dev=self.seed_dev, dout=self.dctx, lddo=H,
                 dq=self.dq2, lddq=H, dk=(dkv, 0), lddk=2 * H, dv=(dkv, H), lddv=2 * H), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, dkv, 2 * H, enc16, H, 2 * H, H, Tkv, trans_a=1, trans_b=1,
-                                              out32=fl.g_fused(nm["c_kv_w"]), ldc=H, accumulate=gs.acc(nm["c_kv_w"][0]),
-                                              dbias=fl.g_fused(nm["c_kv_b"])), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, dkv, 2 * H, fl.wop_fused(nm["c_kv_w"]), H, Tkv, H, 2 * H, trans_b=1,
-                                              out32=denc32, ldc=H, accumulate=True), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, self.dq2, H, ws["a16"], H, H, H, Tq, trans_a=1, trans_b=1, out32=G(nm["c_q_w"]),
-                                              ldc=H, accumulate=gs.acc(nm["c_q_w"]), dbias=G(nm["c_q_b"])), sm)
+            emit(_gemm_desc(dt, dkv, 2 * H, enc16, H, 2 * H, H, Tkv, trans_a=1, trans_b=1,
+                            out32=fl.g_fused(nm["c_kv_w"]), ldc=H, accumulate=gs.acc(nm["c_kv_w"][0]),
+                            dbias=fl.g_fused(nm["c_kv_b"])),
+                 _gemm_desc(dt, dkv, 2 * H, fl.wop_fused(nm["c_kv_w"]), H, Tkv, H, 2 * H, trans_b=1,
+                            out32=denc32, ldc=H, accumulate=True))
             da = self.g2
-            plan.add("univl_gemm", _gemm_desc(dt, self.dq2, H, fl.wop(nm["c_q_w"]), H, Tq, H, H, trans_b=1, out32=da, ldc=H,
-                                              residual=dy2, ldr=H), sm)
+            emit(_gemm_desc(dt, self.dq2, H, ws["a16"], H, H, H, Tq, trans_a=1, trans_b=1, out32=G(nm["c_q_w"]),
+                            ldc=H, accumulate=gs.acc(nm["c_q_w"]), dbias=G(nm["c_q_b"])),
+                 _gemm_desc(dt, self.dq2, H, fl.wop(nm["c_q_w"]), H, Tq, H, H, trans_b=1, out32=da, ldc=H,
+                            residual=dy2, ldr=H))
             # causal self-attention block
             dy1 = self.g1
             plan.add("univl_layernorm_bwd", ops.layernorm_desc(
                 dt, Tq, H, gamma=fl.w32(nm["s_ln_g"]), y=ws["y1"], stats=ws["st1"], dout=da, dx32=dy1, dxd16=self.dxd,
                 dgamma=G(nm["s_ln_g"]), dbeta=G(nm["s_ln_b"]), dbias=G(nm["s_o_b"]), p_pre=p, off_pre=off[1], seed_dev=self.seed_dev), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, ws["ctx1"], H, H, H, Tq, trans_a=1, trans_b=1, out32=G(nm["s_o_w"]),
-                                              ldc=H, accumulate=gs.acc(nm["s_o_w"])), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, self.dxd, H, fl.wop(nm["s_o_w"]), H, Tq, H, H, trans_b=1, out16=self.dctx, ldc=H), sm)
+            emit(_gemm_desc(dt, self.dxd, H, ws["ctx1"], H, H, H, Tq, trans_a=1, trans_b=1, out32=G(nm["s_o_w"]),
+                            ldc=H, accumulate=gs.acc(nm["s_o_w"])),
+                 _gemm_desc(dt, self.dxd, H, fl.wop(nm["s_o_w"]), H, Tq, H, H, trans_b=1, out16=self.dctx, ldc=H))
             qkv, dqkv = ws["qkv"], self.dqkv
             plan.add("univl_attention_bwd", ops.attention_desc(
                 dt, B, self.NH, Wd, Wd, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx1"], H, ws["lse1"],
                 key_mask=self.dec_mask, causal=True, p_drop=p, offset=off[0], seed_dev=self.seed_dev, dout=self.dctx, lddo=H,
                 dq=(dqkv, 0), lddq=3 * H, dk=(dqkv, H), lddk=3 * H, dv=(dqkv, 2 * H), lddv=3 * H), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, dqkv, 3 * H, xin16, H, 3 * H, H, Tq, trans_a=1, trans_b=1,
-                                              out32=fl.g_fused(nm["s_qkv_w"]), ldc=H, accumulate=gs.acc(nm["s_qkv_w"][0]),
-                                              dbias=fl.g_fused(nm["s_qkv_b"])), sm)
             dx = self.g2
-            plan.add("univl_gemm", _gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["s_qkv_w"]), H, Tq, H, 3 * H, trans_b=1, out32=dx,
-                                              ldc=H, residual=dy1, ldr=H), sm)
+            emit(_gemm_desc(dt, dqkv, 3 * H, xin16, H, 3 * H, H, Tq, trans_a=1, trans_b=1,
+                            out32=fl.g_fused(nm["s_qkv_w"]), ldc=H, accumulate=gs.acc(nm["s_qkv_w"][0]),
+                            dbias=fl.g_fused(nm["s_qkv_b"])),
+                 _gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["s_qkv_w"]), H, Tq, H, 3 * H, trans_b=1, out32=dx,
+                            ldc=H, residual=dy1, ldr=H))
             gin = dx
         return gin

@@ -402,7 +402,16 @@ class VocabHead:
         cx, fl, dt, n, T, sm = self.cx, self.cx.fl, self.cx.dt, self.names(), self.T, self.sm
         W32, G = fl.w32, fl.g
         bwd.add_callable(lambda: ops.scale_ct(self.dlogits, gout), sm)
-        bwd.add("univl_gemm", _gemm_desc(dt, self.dlogits, self.ldv, fl.wop(n["emb"]), H, T, H, self.V, trans_b=1, out32=self.dh, ldc=H), sm)
+        # dh = dlogits . E contracts over the 30522-word vocabulary with only (T / 64) x 12 output tiles: unsplit, each workgroup
+        # walks 239 K steps alone (a ~240 us latency chain at T = 512).  Split over the vocabulary so that ~512 workgroups share it
+        # (fp32 atomics into the pre-zeroed dh; one slice in deterministic mode).  UNIVL_VOCAB_DGRAD_SPLIT=0: unsplit.
+        ks = 1
+        if os.environ.get("UNIVL_VOCAB_DGRAD_SPLIT", "1") != "0":
+            ks = max(1, min(16, 512 // max(1, ((T + 63) // 64) * (H // 64))))
+        if ks > 1:
+            bwd.add_zeros([self.dh], sm)
+        bwd.add("univl_gemm", _gemm_desc(dt, self.dlogits, self.ldv, fl.wop(n["emb"]), H, T, H, self.V, trans_b=1, out32=self.dh, ldc=H,
+                                         ksplit=ks), sm)
         bwd.add("univl_gemm", _gemm_desc(dt, self.dlogits, self.ldv, self.h16, H, self.V, H, T, trans_a=1, trans_b=1, out32=G(n["emb"]),
                                          ldc=H, accumulate=True, dbias=G(n["bias"])), sm)
         bwd.add("univl_layernorm_bwd", ops.layernorm_desc(dt, T, H, gamma=W32(n["lg"]), y=self.hy, stats=self.hst, dout=self.dh,
