@@ -810,7 +810,7 @@ def test_weight_gradient_packaging_matches_golden(golden_dir, name, ride, monkey
         assert kinds.count("univl_gemm_pair") == 0 and kinds.count("univl_gemm_group") >= cfg.text_num_hidden_layers + cfg.visual_num_hidden_layers
 
 
-@pytest.mark.parametrize("case", ["joint_full", "pretrain_small", "caption_small"])
+@pytest.mark.parametrize("case", ["joint_full", "pretrain_small", "caption_small", "align_small"])
 def test_adam_update_riding_with_the_next_forward_matches_eager(case, monkeypatch):
     """UNIVL_ADAM_RIDE=1 + GraphedTrainStep(pipeline_optimizer=True): the BertAdam update of iteration t is applied by the forward
     of iteration t + 1 -- embedding tables, vectors and each stack's first layer as launches in front of it, the other layers'

@@ -106,9 +106,16 @@ __global__ __launch_bounds__(256) void postype_bwd_kernel(const float* dpt, int 
     dpos[i] += dpt[i];
     if (s == 0 || s == W) {
         const int s1 = (s == 0 && W > 0) ? W : S;            // W == 0: position 0 is already the second half
-        float acc = 0.f;
-        for (int u = s; u < s1; ++u) acc += dpt[(long)u * N + c];
-        dtype[((s >= W) ? N : 0) + c] += acc;
+        // eight independent partial sums (positions u, u + 1, ... u + 7 of every group of eight), folded in a fixed order: the
+        // loads of a group are in flight together instead of one dependent round trip per position
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int u = s;
+        for (; u + 8 <= s1; u += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += dpt[(long)(u + k) * N + c];
+        }
+        for (int k = 0; u < s1; ++u, ++k) a[k] += dpt[(long)u * N + c];
+        dtype[((s >= W) ? N : 0) + c] += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
 }
 

@@ -604,10 +604,11 @@ class EncoderStack:
                      and self.sw is None and self.s_off is None)
         # The forward products of layer l can carry the BertAdam chunks of layer l + 1 (Plan.add_gemm_rider): switched on per model by
         # graphed.GraphedTrainStep(pipeline_optimizer=True) (flat.adam_ride), or for every model by UNIVL_ADAM_RIDE=1.
-        # Only the text / video stacks: all their passes of one forward run one after the other on the stack's own stream, so a
-        # layer's update (carried by the FIRST pass through the layer before it) is complete before anybody reads the layer.
+        # All passes of a stack through its layers in one forward (text / video: clean + masked pass; cross: up to three runs) are
+        # enqueued one after the other on ONE stream, so a layer's update (carried by the FIRST pass through the layer before it)
+        # is complete before anybody reads the layer.
         self.adam_ride = ((getattr(flat, "adam_ride", False) or os.environ.get("UNIVL_ADAM_RIDE", "") == "1")
-                          and flat.compute_dtype == torch.bfloat16 and prefix in ("bert", "visual"))
+                          and flat.compute_dtype == torch.bfloat16 and prefix in ("bert", "visual", "cross"))
         self.T = B * S
         self.key_mask = key_mask            # int64 [B,S] device tensor (static buffer)
         self.p = float(p_drop)
@@ -885,12 +886,25 @@ class DecoderStack:
     def build_forward(self, plan, x32, x16, enc16, training):
         fl, dt, H, I, B, Wd, Sk, Tq, Tkv, sm = self.flat, self.flat.dt, self.H, self.I, self.B, self.Wd, self.Sk, self.Tq, self.Tkv, self.sm
         p = self.p if training else 0.0
+        adam_ride = ((getattr(fl, "adam_ride", False) or os.environ.get("UNIVL_ADAM_RIDE", "") == "1")
+                     and fl.compute_dtype == torch.bfloat16 and training)
         for l, ws in enumerate(self.layers):
             nm = self._names(l)
             off = ws["off"]
             plan.wait_point(("layer", "decoder", l), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, x16, H, fl.wop_fused(nm["s_qkv_w"]), H, Tq, 3 * H, H, out16=ws["qkv"], ldc=3 * H,
-                                              bias=fl.w32_fused(nm["s_qkv_b"])), sm)
+            slot = [0]
+
+            def big(desc, _l=l, _slot=slot):
+                """one of the layer's four large forward products: with the riding optimizer update it carries a quarter of the
+                chunks of layer l + 1 (Plan.add_gemm_rider; the decoder runs once per forward, on one stream)"""
+                if adam_ride and _l + 1 < self.L:
+                    plan.add_gemm_rider(desc, ("layer", "decoder", _l + 1), _slot[0], 4, sm)
+                    _slot[0] += 1
+                else:
+                    plan.add("univl_gemm", desc, sm)
+
+            big(_gemm_desc(dt, x16, H, fl.wop_fused(nm["s_qkv_w"]), H, Tq, 3 * H, H, out16=ws["qkv"], ldc=3 * H,
+                           bias=fl.w32_fused(nm["s_qkv_b"])))
             qkv = ws["qkv"]
             plan.add("univl_attention_fwd", ops.attention_desc(
                 dt, B, self.NH, Wd, Wd, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx1"], H, ws["lse1"],
@@ -903,8 +917,8 @@ class DecoderStack:
                 seed_dev=self.seed_dev), sm)
             plan.add("univl_gemm", _gemm_desc(dt, ws["a16"], H, fl.wop(nm["c_q_w"]), H, Tq, H, H, out16=ws["q2"], ldc=H,
                                               bias=fl.w32(nm["c_q_b"])), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, enc16, H, fl.wop_fused(nm["c_kv_w"]), H, Tkv, 2 * H, H, out16=ws["kv2"],
-                                              ldc=2 * H, bias=fl.w32_fused(nm["c_kv_b"])), sm)
+            big(_gemm_desc(dt, enc16, H, fl.wop_fused(nm["c_kv_w"]), H, Tkv, 2 * H, H, out16=ws["kv2"],
+                           ldc=2 * H, bias=fl.w32_fused(nm["c_kv_b"])))
             kv = ws["kv2"]
             plan.add("univl_attention_fwd", ops.attention_desc(
                 dt, B, self.NH, Wd, Sk, ws["q2"], H, (kv, 0), 2 * H, (kv, H), 2 * H, ws["ctx2"], H, ws["lse2"],
@@ -915,10 +929,10 @@ class DecoderStack:
                 dt, Tq, H, x=ws["y2"], residual=ws["a32"], gamma=fl.w32(nm["c_ln_g"]), beta=fl.w32(nm["c_ln_b"]), y=ws["y2"],
                 stats=ws["st2"], out32=ws["d32"], out16=ws["d16"] if self.bf else None, p_pre=p, off_pre=off[3],
                 seed_dev=self.seed_dev), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, ws["d16"], H, fl.wop(nm["w1"]), H, Tq, I, H, out16=ws["f"], ldc=I,
-                                              bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd"), sm)
-            plan.add("univl_gemm", _gemm_desc(dt, ws["f"], I, fl.wop(nm["w2"]), I, Tq, H, I, out32=ws["y3"], ldc=H,
-                                              bias=fl.w32(nm["b2"])), sm)
+            big(_gemm_desc(dt, ws["d16"], H, fl.wop(nm["w1"]), H, Tq, I, H, out16=ws["f"], ldc=I,
+                           bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd"))
+            big(_gemm_desc(dt, ws["f"], I, fl.wop(nm["w2"]), I, Tq, H, I, out32=ws["y3"], ldc=H,
+                           bias=fl.w32(nm["b2"])))
             plan.add("univl_layernorm_fwd", ops.layernorm_desc(
                 dt, Tq, H, x=ws["y3"], residual=ws["d32"], gamma=fl.w32(nm["ln_g"]), beta=fl.w32(nm["ln_b"]), y=ws["y3"],
                 stats=ws["st3"], out32=ws["o32"], out16=ws["o16"] if self.bf else None, p_pre=p, off_pre=off[4],
