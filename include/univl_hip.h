@@ -252,9 +252,17 @@ typedef struct UnivlPool {
     const float* dout;  /* bwd: [B,N] */
     float* dx;          /* bwd: [B,S,N] */
     int32_t accumulate; /* bwd: dx += instead of dx = */
+    /* bwd, optional: take the upstream gradient from the similarity matrix's instead of `dout` -- torch.matmul(text, video.t())
+     * of modeling.py:389 backward folded in: dout[b, :] = gscale[0] * sum_k dsim[b, k] * other[k, :] (transpose = 0: this side
+     * indexes the ROWS of dsim) or sum_k dsim[k, b] * other[k, :] (transpose = 1: the columns); `other` = the other modality's
+     * pooled (normalised) [n_other, N] matrix, dsim rows ldsim floats apart, gscale a device scalar (NULL: 1). */
+    const float* dsim; int64_t ldsim; const float* other; int32_t n_other; int32_t transpose; const float* gscale;
 } UnivlPool;
 int univl_pool_fwd(const UnivlPool* d, hipStream_t stream);
 int univl_pool_bwd(const UnivlPool* d, hipStream_t stream);
+/* The text and the video pooling of one similarity head in ONE launch each way (the two descriptors of modeling.py:327-339). */
+int univl_pool_pair_fwd(const UnivlPool* a, const UnivlPool* b, hipStream_t stream);
+int univl_pool_pair_bwd(const UnivlPool* a, const UnivlPool* b, hipStream_t stream);
 
 /* MaxMarginRankingLoss (until_module.py:245-251): loss = mean(w * (relu(m + x - diag_col) + relu(m + x - diag_row))).
  * `sim` and `dsim` are [n, ld] row-major (ld >= n).  Writes the scalar loss and d loss / d x (for an upstream

@@ -59,7 +59,8 @@ def test_flat_layout_and_plans_build_on_cpu():
     m.train()
     from univl_amd.steps import build_step
     st = build_step(m, "joint", 2, 16, 16, True)
-    assert len(st.fwd) >= 3 * 7 + 4 + 4 and len(st.backward_plan(True)) > len(st.fwd)
+    # (the similarity head's backward is ONE launch since round 3, so the backward plan is no longer the longer one)
+    assert len(st.fwd) >= 3 * 7 + 4 + 4 and len(st.backward_plan(True)) >= 3 * 7 + 4
     # data-parallel buckets: disjoint, cover every parameter that gets a gradient
     b = layer_buckets(fl, m.used_parameter_names())
     sl = sorted(list(b["layers"].values()) + b["tail"])

@@ -531,6 +531,45 @@ def test_pool_fwd_bwd(B, S):
         assert rel_err(dx2 - base, xr.grad) < 1e-4
 
 
+@pytest.mark.parametrize("B,W,F", [(4, 48, 48), (6, 20, 300), (16, 48, 12)])
+def test_pool_pair_launches_and_similarity_backward_folded_in(B, W, F):
+    """univl_pool_pair_fwd / _bwd: the text and the video pooling of one similarity head in one launch each way; the backward takes
+    its upstream gradient from d loss / d sim (UnivlPool.dsim: torch.matmul(text, video.t()) of modeling.py:389 and the upstream
+    factor folded in).  Against the separate kernels (scale, two fp32 GEMMs, two pool backwards)."""
+    xt, xv = gen(B, W, 768, seed=1).to(DEV), gen(B, F, 768, seed=2).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    mt = (torch.arange(W)[None] < torch.randint(2, W + 1, (B, 1), generator=g)).long().to(DEV)
+    mv = (torch.arange(F)[None] < torch.randint(0, F + 1, (B, 1), generator=g)).long().to(DEV)
+    ldp = (B + 3) // 4 * 4
+    dsim = torch.zeros(ldp, ldp, device=DEV); dsim[:B, :B] = gen(B, B, seed=4).to(DEV)
+    gout = torch.tensor([0.5], device=DEV)
+    e = lambda *s_: torch.empty(*s_, device=DEV)
+    # reference: separate launches
+    tm, tn, vm, vn = e(B, 768), torch.zeros(ldp, 768, device=DEV), e(B, 768), torch.zeros(ldp, 768, device=DEV)
+    ops.pool_fwd(B, W, xt, mt, skip_first=True, normalize=True, mean=tm, out=tn)
+    ops.pool_fwd(B, F, xv, mv, skip_first=False, normalize=True, mean=vm, out=vn)
+    ds = dsim.clone()
+    ops.scale_by_device_scalar(ds, gout)
+    dtn, dvn = e(B, 768), e(B, 768)
+    ops.gemm(ds, vn, B, 768, B, trans_b=True, out32=dtn)
+    ops.gemm(ds, tn, B, 768, B, trans_a=True, trans_b=True, out32=dvn)
+    base_t, base_v = gen(B, W, 768, seed=5).to(DEV), gen(B, F, 768, seed=6).to(DEV)
+    dxt, dxv = base_t.clone(), base_v.clone()
+    ops.pool_bwd(B, W, xt, mt, skip_first=True, normalize=True, mean=tm, out=tn, dout=dtn, dx=dxt, accumulate=True)
+    ops.pool_bwd(B, F, xv, mv, skip_first=False, normalize=True, mean=vm, out=vn, dout=dvn, dx=dxv, accumulate=True)
+    # pair launches
+    tm2, tn2, vm2, vn2 = e(B, 768), torch.zeros(ldp, 768, device=DEV), e(B, 768), torch.zeros(ldp, 768, device=DEV)
+    ops.pool_pair_fwd(ops.pool_desc(B, W, xt, mt, skip_first=True, normalize=True, mean=tm2, out=tn2),
+                      ops.pool_desc(B, F, xv, mv, skip_first=False, normalize=True, mean=vm2, out=vn2))
+    assert torch.equal(tn2, tn) and torch.equal(vn2, vn) and torch.equal(tm2, tm) and torch.equal(vm2, vm)
+    dxt2, dxv2 = base_t.clone(), base_v.clone()
+    ops.pool_pair_bwd(ops.pool_desc(B, W, xt, mt, skip_first=True, normalize=True, mean=tm2, out=tn2, dx=dxt2, accumulate=True,
+                                    dsim=dsim, other=vn2, n_other=B, transpose=False, gscale=gout),
+                      ops.pool_desc(B, F, xv, mv, skip_first=False, normalize=True, mean=vm2, out=vn2, dx=dxv2, accumulate=True,
+                                    dsim=dsim, other=tn2, n_other=B, transpose=True, gscale=gout))
+    assert rel_err(dxt2 - base_t, dxt - base_t) < 1e-5 and rel_err(dxv2 - base_v, dxv - base_v) < 1e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(4, 4, 768), (16, 16, 768), (32, 7, 1023), (1, 1, 5)])
 def test_gemm_small_fp32_dot_path(M, N, K):
     """B x B similarity products (modeling.py:389) take the one-workgroup-per-output path."""

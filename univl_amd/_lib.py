@@ -47,7 +47,8 @@ class EmbedText(C.Structure):
 
 class Pool(C.Structure):
     _fields_ = [("B", i32), ("S", i32), ("N", i32), ("x", vp), ("ldx_row", i64), ("mask", vp),
-                ("skip_first", i32), ("normalize", i32), ("mean", vp), ("out", vp), ("dout", vp), ("dx", vp), ("accumulate", i32)]
+                ("skip_first", i32), ("normalize", i32), ("mean", vp), ("out", vp), ("dout", vp), ("dx", vp), ("accumulate", i32),
+                ("dsim", vp), ("ldsim", i64), ("other", vp), ("n_other", i32), ("transpose", i32), ("gscale", vp)]
 
 
 class Seg(C.Structure):
@@ -90,6 +91,8 @@ def lib():
                  "univl_pool_bwd", "univl_bert_adam"):
         getattr(L, name).argtypes = [vp, vp]
         getattr(L, name).restype = i32
+    L.univl_pool_pair_fwd.argtypes = [vp, vp, vp]
+    L.univl_pool_pair_bwd.argtypes = [vp, vp, vp]
     L.univl_gemm_group.argtypes = [vp, i32, vp]
     L.univl_gemm_group.restype = i32
     L.univl_gemm_group_limited.argtypes = [vp, i32, i32, vp]
@@ -156,7 +159,7 @@ EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_dev
             "univl_allreduce_bucket", "univl_set_deterministic", "univl_get_deterministic", "univl_gemm", "univl_gemm_group_limited", "univl_gemm_group", "univl_gemm_tile_map", "univl_gemm_pair", "univl_gemm_rider", "univl_gemm_rider_prime",
             "univl_layernorm_fwd", "univl_layernorm_bwd", "univl_attention_fwd", "univl_attention_bwd",
             "univl_embed_text_fwd", "univl_embed_text_bwd", "univl_embed_scatter", "univl_rows_zero", "univl_rows_append",
-            "univl_rows_sumsq", "univl_zero_many", "univl_copy_many", "univl_pool_fwd", "univl_pool_bwd",
+            "univl_rows_sumsq", "univl_zero_many", "univl_copy_many", "univl_pool_fwd", "univl_pool_bwd", "univl_pool_pair_fwd", "univl_pool_pair_bwd",
             "univl_maxmargin_loss", "univl_crossen_loss", "univl_milnce_loss", "univl_rank_counts", "univl_gather_rows", "univl_log_softmax_rows", "univl_scale_by_device_scalar", "univl_pair_concat_fwd", "univl_pair_concat_bwd", "univl_postype_fwd", "univl_postype_bwd", "univl_tanh_fwd",
             "univl_tanh_bwd", "univl_gelu_bwd", "univl_colsum", "univl_scale_ct_by_device_scalar", "univl_simdense_fwd", "univl_simdense_bwd", "univl_ce_loss", "univl_mfm_nce_loss", "univl_grad_sumsq", "univl_sumsq_finish",
             "univl_clip_coef", "univl_scale_grads", "univl_bert_adam", "univl_bert_adam_range", "univl_cast_bf16", "univl_bump_counter", "univl_probe_layouts"]

@@ -47,10 +47,8 @@ __device__ __forceinline__ float stage_weights(const UnivlPool& p, int b, int s0
     return block_sum(w, red);          // includes the barrier that publishes wts
 }
 
-__global__ __launch_bounds__(256) void pool_fwd_kernel(UnivlPool p) {
-    __shared__ float red[4];
-    __shared__ float wts[PCHUNK];
-    const int b = blockIdx.x, t = threadIdx.x;
+__device__ __forceinline__ void pool_fwd_body(const UnivlPool& p, const int b, float* red, float* wts) {
+    const int t = threadIdx.x;
     float acc[PC] = {0.f, 0.f, 0.f};
     float cnt = 0.f;
     for (int s0 = 0; s0 < p.S; s0 += PCHUNK) {
@@ -81,17 +79,29 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(UnivlPool p) {
     }
 }
 
-// grid (B, ceil(S / PCHUNK)): every block recomputes the row's count (cheap, from LDS-staged weights) and writes its
-// own chunk of sequence positions
-__global__ __launch_bounds__(256) void pool_bwd_kernel(UnivlPool p) {
+__global__ __launch_bounds__(256) void pool_fwd_kernel(UnivlPool p) {
     __shared__ float red[4];
     __shared__ float wts[PCHUNK];
-    __shared__ float mine[PCHUNK];
-    const int b = blockIdx.x, t = threadIdx.x;
+    pool_fwd_body(p, blockIdx.x, red, wts);
+}
+
+// two descriptors in one launch: blocks [0, a.B) pool a's rows, the rest b's (block-uniform choice)
+__global__ __launch_bounds__(256) void pool_pair_fwd_kernel(UnivlPool a, UnivlPool b) {
+    __shared__ float red[4];
+    __shared__ float wts[PCHUNK];
+    if ((int)blockIdx.x < a.B) pool_fwd_body(a, blockIdx.x, red, wts);
+    else pool_fwd_body(b, (int)blockIdx.x - a.B, red, wts);
+}
+
+// grid (B, ceil(S / PCHUNK)): every block recomputes the row's count (cheap, from LDS-staged weights) and writes its
+// own chunk of sequence positions
+__device__ __forceinline__ void pool_bwd_body(const UnivlPool& p, const int b, const int chunk, float* red, float* wts, float* mine) {
+    const int t = threadIdx.x;
+    if (chunk * PCHUNK >= p.S) return;              // (pair launch: the grid is sized for the longer sequence) -- block-uniform
     float cnt = 0.f;
     for (int s0 = 0; s0 < p.S; s0 += PCHUNK) {
         cnt += stage_weights(p, b, s0, wts, red);
-        if (s0 == (int)blockIdx.y * PCHUNK) mine[t] = wts[t];
+        if (s0 == chunk * PCHUNK) mine[t] = wts[t];
         __syncthreads();
     }
     if (!p.skip_first && cnt == 0.0f) cnt = 1.0f;
@@ -100,7 +110,21 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(UnivlPool p) {
 #pragma unroll
     for (int j = 0; j < PC; ++j) {
         m[j] = p.mean[(long)b * PN + t + 256 * j];
-        d[j] = p.dout[(long)b * PN + t + 256 * j];
+        d[j] = p.dsim ? 0.0f : p.dout[(long)b * PN + t + 256 * j];
+    }
+    if (p.dsim) {
+        // upstream gradient straight from d loss / d sim (UnivlPool.dsim): row b (or column b) of dsim times the other side's matrix
+        const float gs = p.gscale ? p.gscale[0] : 1.0f;
+        for (int k = 0; k < p.n_other; ++k) {
+            const float w = p.transpose ? p.dsim[(long)k * p.ldsim + b] : p.dsim[(long)b * p.ldsim + k];
+#pragma unroll
+            for (int j = 0; j < PC; ++j) d[j] += w * p.other[(long)k * PN + t + 256 * j];
+        }
+#pragma unroll
+        for (int j = 0; j < PC; ++j) d[j] *= gs;
+    }
+#pragma unroll
+    for (int j = 0; j < PC; ++j) {
         sq += m[j] * m[j];
         dot += m[j] * d[j];
     }
@@ -111,7 +135,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(UnivlPool p) {
         for (int j = 0; j < PC; ++j) d[j] = (d[j] - m[j] * dd) / nrm;
     }
     const float inv_cnt = 1.0f / cnt;
-    const int s0 = blockIdx.y * PCHUNK, n = min(PCHUNK, p.S - s0);
+    const int s0 = chunk * PCHUNK, n = min(PCHUNK, p.S - s0);
     float* dx = p.dx + ((long)b * p.S + s0) * PN + t;
     if (p.accumulate) {
         // read-modify-write of dx: the old values of 8 sequence positions are fetched before the first store (the loads
@@ -143,6 +167,21 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(UnivlPool p) {
             for (int j = 0; j < PC; ++j) dx[(long)s * PN + 256 * j] = d[j] * w;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_kernel(UnivlPool p) {
+    __shared__ float red[4];
+    __shared__ float wts[PCHUNK];
+    __shared__ float mine[PCHUNK];
+    pool_bwd_body(p, blockIdx.x, blockIdx.y, red, wts, mine);
+}
+
+__global__ __launch_bounds__(256) void pool_pair_bwd_kernel(UnivlPool a, UnivlPool b) {
+    __shared__ float red[4];
+    __shared__ float wts[PCHUNK];
+    __shared__ float mine[PCHUNK];
+    if ((int)blockIdx.x < a.B) pool_bwd_body(a, blockIdx.x, blockIdx.y, red, wts, mine);
+    else pool_bwd_body(b, (int)blockIdx.x - a.B, blockIdx.y, red, wts, mine);
 }
 
 // ----------------------------------------------------------------------------------------------- losses
@@ -294,10 +333,38 @@ extern "C" int univl_pool_fwd(const UnivlPool* d, hipStream_t stream) {
     return UNIVL_OK;
 }
 
+static int pool_bwd_check(const UnivlPool* d, const char* who) {
+    UNIVL_CHECK_ARG(d && d->N == 768 && d->B > 0 && d->S > 0 && d->mean && d->dx && (d->dout || (d->dsim && d->other && d->n_other > 0)),
+                    UNIVL_EINVAL, "%s: bad argument", who);
+    return UNIVL_OK;
+}
+
 extern "C" int univl_pool_bwd(const UnivlPool* d, hipStream_t stream) {
     UNIVL_ON_STREAM_DEVICE(stream);
-    UNIVL_CHECK_ARG(d && d->N == 768 && d->B > 0 && d->S > 0 && d->mean && d->dout && d->dx, UNIVL_EINVAL, "univl_pool_bwd: bad argument");
+    const int rc = pool_bwd_check(d, "univl_pool_bwd");
+    if (rc) return rc;
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(d->B, (d->S + PCHUNK - 1) / PCHUNK), dim3(256), 0, stream, *d);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+extern "C" int univl_pool_pair_fwd(const UnivlPool* a, const UnivlPool* b, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    UNIVL_CHECK_ARG(a && b && a->N == 768 && b->N == 768 && a->B > 0 && b->B > 0 && a->S > 0 && b->S > 0 && a->x && b->x && a->out && b->out,
+                    UNIVL_EINVAL, "univl_pool_pair_fwd: bad argument (N must be 768)");
+    hipLaunchKernelGGL(pool_pair_fwd_kernel, dim3(a->B + b->B), dim3(256), 0, stream, *a, *b);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+extern "C" int univl_pool_pair_bwd(const UnivlPool* a, const UnivlPool* b, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    int rc = pool_bwd_check(a, "univl_pool_pair_bwd");
+    if (rc) return rc;
+    rc = pool_bwd_check(b, "univl_pool_pair_bwd");
+    if (rc) return rc;
+    const int smax = a->S > b->S ? a->S : b->S;
+    hipLaunchKernelGGL(pool_pair_bwd_kernel, dim3(a->B + b->B, (smax + PCHUNK - 1) / PCHUNK), dim3(256), 0, stream, *a, *b);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }

@@ -314,6 +314,13 @@ class Plan:
         self.descs[len(self.ops)] = [desc]
         self.ops.append(("call", fn, C.byref(desc), fn_name, stream))
 
+    def add_pair_call(self, fn_name, da, db, stream=0):
+        """An entry point that takes two descriptors (univl_pool_pair_fwd / _bwd)."""
+        fn = getattr(_lib.lib(), fn_name)
+        self.keep += [da, db]
+        self.descs[len(self.ops)] = [da, db]
+        self.ops.append(("call2", fn, (da, db), fn_name, stream))
+
     def add_gemm_group(self, descs, stream=0, max_blocks=0):
         """Independent GEMMs with the same operand layouts as ONE launch (univl_gemm_group), in chunks of GEMM_GROUP_MAX.
         max_blocks > 0: at most that many workgroups (the kernel walks its tiles)."""
@@ -392,6 +399,13 @@ class Plan:
                 if h is None:
                     h = handles[sidx] = C.c_void_p(self._stream(sidx, cur).cuda_stream)
                 rc = a(b, h)
+                if rc != 0:
+                    _lib.check(rc, name)
+            elif kind == "call2":
+                h = handles.get(sidx)
+                if h is None:
+                    h = handles[sidx] = C.c_void_p(self._stream(sidx, cur).cuda_stream)
+                rc = a(C.byref(b[0]), C.byref(b[1]), h)
                 if rc != 0:
                     _lib.check(rc, name)
             elif kind == "group":

@@ -184,13 +184,18 @@ def embed_text_bwd(*a, **kw):
     _lib.check(_lib.lib().univl_embed_text_bwd(_BYREF(d), _stream()), "embed_text_bwd")
 
 
-def pool_desc(B, S, x, mask, *, skip_first, normalize, mean=None, out=None, dout=None, dx=None, ldx_row=768, accumulate=False):
+def pool_desc(B, S, x, mask, *, skip_first, normalize, mean=None, out=None, dout=None, dx=None, ldx_row=768, accumulate=False,
+              dsim=None, other=None, n_other=0, transpose=False, gscale=None):
+    """dsim / other / n_other / transpose / gscale: the backward takes its upstream gradient from d loss / d sim instead of dout
+    (include/univl_hip.h: UnivlPool.dsim)."""
     d = _lib.Pool()
     d.B, d.S, d.N = B, S, 768
     d.x, d.ldx_row, d.mask = _p(x), ldx_row, _p(mask)
     d.skip_first, d.normalize = int(skip_first), int(normalize)
     d.mean, d.out, d.dout, d.dx = _p(mean), _p(out), _p(dout), _p(dx)
     d.accumulate = int(accumulate)
+    d.dsim, d.ldsim = _p(dsim), (dsim.stride(0) if dsim is not None else 0)
+    d.other, d.n_other, d.transpose, d.gscale = _p(other), int(n_other), int(bool(transpose)), _p(gscale)
     return d
 
 
@@ -202,6 +207,14 @@ def pool_fwd(*a, **kw):
 def pool_bwd(*a, **kw):
     d = pool_desc(*a, **kw)
     _lib.check(_lib.lib().univl_pool_bwd(_BYREF(d), _stream()), "pool_bwd")
+
+
+def pool_pair_fwd(da, db):
+    _lib.check(_lib.lib().univl_pool_pair_fwd(_BYREF(da), _BYREF(db), _stream()), "pool_pair_fwd")
+
+
+def pool_pair_bwd(da, db):
+    _lib.check(_lib.lib().univl_pool_pair_bwd(_BYREF(da), _BYREF(db), _stream()), "pool_pair_bwd")
 
 
 def maxmargin_loss(sim, margin, weight, loss, dsim):

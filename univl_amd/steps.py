@@ -245,20 +245,36 @@ class JointSim:
         self.sim, self.dsim = e(self.ldp, self.ldp), e(self.ldp, self.ldp)
         self.dtn, self.dvn = e(B, H), e(B, H)
         self.norm = not bool(cx.tc.use_mil)
+        # one launch for both poolings, one for the whole similarity-head backward (UNIVL_FUSED_SIM=0: the separate kernels); up to
+        # 256 rows the per-row loop over the other modality's matrix is cheaper than two extra launches
+        self.fused = os.environ.get("UNIVL_FUSED_SIM", "1") != "0" and B <= 256
         self.lossfn = SimLoss(cx, loss_kind, B)
         self.loss = self.lossfn.loss
 
     def build_forward(self, fwd):
         enc, B = self.enc, self.enc.B
-        fwd.add("univl_pool_fwd", ops.pool_desc(B, enc.W, enc.seq_out, enc.amask, skip_first=True, normalize=self.norm,
-                                                mean=self.tmean, out=self.tn))
-        fwd.add("univl_pool_fwd", ops.pool_desc(B, enc.F, enc.vis_out, enc.vmask, skip_first=False, normalize=self.norm,
-                                                mean=self.vmean, out=self.vn))
+        dt_ = ops.pool_desc(B, enc.W, enc.seq_out, enc.amask, skip_first=True, normalize=self.norm, mean=self.tmean, out=self.tn)
+        dv_ = ops.pool_desc(B, enc.F, enc.vis_out, enc.vmask, skip_first=False, normalize=self.norm, mean=self.vmean, out=self.vn)
+        if self.fused:
+            fwd.add_pair_call("univl_pool_pair_fwd", dt_, dv_)          # text and video pooling: one launch
+        else:
+            fwd.add("univl_pool_fwd", dt_)
+            fwd.add("univl_pool_fwd", dv_)
         fwd.add("univl_gemm", _gemm_desc(_lib.DT_F32, self.tn, H, self.vn, H, B, B, H, out32=self.sim, ldc=self.ldp))
         self.lossfn.build(fwd, self.sim[:B], self.dsim[:B])
 
     def build_backward(self, bwd, gout):
         enc, B, ldp = self.enc, self.enc.B, self.ldp
+        if self.fused:
+            # torch.matmul(text, video.t()) backward (modeling.py:389), the upstream factor and both pooling backwards in ONE launch
+            # (UnivlPool.dsim): five kernels of the chain between the forward and the encoders' backward become one
+            bwd.add_pair_call(
+                "univl_pool_pair_bwd",
+                ops.pool_desc(B, enc.W, enc.seq_out, enc.amask, skip_first=True, normalize=self.norm, mean=self.tmean, out=self.tn,
+                              dx=enc.dseq, accumulate=True, dsim=self.dsim, other=self.vn, n_other=B, transpose=False, gscale=gout),
+                ops.pool_desc(B, enc.F, enc.vis_out, enc.vmask, skip_first=False, normalize=self.norm, mean=self.vmean, out=self.vn,
+                              dx=enc.dvis, accumulate=True, dsim=self.dsim, other=self.tn, n_other=B, transpose=True, gscale=gout))
+            return
         bwd.add_callable(lambda: ops.scale_by_device_scalar(self.dsim, gout))
         bwd.add("univl_gemm", _gemm_desc(_lib.DT_F32, self.dsim, ldp, self.vn, H, B, H, B, trans_b=1, out32=self.dtn, ldc=H))
         bwd.add("univl_gemm", _gemm_desc(_lib.DT_F32, self.dsim, ldp, self.tn, H, B, H, B, trans_a=1, trans_b=1, out32=self.dvn, ldc=H))
