@@ -567,7 +567,8 @@ def test_pool_pair_launches_and_similarity_backward_folded_in(B, W, F):
                                     dsim=dsim, other=vn2, n_other=B, transpose=False, gscale=gout),
                       ops.pool_desc(B, F, xv, mv, skip_first=False, normalize=True, mean=vm2, out=vn2, dx=dxv2, accumulate=True,
                                     dsim=dsim, other=tn2, n_other=B, transpose=True, gscale=gout))
-    assert rel_err(dxt2 - base_t, dxt - base_t) < 1e-5 and rel_err(dxv2 - base_v, dxv - base_v) < 1e-5
+    # (dx - base cancels ~2 digits of the fp32 sums on both sides: the gate of the accumulate form, as in test_pool_fwd_bwd)
+    assert rel_err(dxt2 - base_t, dxt - base_t) < 1e-4 and rel_err(dxv2 - base_v, dxv - base_v) < 1e-4
 
 
 @pytest.mark.parametrize("M,N,K", [(4, 4, 768), (16, 16, 768), (32, 7, 1023), (1, 1, 5)])
