@@ -5,10 +5,14 @@ At 4-16 pairs per GPU a step is ~380 kernels of 2-10 us each; launched one by on
 bottleneck (~10 us per ctypes call).  `GraphedTrainStep` captures the iteration once and replays it:
 
   * one process, no gradient exchange: ONE graph holds the whole iteration;
-  * data parallel (UniVL.enable_data_parallel): RCCL collectives stay OUTSIDE the graphs -- the forward is one graph,
-    the backward plan is cut at its gradient-exchange points into captured segments (engine.Plan.run_graphed) with
-    the all-reduces issued from the host between the replays (they run on RCCL's own stream and overlap the
-    following segments), and clip + BertAdam are a last graph that is replayed after the reducer's join.
+  * data parallel over RCCL (UniVL.enable_data_parallel; parallel.BucketReducer.enable_capture): the collectives go through a
+    communicator of our own on a communication stream (univl_amd.rccl), so they are nodes of the SAME graph -- still ONE
+    graph per iteration;
+  * data parallel through torch's process group (gloo, the sharded optimizer, UNIVL_DP_CAPTURE=0): the collectives stay
+    OUTSIDE the graphs -- the forward is one graph, the backward plan is cut at its gradient-exchange points into captured
+    segments (engine.Plan.run_graphed) with the all-reduces issued from the host between the replays (they run on the
+    process group's own stream and overlap the following segments), and clip + BertAdam are a last graph that is replayed
+    after the reducer's join.
 
 Pipelined optimizer (pipeline_optimizer=True).  Two forms: the RIDING form (default where it applies: bf16, one process -- the
 pending update goes out as extra workgroups of the next forward's own GEMM launches, engine.Plan.add_gemm_rider; -8 % per step at 4
