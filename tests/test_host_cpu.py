@@ -270,3 +270,38 @@ def test_bench_refuses_more_gpus_than_visible():
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 2, (r.returncode, r.stderr[-400:])
     assert "--gpus 2 requested but only" in r.stderr
+
+
+def test_word_table_chunks_start_on_row_boundaries_and_plan_ops_are_capturable():
+    """Host logic of round 3: (1) the optimizer's chunk table cuts the word-embedding table into whole rows (UnivlAdam.row_flags
+    tests rows, so a chunk must not straddle one), covers it exactly once, and leaves every other tensor on 8192-element chunks;
+    (2) a plan whose exchange points are `with_streams` callables (the captured RCCL form) has NO eager segment -- the whole
+    backward is one capturable run -- while the process-group form cuts it."""
+    from univl_amd.optimization import _Tables, CHUNK
+    from univl_amd.engine import Plan
+    m, cfg = _model("fp32")
+    fl = FlatParams(list(m.named_parameters()), "cpu", torch.float32)
+    assert fl.word_ever is not None and fl.word_ever.numel() == cfg.vocab_size and int(fl.word_ever.sum()) == 0
+    names = m.used_parameter_names()
+    tb = _Tables(fl, {n: (1e-4, 0.01, 1.0, 1) for n in names})
+    seg = fl.seg_of[fl.WORD]
+    off, numel, shp = fl.index[fl.WORD]
+    row = shp[1]
+    cs, co, cl = tb.chunk_seg.tolist(), tb.chunk_off.tolist(), tb.chunk_len.tolist()
+    mine = [(o, l) for s_, o, l in zip(cs, co, cl) if s_ == seg]
+    assert mine[0][0] == off and sum(l for _, l in mine) == numel
+    assert all((o - off) % row == 0 for o, _ in mine) and all(l % row == 0 for _, l in mine)
+    assert all(a[0] + a[1] == b[0] for a, b in zip(mine, mine[1:]))                     # contiguous, in order, no overlap
+    assert all(l <= CHUNK for l in cl) and max(l for s_, l in zip(cs, cl) if s_ != seg) == CHUNK
+    fl.mark_all_word_rows()
+    assert int(fl.word_ever.sum()) == cfg.vocab_size and fl.word_ever_all
+    p1, p2 = Plan(), Plan()
+    for p, captured in ((p1, True), (p2, False)):
+        p.add_callable(lambda: None)
+        if captured:
+            p.add_callable(lambda streams: None, with_streams=True)
+        else:
+            p.add_callable(lambda: None, eager=True)
+        p.add_callable(lambda: None)
+    assert [k for k, _ in p1.segments()] == ["graph"]
+    assert [k for k, _ in p2.segments()] == ["graph", "eager", "graph"]
