@@ -101,7 +101,7 @@ def test_every_forward_branch_builds_its_plans(kw, kind):
     m.train()
     assert m.step_kind(True) == kind
     st = build_step(m, kind, 2, 16, 16, True)
-    assert len(st.fwd) > 20 and len(st.backward_plan(True)) > len(st.fwd)
+    assert len(st.fwd) > 20 and len(st.backward_plan(True)) > 20      # (FT-Joint: the similarity head's backward is one launch)
     assert len(st.backward_plan(False)) > 0
 
 
