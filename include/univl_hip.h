@@ -217,7 +217,7 @@ typedef struct UnivlEmbedText {
     float p_post; uint64_t seed, off_post;
     const uint64_t* seed_dev;
     const float* dout;
-    float* dword; float* dpos; float* dtype_emb; float* dgamma; float* dbeta;
+    float* dword; float* dpos; float* dtype_emb; float* dgamma; float* dbeta;   /* dpos may be NULL when drows is given */
     /* optional [B*S, N]: store each token's word-table gradient row here INSTEAD of scatter-adding it into dword.  Under
      * data parallelism the dense table gradient (30522 x 768 fp32 = 94 MB, at most B*S non-zero rows) is then exchanged
      * as (ids, rows) and rebuilt by univl_embed_scatter on every rank. */
@@ -236,6 +236,10 @@ int univl_rows_zero(float* table, int64_t rows_total, const int64_t* list, const
 int univl_rows_append(const int64_t* ids, int32_t n, int64_t* list, int32_t cap, int32_t* meta, int32_t reset, uint8_t* ever,
                       int64_t rows_total, hipStream_t stream);
 int univl_rows_sumsq(const float* table, int64_t rows_total, const int64_t* list, const int32_t* meta, float* out, hipStream_t stream);
+/* out[s, c] += sum of rows[r, c] over r = s, s + period, s + 2 period, ... < n_rows (ascending, fixed order): the gradient of a
+ * [period, n] position table from per-token gradient rows (UnivlEmbedText.drows, UnivlLayerNorm.dx32) -- used instead of the fused
+ * kernels' scatter-add (dpos) from 32 rows per position on, where B atomics per table element dominate those kernels. */
+int univl_rows_gather_sum(const float* rows, int32_t n_rows, int32_t period, int32_t n, float* out, hipStream_t stream);
 /* dword[ids[t]] += scale * rows[t] for t < n (fp32 atomics; rows [n, 768]): the second half of the sparse exchange */
 int univl_embed_scatter(const int64_t* ids, const float* rows, int64_t n, float scale, float* dword, hipStream_t stream);
 

@@ -531,6 +531,19 @@ def test_pool_fwd_bwd(B, S):
         assert rel_err(dx2 - base, xr.grad) < 1e-4
 
 
+@pytest.mark.parametrize("rows,period,n", [(6144, 48, 768), (50, 7, 768), (3, 5, 1024), (128, 128, 768)])
+def test_rows_gather_sum(rows, period, n):
+    """univl_rows_gather_sum: out[s] += sum of rows[s::period] -- the position-table gradient from per-token rows."""
+    x = gen(rows, n, seed=1)
+    base = gen(period, n, seed=2)
+    out = base.clone().to(DEV)
+    ops.rows_gather_sum(x.to(DEV), period, out)
+    ref = base.double().clone()
+    for s_ in range(period):
+        ref[s_] += x[s_::period].double().sum(0)
+    assert rel_err(out, ref) < 1e-5
+
+
 @pytest.mark.parametrize("B,W,F", [(4, 48, 48), (6, 20, 300), (16, 48, 12)])
 def test_pool_pair_launches_and_similarity_backward_folded_in(B, W, F):
     """univl_pool_pair_fwd / _bwd: the text and the video pooling of one similarity head in one launch each way; the backward takes

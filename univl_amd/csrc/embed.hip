@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(UnivlEmbedText p, float*
                 const float dx = rstd * (dy[j][e] * ga[j][e] - s1 - xh[j][e] * s2);
                 if (p.drows) p.drows[(long)row * N + col + e] = dx;
                 else unsafeAtomicAdd(p.dword + id * N + col + e, dx);
-                if (!DET) unsafeAtomicAdd(p.dpos + (long)s * N + col + e, dx);
+                if (!DET && p.dpos) unsafeAtomicAdd(p.dpos + (long)s * N + col + e, dx);
                 // token types 0 / 1 (every row of a batch hits the same one or two table rows) are combined per
                 // block below; anything else goes straight to the table
                 if (p.dtype_emb && tt > 1) unsafeAtomicAdd(p.dtype_emb + tt * N + col + e, dx);
@@ -374,7 +374,8 @@ extern "C" int univl_embed_text_bwd(const UnivlEmbedText* d, hipStream_t stream)
     UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(d != nullptr, UNIVL_EINVAL, "univl_embed_text_bwd: null descriptor");
     UNIVL_CHECK_ARG(d->N == 768, UNIVL_EUNSUPPORTED, "univl_embed_text_bwd: N=%d (768 supported)", d->N);
-    UNIVL_CHECK_ARG(d->B > 0 && d->S > 0 && d->ids && d->dout && d->y && d->stats && d->gamma && d->dword && d->dpos &&
+    // dpos may be null when drows is given: the caller builds the position-table gradient from the rows itself (univl_rows_gather_sum)
+    UNIVL_CHECK_ARG(d->B > 0 && d->S > 0 && d->ids && d->dout && d->y && d->stats && d->gamma && d->dword && (d->dpos || d->drows) &&
                         d->dgamma && d->dbeta,
                     UNIVL_EINVAL, "univl_embed_text_bwd: null / empty argument");
     dim3 grid((d->B * d->S + 3) / 4), block(256);
@@ -391,7 +392,8 @@ extern "C" int univl_embed_text_bwd(const UnivlEmbedText* d, hipStream_t stream)
         hipLaunchKernelGGL(embed_bwd_kernel<true>, grid, block, 0, stream, q, part, counter);
         if (!d->drows)       // the caller wants the table gradient itself, not the per-token rows
             hipLaunchKernelGGL(embed_scatter_det_kernel, dim3((unsigned)T), block, 0, stream, d->ids, q.drows, T, 1.0f, d->dword);
-        hipLaunchKernelGGL(embed_dpos_gather_kernel, dim3((unsigned)(((long)d->S * N + 255) / 256)), block, 0, stream, q.drows, d->B, d->S, d->dpos);
+        if (d->dpos)
+            hipLaunchKernelGGL(embed_dpos_gather_kernel, dim3((unsigned)(((long)d->S * N + 255) / 256)), block, 0, stream, q.drows, d->B, d->S, d->dpos);
         if (d->dtype_emb)
             hipLaunchKernelGGL(embed_dtype_gather_kernel, dim3(N / 256, 2), block, 0, stream, d->type_ids, q.drows, T, d->dtype_emb);
         UNIVL_LAUNCH_CHECK();

@@ -250,9 +250,18 @@ __global__ __launch_bounds__(256) void ln_dpos_gather_kernel(const float* dx, in
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)period * n) return;
     const int s = (int)(i / n), c = (int)(i % n);
-    float acc = 0.f;
-    for (long r = s; r < rows; r += period) acc += dx[r * n + c];
-    dpos[i] += acc;
+    // four independent partial sums (rows s, s + period, s + 2 period, s + 3 period of every group of four), folded in a fixed
+    // order: four loads in flight per thread instead of one dependent add per row
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    long r = s;
+    const long p = period;
+    for (; r + 3 * p < rows; r += 4 * p) {
+        a0 += dx[r * n + c]; a1 += dx[(r + p) * n + c]; a2 += dx[(r + 2 * p) * n + c]; a3 += dx[(r + 3 * p) * n + c];
+    }
+    if (r < rows) a0 += dx[r * n + c];
+    if (r + p < rows) a1 += dx[(r + p) * n + c];
+    if (r + 2 * p < rows) a2 += dx[(r + 2 * p) * n + c];
+    dpos[i] += (a0 + a1) + (a2 + a3);
 }
 
 int check_common(const UnivlLayerNorm* d, const char* who) {
@@ -334,6 +343,18 @@ extern "C" int univl_layernorm_bwd(const UnivlLayerNorm* d, hipStream_t stream) 
         if (bf) hipLaunchKernelGGL((ln_bwd_kernel<1024, __bf16>), grid, block, 0, stream, *d, rpw);
         else hipLaunchKernelGGL((ln_bwd_kernel<1024, float>), grid, block, 0, stream, *d, rpw);
     }
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+// out[s, c] += sum over the rows r = s, s + period, ... of rows[r, c]  (r ascending; fixed order, no atomics): the position-table
+// gradient of an embedding layer from the per-token gradient rows.  With B rows per position the scatter-add of the fused backward
+// kernels puts B fp32 atomics on every element of a [period, n] table -- at 128 pairs that contention is most of those kernels
+// (embed_bwd 173 us, the video embedding's LayerNorm backward 189 us); the callers switch to this gather from 32 rows per position.
+extern "C" int univl_rows_gather_sum(const float* rows, int32_t n_rows, int32_t period, int32_t n, float* out, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    UNIVL_CHECK_ARG(rows && out && n_rows > 0 && period > 0 && n > 0, UNIVL_EINVAL, "univl_rows_gather_sum: bad argument");
+    hipLaunchKernelGGL(ln_dpos_gather_kernel, dim3((unsigned)(((long)period * n + 255) / 256)), dim3(256), 0, stream, rows, n_rows, period, n, out);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }

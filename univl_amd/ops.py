@@ -280,6 +280,12 @@ def embed_scatter(ids, rows, scale, dword):
     _lib.check(_lib.lib().univl_embed_scatter(_p(ids), _p(rows), ids.numel(), float(scale), _p(dword), _stream()), "embed_scatter")
 
 
+def rows_gather_sum(rows, period, out):
+    """out[s, :] += sum of rows[s::period, :] (fixed order); rows [n_rows, n] fp32, out [period, n] fp32 (a view of a table's first rows)."""
+    _require_gpu(rows, out)
+    _lib.check(_lib.lib().univl_rows_gather_sum(_p(rows), rows.shape[0], int(period), rows.shape[1], _p(out), _stream()), "rows_gather_sum")
+
+
 def sumsq_finish(partials, seg, start, count, out):
     _lib.check(_lib.lib().univl_sumsq_finish(_p(partials), _p(seg), _p(start), _p(count), seg.numel(), _p(out), _stream()),
                "sumsq_finish")

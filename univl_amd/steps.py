@@ -173,13 +173,26 @@ class EncoderPass:
                 self._video_tail(bwd, gs, self.vis.bwd_out)
         bwd.join(SV, ST)
 
+    # From this many rows per position the position-table gradients are built by a gather over the per-token gradient rows
+    # (univl_rows_gather_sum) instead of B atomics per table element inside the fused kernels (128 pairs: embed_bwd 173 us, the video
+    # embedding's LayerNorm backward 189 us -- profiles/r03q_bench_b128_kernel_stats.csv).  UNIVL_DPOS_GATHER_MIN=0: never.
+    DPOS_GATHER_MIN = int(os.environ.get("UNIVL_DPOS_GATHER_MIN", "32"))
+
+    def _gather_dpos(self):
+        return self.DPOS_GATHER_MIN > 0 and self.B >= self.DPOS_GATHER_MIN
+
     def _video_tail(self, bwd, gs, dxv):
         cx, n, fl, dt = self.cx, self.N, self.cx.fl, self.cx.dt
         W32, G, p, F, D, Tv, SV = fl.w32, fl.g, cx.p, self.F, self.D, self.Tv, self.SV
+        gather = self._gather_dpos()
+        if gather and getattr(self, "dxe", None) is None:
+            self.dxe = cx.e(Tv, H)                       # grad wrt the pre-LayerNorm sum = grad of the position rows
         bwd.add("univl_layernorm_bwd", ops.layernorm_desc(
             dt, Tv, H, gamma=W32(n["vlg"]), y=self.ve, stats=self.vest, dout=dxv, dxd16=self.de_op, dgamma=G(n["vlg"]),
-            dbeta=G(n["vlb"]), dbias=G(n["vb"]), dpos=G(n["vpos"]), pos_period=F, p_post=p, seed=cx.seed, off_post=self.off_v,
-            seed_dev=cx.seed_dev), SV)
+            dbeta=G(n["vlb"]), dbias=G(n["vb"]), dpos=None if gather else G(n["vpos"]), dx32=self.dxe if gather else None,
+            pos_period=F, p_post=p, seed=cx.seed, off_post=self.off_v, seed_dev=cx.seed_dev), SV)
+        if gather:
+            bwd.add_callable(lambda: ops.rows_gather_sum(self.dxe, F, G(n["vpos"])[:F]), SV)
         bwd.add("univl_gemm", _gemm_desc(dt, self.de_op, H, self.vn_op, D, H, D, Tv, trans_a=1, trans_b=1, out32=G(n["vw"]),
                                          ldc=D, accumulate=gs.acc(n["vw"])), SV)
         bwd.add("univl_gemm", _gemm_desc(dt, self.de_op, H, fl.wop(n["vw"]), D, Tv, D, H, trans_b=1, out32=self.dvnorm, ldc=D,
@@ -191,13 +204,20 @@ class EncoderPass:
         cx, n, fl, dt = self.cx, self.N, self.cx.fl, self.cx.dt
         W32, G, p, B, W, ST = fl.w32, fl.g, cx.p, self.B, self.W, self.ST
         sparse = getattr(self, "sparse_word_grad", False)
-        if sparse and getattr(self, "drows", None) is None:
+        gather = self._gather_dpos()
+        if (sparse or gather) and getattr(self, "drows", None) is None:
             self.drows = cx.e(self.Tt, H)
         bwd.add("univl_embed_text_bwd", ops.embed_text_desc(
             dt, B, W, self.ids, W32(n["bw"]), W32(n["bp"]), W32(n["blg"]), W32(n["blb"]), type_ids=self.type_ids,
             type_emb=W32(n["bt"]), y=self.te, stats=self.test, p_post=p, seed=cx.seed, off_post=self.off_t,
-            seed_dev=cx.seed_dev, dout=dxt, dword=G(n["bw"]), dpos=G(n["bp"]), dtype_emb=G(n["bt"]), dgamma=G(n["blg"]),
-            dbeta=G(n["blb"]), drows=self.drows if sparse else None), ST)
+            seed_dev=cx.seed_dev, dout=dxt, dword=G(n["bw"]), dpos=None if gather else G(n["bp"]), dtype_emb=G(n["bt"]),
+            dgamma=G(n["blg"]), dbeta=G(n["blb"]), drows=self.drows if (sparse or gather) else None), ST)
+        if gather:
+            # the per-token rows: position table by the gather; word table by the scatter kernel (few rows share an id) unless the
+            # data-parallel exchange takes the rows themselves
+            bwd.add_callable(lambda: ops.rows_gather_sum(self.drows, W, G(n["bp"])[:W]), ST)
+            if not sparse:
+                bwd.add_callable(lambda: ops.embed_scatter(self.ids.view(-1), self.drows, 1.0, G(n["bw"])), ST)
         rows = getattr(self, "word_rows", None)
         if rows is not None and not sparse:            # remember which table rows this backward wrote (engine.FlatParams.word_rows)
             lst, meta, reset = rows
