@@ -377,7 +377,7 @@ int univl_bert_adam(const UnivlAdam* d, hipStream_t stream);
  * applies the update layer by layer next to the following forward pass (univl_amd/graphed.py). */
 int univl_bert_adam_range(const UnivlAdam* d, int32_t chunk_begin, int32_t chunk_count, int32_t do_prep, int32_t max_blocks,
                           hipStream_t stream);
-/* EXPERIMENTAL.  A forward product (both operands K-major, bf16, 64 x 64 tiles) and chunks [chunk_begin, +chunk_count) of a
+/* (Round 3: validated bit-exact against the sequential loop and the default of the captured step.)  A forward product (both operands K-major, bf16, 64 x 64 tiles) and chunks [chunk_begin, +chunk_count) of a
  * prepared BertAdam update (univl_bert_adam_range with do_prep ran before) in ONE launch: the update of step t rides with the
  * forward of step t + 1 (univl_amd/graphed.py).  Products the kernel does not carry are launched the ordinary way, followed by
  * the chunk range as its own launch -- same result.  max_blocks > 0 caps the workgroups given to the update. */

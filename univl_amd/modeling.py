@@ -431,7 +431,7 @@ class UniVL(UniVLPreTrainedModel):
         self._steps = {}
         self._param_events = {}        # filled by a pipelined optimizer update in flight (univl_amd.graphed)
         self._pending_update = None    # the optimizer holding a deferred update, if any
-        self._rider_update = None      # EXPERIMENTAL (UNIVL_ADAM_RIDE): dict(desc, groups, max_blocks) of a prepared BertAdam update
+        self._rider_update = None      # riding optimizer update (graphed.GraphedTrainStep): dict(desc, groups, max_blocks) of a prepared BertAdam update
                                        # that THIS forward applies -- prologue launches + riders of its forward products
         self._in_pipelined_call = False
         self._reducer = None
@@ -728,7 +728,7 @@ class UniVL(UniVLPreTrainedModel):
             st.fwd.riders = None
 
     def _start_riding_update(self, st, ru):
-        """EXPERIMENTAL (UNIVL_ADAM_RIDE, univl_amd.graphed): the BertAdam update of the previous iteration is applied BY this
+        """Riding optimizer update (univl_amd.graphed, UNIVL_ADAM_RIDE): the BertAdam update of the previous iteration is applied BY this
         forward -- chunk groups the forward plan cannot carry (embedding tables, vectors, the first layer of each stack, the
         cross encoder / decoder) as ordinary launches on the calling stream right now, the others as extra workgroups of the
         forward products of the layer before (engine.Plan.add_gemm_rider)."""
