@@ -3,7 +3,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-OUT=gpurun_out/r03k
+OUT=gpurun_out/${OUTDIR:-r03k}
 mkdir -p $OUT
 run() { local name=$1; shift
   timeout 120 python bench.py --steps 60 --warmup 10 --no-cpu-baseline "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err
