@@ -106,7 +106,8 @@ typedef struct UnivlGemm {
     float alpha;
     int32_t flags;
     int32_t ksplit;        /* >1: split the contraction over gridDim.z, fp32 atomics into pre-zeroed C32 */
-    int32_t tile;          /* 0 auto; 64 (64x64, 4 waves), 128 (128x128, 4 waves), 256 (256x128, 8 waves; bf16, else 128) */
+    int32_t tile;          /* 0 auto; 64 (64x64, 4 waves), 128 (128x128, 4 waves), 256 (256x128, 8 waves; bf16, else 128);
+                            * 12864 / 64128 (128x64 / 64x128; bf16, K-major A, no sumsq / dbias, univl_gemm only -- else 128) */
     /* optional, no split-K: every wave stores the sum of squares of the FINAL values it wrote to
      *   sumsq[(m0 / sumsq_rows) * sumsq_stride + (((m0 % sumsq_rows) / tile) * tiles_x + tile_x) * waves + wave]
      * (sumsq_rows = 0: the whole output is one tensor).  Partial sums, no atomics: thousands of workgroups adding to one

@@ -229,6 +229,47 @@ def test_gemm_ring_and_wide_tile_forward_dgrad(M, N, K):
             assert torch.equal(out, dbase), ("dgrad", tile, stages, waves, rep, float((out - dbase).abs().max()))
 
 
+@pytest.mark.parametrize("M,N,K", [(6144, 768, 3072), (700, 1000, 768), (300, 264, 100), (130, 70, 64)])
+def test_gemm_half_width_tiles_forward_dgrad(M, N, K):
+    """UnivlGemm.tile = 12864 / 64128 (128 x 64 and 64 x 128 tiles on 4 or 8 waves; opt-in, UNIVL_GEMM_RECT): BIT-identical to the
+    128 tile (same 64-deep K steps, same chunk order per output element) for the two layouts they serve -- forward
+    (K-major x K-major, bias, fp32 + bf16 outputs) and dgrad (K-major x T-major, fp32 residual); a weight-gradient
+    descriptor (T-major A) falls back to the 128 tile."""
+    dtype = torch.bfloat16
+    Kp, Np, ldc = (K + 7) // 8 * 8, (N + 7) // 8 * 8, (N + 7) // 8 * 8
+    A = torch.zeros(M, Kp); A[:, :K] = gen(M, K, seed=1)
+    B = torch.zeros(N, Kp); B[:, :K] = gen(N, K, seed=2, scale=0.05)
+    bias = gen(N, seed=3).to(DEV)
+    Ad, Bd = A.to(DEV, dtype), B.to(DEV, dtype)
+    base = torch.zeros(M, ldc, device=DEV)
+    base16 = torch.zeros(M, ldc, device=DEV, dtype=dtype)
+    ops.gemm(Ad, Bd, M, N, K, out32=base, out16=base16, bias=bias, tile=128, stages=2, waves=4)
+    assert rel_err(base[:, :N], Ad.double().cpu()[:, :K] @ Bd.double().cpu()[:, :K].T + bias.double().cpu()) < 2e-3
+    dY = torch.zeros(M, Np); dY[:, :N] = gen(M, N, seed=4)
+    dYd = dY.to(DEV, dtype)
+    Wd = torch.zeros(Np, Kp, device=DEV, dtype=dtype); Wd[:N] = Bd
+    res = gen(M, Kp, seed=5).to(DEV)
+    dbase = torch.zeros(M, Kp, device=DEV)
+    ops.gemm(dYd, Wd, M, Kp, N, trans_b=True, out32=dbase, residual=res, tile=128, stages=2, waves=4)
+    for tile in (12864, 64128):
+        for waves in (8, 4):
+            for rep in range(2):
+                out = torch.zeros(M, ldc, device=DEV)
+                o16 = torch.zeros(M, ldc, device=DEV, dtype=dtype)
+                ops.gemm(Ad, Bd, M, N, K, out32=out, out16=o16, bias=bias, tile=tile, waves=waves)
+                assert torch.equal(out, base), ("forward", tile, waves, rep, float((out - base).abs().max()))
+                assert torch.equal(o16, base16), ("forward bf16", tile, waves, rep)
+                out = torch.zeros(M, Kp, device=DEV)
+                ops.gemm(dYd, Wd, M, Kp, N, trans_b=True, out32=out, residual=res, tile=tile, waves=waves)
+                assert torch.equal(out, dbase), ("dgrad", tile, waves, rep, float((out - dbase).abs().max()))
+        # T-major A: served by the 128 tile
+        wg = torch.zeros(N, Kp, device=DEV)
+        wb = torch.zeros(N, Kp, device=DEV)
+        ops.gemm(dYd, Ad, N, Kp, M, trans_a=True, trans_b=True, out32=wb, tile=128, stages=2, waves=4)
+        ops.gemm(dYd, Ad, N, Kp, M, trans_a=True, trans_b=True, out32=wg, tile=tile)
+        assert torch.equal(wg, wb), ("wgrad fallback", tile)
+
+
 @pytest.mark.parametrize("T", [192, 1000, 6144])
 def test_gemm_ring_and_wide_tile_wgrad(T):
     """Weight-gradient layout (both operands T-major) with the fused bias gradient, accumulate, the per-tensor sum of squares

@@ -513,8 +513,10 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz, int gm) {
     xcd_tile_grid(gridDim.x, gridDim.y, gridDim.z, gm, bx, by, bz);
 }
 
+// (hipcc: the second launch bound is WAVES PER SIMD.)  The half-width tiles (128 x 64 / 64 x 128, 48 KB of LDS) are built for THREE
+// resident workgroups per compute unit: 6 waves per SIMD (<= 80 VGPRs) on 8 waves, 3 on 4 waves.
 template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC, int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmArgs p) {
+__global__ __launch_bounds__(64 * WGM * WGN, (BM != BN && BM * BN == 128 * 64) ? (WGM * WGN == 8 ? 6 : 3) : 2) void gemm_kernel(GemmArgs p) {
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (p.flags & UNIVL_GEMM_XCD_MAP) xcd_tile(bx, by, bz, p.gm);
     gemm_tile<T, TA, TB, BM, BN, D, NC, 0, WGM, WGN>(p, bx, by, bz, gridDim.z);
@@ -733,12 +735,19 @@ __global__ __launch_bounds__(256) void dot_kernel(GemmArgs p) {
 //   128  128 x 128, 4 waves, BK = 64        -- two workgroups per compute unit
 //   256  256 x 128, 8 waves (4 x 2), BK = 64, bf16 only -- 85 flop per staged byte instead of 64; one workgroup per compute
 //        unit, which is what the three-stage ring is for
+//   12864 / 64128  128 x 64 / 64 x 128, 8 waves, BK = 64, bf16, K-major A (forward / dgrad), no sumsq / dbias, univl_gemm only
+//        (else 128): 48 KB of LDS and <= 80 VGPRs, i.e. THREE workgroups per compute unit (768 slots) instead of two (512).
+//        Picked instead of the 128 tile where it fills its slots better (UNIVL_GEMM_RECT = 2 | 1: 64 x 128 | 128 x 64, 0: never):
+//        a 6144 x 768 output is 288 tiles of 128 x 128 in 512 slots -- 32 units run two workgroups, 224 run one -- but 576 half
+//        tiles in 768 slots; 6144 x 3072 is 2.25 rounds of 512 slots against exactly 3 rounds of 768; 6144 x 2304 (1.69 rounds
+//        against 2.25) stays on the 128 tile.  Per-shape table at 6144 rows: profiles/r03u_gemm_variants_b128.txt (+3..13 % per
+//        product where picked; bit-identical results: same 64-deep K steps, same chunk order per output element).
 // stages = 2: the double-buffered loop; 3: ring with counted waits (bf16 only).  waves = 4 | 8 (tiles 64 / 128, bf16 only).
 struct Choice { int tile, nc, stages, waves; };
 
 static inline long env_long(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
 
-static Choice choose(const UnivlGemm* d, int forced_tile, int forced_nc = 0) {
+static Choice choose(const UnivlGemm* d, int forced_tile, int forced_nc = 0, bool allow_rect = false) {
     static const long big_min = env_long("UNIVL_GEMM_BIG_MIN", 256L);
     static const long t256_min = env_long("UNIVL_GEMM_T256_MIN", 0L);              // 0: never picked automatically
     static const int stages_dflt = (int)env_long("UNIVL_GEMM_STAGES", 2L);         // tiles 64 / 128
@@ -748,8 +757,32 @@ static Choice choose(const UnivlGemm* d, int forced_tile, int forced_nc = 0) {
     const int want = forced_tile ? forced_tile : d->tile;
     const long tiles128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
     const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 127) / 128);
+    static const int rect = (int)env_long("UNIVL_GEMM_RECT", 2L);                  // 0 off | 1: 128 x 64 | 2: 64 x 128
+    const bool rect_ok = allow_rect && bf16 && !d->trans_a && !d->sumsq && !d->dbias;      // univl_gemm only (single launch)
     Choice c;
+    if (want == 12864 || want == 64128) {
+        c.tile = rect_ok ? want : 128;
+        c.nc = 2;
+        c.stages = 2;
+        c.waves = !rect_ok ? 4 : (d->waves ? d->waves : 8);
+        return c;
+    }
     c.tile = (want >= 128 || (want == 0 && tiles128 >= big_min)) ? 128 : 64;
+    if (rect && want == 0 && c.tile == 128 && rect_ok && d->stages == 0 && d->waves == 0) {
+        // fill of the resident-workgroup slots in the last round: tiles / (rounds x slots)
+        const long tiles_r = rect == 2 ? (long)((d->M + 63) / 64) * ((d->N + 127) / 128) : (long)((d->M + 127) / 128) * ((d->N + 63) / 64);
+        const double fill128 = (double)tiles128 / (double)(((tiles128 + 511) / 512) * 512);
+        const double fill_r = (double)tiles_r / (double)(((tiles_r + 767) / 768) * 768);
+        // measured (6144 rows): with T-major B (dgrad) the half tile wins at equal fill and above; with K-major B (forward) it
+        // needs a clear fill advantage (0.75 vs 0.84: -7 %; 1.0 vs 0.75: +1 %; 0.75 vs 0.56: +3..9 %)
+        if (fill_r >= fill128 * (d->trans_b ? 1.0 : 1.2)) {
+            c.tile = rect == 2 ? 64128 : 12864;
+            c.nc = 2;
+            c.stages = 2;
+            c.waves = 8;
+            return c;
+        }
+    }
     if (bf16 && (want == 256 || (want == 0 && c.tile == 128 && t256_min > 0 && tiles256 >= t256_min))) c.tile = 256;
     if (c.tile == 256 && d->sumsq && d->sumsq_rows % 256 != 0) c.tile = 128;     // a tile must not straddle two tensors
     c.nc = c.tile == 64 ? 4 : 2;
@@ -773,12 +806,13 @@ static Choice choose(const UnivlGemm* d, int forced_tile, int forced_nc = 0) {
     return c;
 }
 
-static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int forced_tile = 0, int forced_nc = 0) {
+static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int forced_tile = 0, int forced_nc = 0, bool allow_rect = false) {
     UNIVL_CHECK_ARG(d != nullptr, UNIVL_EINVAL, "univl_gemm: null descriptor");
     UNIVL_CHECK_ARG(d->dtype == UNIVL_F32 || d->dtype == UNIVL_BF16, UNIVL_EUNSUPPORTED, "univl_gemm: dtype %d", d->dtype);
     UNIVL_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, UNIVL_EINVAL, "univl_gemm: empty problem %dx%dx%d", d->M, d->N, d->K);
     UNIVL_CHECK_ARG(d->A && d->B && (d->C32 || d->C16), UNIVL_EINVAL, "univl_gemm: null operand");
-    UNIVL_CHECK_ARG(d->tile == 0 || d->tile == 64 || d->tile == 128 || d->tile == 256, UNIVL_EINVAL, "univl_gemm: tile %d (0, 64, 128, 256)", d->tile);
+    UNIVL_CHECK_ARG(d->tile == 0 || d->tile == 64 || d->tile == 128 || d->tile == 256 || d->tile == 12864 || d->tile == 64128, UNIVL_EINVAL,
+                    "univl_gemm: tile %d (0, 64, 128, 256, 12864, 64128)", d->tile);
     UNIVL_CHECK_ARG(d->stages == 0 || d->stages == 2 || d->stages == 3, UNIVL_EINVAL, "univl_gemm: stages %d (0, 2, 3)", d->stages);
     UNIVL_CHECK_ARG(d->waves == 0 || d->waves == 4 || d->waves == 8, UNIVL_EINVAL, "univl_gemm: waves %d (0, 4, 8)", d->waves);
     const int epc = d->dtype == UNIVL_BF16 ? 8 : 4;
@@ -791,7 +825,7 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int 
     // tile choice: 128x128 once the grid fills the chip (>= 256 tiles, measured: +6 % at bs 128 over 384, same at bs 16), else
     // 64x64 for parallelism.  The small tile stages 4 chunks (128 bf16 / 64 f32) per barrier: at M <= a few hundred the kernel
     // is a latency chain of K steps (DMA -> barrier -> ds_read -> MFMA), so fewer, deeper steps win.
-    c = choose(d, forced_tile, forced_nc);
+    c = choose(d, forced_tile, forced_nc, allow_rect);
     // deterministic mode (common.h): no split-K -- the slices of a split product meet in fp32 atomics whose order is the hardware's;
     // one workgroup per output tile walks the whole contraction in order (the pre-zeroed arena is simply overwritten)
     ksplit = (d->ksplit < 1 || univl_deterministic()) ? 1 : d->ksplit;
@@ -841,7 +875,7 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
     GemmArgs a;
     int ksplit;
     Choice c;
-    const int rc = prepare(d, a, ksplit, c);
+    const int rc = prepare(d, a, ksplit, c, 0, 0, true);
     if (rc != UNIVL_OK) return rc;
     if (d->dtype == UNIVL_F32 && !d->trans_a && !d->trans_b && d->M <= 32 && d->N <= 32 && ksplit == 1 && d->tile == 0 &&
         !d->bias && !d->R && !d->dbias && !d->sumsq && !(d->flags & (UNIVL_GEMM_GELU_FWD | UNIVL_GEMM_GELU_BWD))) {
@@ -854,6 +888,16 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
         if (c.tile == 256) {
             if (c.stages == 3) return dispatch_trans<__bf16, 256, 128, 3, 2, 4, 2>(a, ta, tb, ksplit, stream);
             return dispatch_trans<__bf16, 256, 128, 2, 2, 4, 2>(a, ta, tb, ksplit, stream);
+        }
+        if (c.tile == 12864) {                       // K-major A only (choose): forward and dgrad products
+            if (c.waves == 8) return tb ? launch<__bf16, false, true, 128, 64, 2, 2, 4, 2>(a, ksplit, stream)
+                                        : launch<__bf16, false, false, 128, 64, 2, 2, 4, 2>(a, ksplit, stream);
+            return tb ? launch<__bf16, false, true, 128, 64, 2, 2, 2, 2>(a, ksplit, stream) : launch<__bf16, false, false, 128, 64, 2, 2, 2, 2>(a, ksplit, stream);
+        }
+        if (c.tile == 64128) {
+            if (c.waves == 8) return tb ? launch<__bf16, false, true, 64, 128, 2, 2, 2, 4>(a, ksplit, stream)
+                                        : launch<__bf16, false, false, 64, 128, 2, 2, 2, 4>(a, ksplit, stream);
+            return tb ? launch<__bf16, false, true, 64, 128, 2, 2, 2, 2>(a, ksplit, stream) : launch<__bf16, false, false, 64, 128, 2, 2, 2, 2>(a, ksplit, stream);
         }
         if (c.tile == 128 && c.waves == 8) {
             if (c.stages == 3) return dispatch_trans<__bf16, 128, 128, 3, 2, 2, 4>(a, ta, tb, ksplit, stream);
@@ -1000,6 +1044,24 @@ extern "C" int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_block
             }
         }
     }
+    // UNIVL_GEMM_GROUP_T256_MINK = k (0: never): a group of bf16 weight-gradient products (both operands T-major) whose contractions
+    // are all at least k deep takes the 256 x 128 tile on the three-stage ring.  A layer's four weight gradients at 6144 tokens are
+    // 1728 tiles of 64 x 64, each pulling 2 x 6144 x 64 x 2 B = 1.5 MB of operand panels through the L2 (2.7 GB per layer and
+    // launch), with 6 transpose reads per 2 MFMAs per wave; they are 216 tiles of 256 x 128 (one round on 256 compute units, 96 K
+    // steps each -- the regime the tile and the ring were built for) pulling 1.0 GB with 16 reads per 16 MFMAs.
+    static const long group_t256_mink = env_long("UNIVL_GEMM_GROUP_T256_MINK", 0L);
+    if (group_t256_mink > 0 && tile_all == 64 && d[0].dtype == UNIVL_BF16 && d[0].trans_a && d[0].trans_b) {
+        bool deep = true;
+        for (int i = 0; i < n; ++i)
+            deep = deep && d[i].K >= group_t256_mink && d[i].tile == 0 && d[i].ksplit <= 1 && !(d[i].sumsq && d[i].sumsq_rows % 256 != 0);
+        if (deep) {
+            tile_all = 256; stages_all = 3; waves_all = 8;
+            for (int i = 0; i < n; ++i) {
+                const Choice ci = choose(&d[i], 256);
+                stages_all = ci.stages < stages_all ? ci.stages : stages_all;
+            }
+        }
+    }
     // Weight gradients over thousands of tokens on the 64 tile (the members are too small for the 128 tile): 64-deep K steps, four
     // workgroups per compute unit.  Measured at 128 pairs x 48 tokens (profiles/r03i_ab_summary.txt): 13.55 / 13.49 vs 14.01 / 14.04 ms
     // per step.  UNIVL_GEMM_NC64_MIN: contraction length from which it applies (0: never).
@@ -1008,6 +1070,16 @@ extern "C" int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_block
     if (nc64_min > 0 && tile_all == 64 && d[0].dtype == UNIVL_BF16 && d[0].trans_a && d[0].trans_b) {
         forced_nc = 2;
         for (int i = 0; i < n; ++i) if (d[i].K < nc64_min || (d[i].ksplit > 1)) forced_nc = 0;
+        // ... on 4 waves (2 x 2, a 32 x 32 sub-tile each: 4 transpose-read fragments per 4 MFMAs) instead of 8 (32 x 16: 3 per 2):
+        // isolated, a layer's group at 6144 tokens runs 231 vs 286 us (profiles/r03w_gemm_group_variants_b128.txt)
+        // (the single-GPU step always ran this group on 4 waves -- its fused sum of squares asks for them; this is the same choice
+        // for the data-parallel and pretrain plans, whose weight gradients carry no sum of squares)
+        static const long nc64_waves = env_long("UNIVL_GEMM_NC64_WAVES", 4L);
+        if (forced_nc == 2 && nc64_waves == 4) {
+            bool plain = true;
+            for (int i = 0; i < n; ++i) plain = plain && d[i].waves == 0;
+            if (plain) waves_all = 4;
+        }
     }
     int total = 0, nc_all = 0;
     const int bm = tile_all, bn = tile_all == 256 ? 128 : tile_all;
