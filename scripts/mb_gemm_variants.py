@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--rows", default="192,768,6144")
     ap.add_argument("--out", default="gpurun_out/mb_gemm_variants.json")
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
+    ap.add_argument("--group-dbias", type=int, default=1, help="0: the grouped weight gradients without the fused bias gradients")
     ap.add_argument("--group-rows", type=int, default=0, help="also time one layer's four weight gradients as a grouped launch over this many tokens")
     ap.add_argument("--variants", default="", help="e.g. 128/2/8,12864/2/8 (default: all)")
     ap.add_argument("--check", type=int, default=1, help="compare every variant's result with torch.matmul once")
@@ -115,7 +116,7 @@ def main():
     if a.group_rows:
         # a layer's four weight-gradient products as ONE grouped launch (what the backward plan issues), contraction over T tokens
         T = a.group_rows
-        print("grouped weight gradients of one layer, T = %d tokens" % T)
+        print("grouped weight gradients of one layer, T = %d tokens, fused bias gradients: %d" % (T, a.group_dbias))
         dYs = {n_: [torch.randn(T, N, device=DEV).to(bf) for _ in range(2)] for n_, N, K in LINEAR}
         Xs = {n_: [torch.randn(T, K, device=DEV).to(bf) for _ in range(2)] for n_, N, K in LINEAR}
         dWs = {n_: torch.zeros(N, K, device=DEV) for n_, N, K in LINEAR}
@@ -125,7 +126,7 @@ def main():
         for tile, stages, waves in [(0, 0, 0)] + [v for v in VARIANTS if v[0] <= 256]:
             def fn(i, tile=tile, stages=stages, waves=waves):
                 ops.gemm_group([ops.gemm_desc(dYs[n_][i % 2], Xs[n_][i % 2], N, K, T, trans_a=True, trans_b=True, out32=dWs[n_],
-                                              dbias=dbs[n_] if n_ in ("qkv", "ffn1") else None, tile=tile, stages=stages, waves=waves)
+                                              dbias=dbs[n_] if (a.group_dbias and n_ in ("qkv", "ffn1")) else None, tile=tile, stages=stages, waves=waves)
                                 for n_, N, K in LINEAR])
             try:
                 us = time_graph(fn)

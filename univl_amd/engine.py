@@ -546,7 +546,7 @@ class Plan:
 
 def _gemm_desc(dt, A, lda, B, ldb, M, N, K, *, trans_a=0, trans_b=0, out32=None, out16=None, ldc=0, bias=None,
                residual=None, ldr=0, aux=None, ldaux=0, gelu=None, accumulate=False, dbias=None, ksplit=1, tile=0,
-               sumsq=None, sumsq_rows=0, sumsq_stride=0, nt_out=False):
+               sumsq=None, sumsq_rows=0, sumsq_stride=0, nt_out=False, stages=0, waves=0):
     d = _lib.Gemm()
     d.dtype, d.trans_a, d.trans_b, d.M, d.N, d.K = dt, trans_a, trans_b, M, N, K
     d.A, d.lda, d.B, d.ldb = A.data_ptr(), lda, B.data_ptr(), ldb
@@ -569,6 +569,7 @@ def _gemm_desc(dt, A, lda, B, ldb, M, N, K, *, trans_a=0, trans_b=0, out32=None,
         flags |= _lib.GEMM_GELU_BWD
     d.flags, d.ksplit, d.tile = flags, ksplit, tile
     d.sumsq, d.sumsq_rows, d.sumsq_stride = (sumsq.data_ptr() if sumsq is not None else None), sumsq_rows, sumsq_stride
+    d.stages, d.waves = stages, waves
     return d
 
 
@@ -754,6 +755,14 @@ class EncoderStack:
         if self.ks_h > 1 and zero_arena:
             plan.add_callable(self.garena.zero_, stream=sm)
         sw = self.sw
+        # Weight gradients over thousands of tokens (UNIVL_WGRAD_BIG_MIN, bf16): the layer's grouped launch on the 128 x 128 tile
+        # (two stages, 4 waves) with the two bias gradients it used to carry on a column-sum kernel instead.  The column-0
+        # workgroups of a product with a fused bias gradient walk their staged A tile element by element every K step; with
+        # a deep contraction they are the stragglers the whole launch waits for -- isolated at 6144 tokens a layer's group runs
+        # 231 us (64 tile, fused bias gradients, the former plan), 185 us (64 tile without them), 138 us (128 tile, 2 stages,
+        # 4 waves, without them): profiles/r03w_gemm_group_variants_b128.txt, r03y2_gemm_group_variants_nodbias_b128.txt.
+        big_wgrad = self.bf and T >= int(os.environ.get("UNIVL_WGRAD_BIG_MIN", "2048"))
+        wg_tile = dict(tile=128, stages=2, waves=4) if big_wgrad else {}
         for l in range(self.L - 1, -1, -1):
             ws, nm = self.layers[l], self._names(l)
             xin32, xin16 = (x0_32, x0_16) if l == 0 else (self.layers[l - 1]["o32"], self.layers[l - 1]["o16"])
@@ -780,17 +789,17 @@ class EncoderStack:
                     wgrads.append(wgrad)
 
             w_ffn2 = _gemm_desc(dt, s_dxd, H, ws["f"], I, H, I, T, trans_a=1, trans_b=1,
-                                out32=fl.g(nm["w2"]), ldc=I, accumulate=gs.acc(nm["w2"]), nt_out=self.nt_wgrad, **gs.sumsq_args(nm["w2"], H, I))
+                                out32=fl.g(nm["w2"]), ldc=I, accumulate=gs.acc(nm["w2"]), nt_out=self.nt_wgrad, **wg_tile, **gs.sumsq_args(nm["w2"], H, I))
             emit(_gemm_desc(dt, s_dxd, H, fl.wop(nm["w2"]), I, T, I, H, trans_b=1, out16=s_du,
                             ldc=I, aux=ws["u"], ldaux=I, gelu="bwd"), w_ffn2)
             # Bias gradients of the two projections whose upstream gradient no LayerNorm kernel sees (FFN1, QKV): column sums of
             # du / dqkv, taken by the weight-gradient GEMM from the operand tiles it stages anyway.  UNIVL_DBIAS_COLSUM_MIN = n:
             # from n tokens on a separate column-sum kernel instead (measured at 6144 tokens, round 3: 13.88 / 13.93 vs 13.92 ms
             # per step -- the per-thread LDS walk of the column-0 workgroups is not what bounds that product; off).
-            sep_dbias = T >= int(os.environ.get("UNIVL_DBIAS_COLSUM_MIN", "1000000000"))
+            sep_dbias = big_wgrad or T >= int(os.environ.get("UNIVL_DBIAS_COLSUM_MIN", "1000000000"))
             w_ffn1 = _gemm_desc(dt, s_du, I, ws["a16"], H, I, H, T, trans_a=1, trans_b=1,
                                 out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=None if sep_dbias else fl.g(nm["b1"]),
-                                nt_out=self.nt_wgrad, **gs.sumsq_args(nm["w1"], I, H))
+                                nt_out=self.nt_wgrad, **wg_tile, **gs.sumsq_args(nm["w1"], I, H))
             if sep_dbias:
                 plan.add_callable(lambda _du=s_du, _g=fl.g(nm["b1"]): ops.colsum(_du, _g), sm)
             emit(_gemm_desc(dt, s_du, I, fl.wop(nm["w1"]), H, T, H, I, trans_b=1, out32=da, ldc=H,
@@ -802,7 +811,7 @@ class EncoderStack:
                 dgamma=fl.g(nm["ln1_g"]), dbeta=fl.g(nm["ln1_b"]), dbias=fl.g(nm["o_b"]), p_pre=p, off_pre=ws["off"][1],
                 seed_dev=self.seed_dev), sm)
             w_o = _gemm_desc(dt, s_dxd2, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
-                             out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"]), nt_out=self.nt_wgrad, **gs.sumsq_args(nm["o_w"], H, H))
+                             out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"]), nt_out=self.nt_wgrad, **wg_tile, **gs.sumsq_args(nm["o_w"], H, H))
             emit(_gemm_desc(dt, s_dxd2, H, fl.wop(nm["o_w"]), H, T, H, H, trans_b=1, out16=self.dctx, ldc=H), w_o)
             qkv, dqkv = ws["qkv"], s_dqkv
             plan.add("univl_attention_bwd", ops.attention_desc(
@@ -811,7 +820,7 @@ class EncoderStack:
                 dq=(dqkv, 0), lddq=3 * H, dk=(dqkv, H), lddk=3 * H, dv=(dqkv, 2 * H), lddv=3 * H), sm)
             w_qkv = _gemm_desc(dt, dqkv, 3 * H, xin16, H, 3 * H, H, T, trans_a=1, trans_b=1,
                                out32=fl.g_fused(nm["qkv_w"]), ldc=H, accumulate=gs.acc(nm["qkv_w"][0]),
-                               dbias=None if sep_dbias else fl.g_fused(nm["qkv_b"]), nt_out=self.nt_wgrad,
+                               dbias=None if sep_dbias else fl.g_fused(nm["qkv_b"]), nt_out=self.nt_wgrad, **wg_tile,
                                **gs.sumsq_args(nm["qkv_w"], H, H))
             if sep_dbias:
                 plan.add_callable(lambda _d=dqkv, _g=fl.g_fused(nm["qkv_b"]): ops.colsum(_d, _g.view(-1)), sm)
