@@ -752,6 +752,12 @@ def test_tanh_gelu_simdense_colsum(dtype):
     cs = torch.ones(1024, device=DEV)
     ops.colsum(m, cs)
     assert rel_err(cs, m.double().cpu().sum(0) + 1) < 1e-5
+    big = gen(777, 1040, seed=9).to(DEV, dtype)            # 16-byte path on a strided view, rows not a multiple of anything; then the
+    for lo, hi in ((8, 1008), (3, 1003)):                  # element-per-lane fallback on a misaligned one
+        view = big[:, lo:hi]
+        cs = torch.full((hi - lo,), 2.0, device=DEV)
+        ops.colsum(view, cs)
+        assert rel_err(cs, view.double().cpu().sum(0) + 2) < 1e-5, (lo, hi)
     z = gen(50, 64, seed=8).to(DEV, dtype)
     ref = z.double().cpu() * 0.25
     ops.scale_ct(z, torch.tensor([0.25], device=DEV))

@@ -777,7 +777,7 @@ class EncoderStack:
                 dt, T, H, gamma=fl.w32(nm["ln2_g"]), y=ws["y2"], stats=ws["st2"], dout=gin, dx32=dz, dxd16=s_dxd,
                 dgamma=fl.g(nm["ln2_g"]), dbeta=fl.g(nm["ln2_b"]), dbias=fl.g(nm["b2"]), p_pre=p, off_pre=ws["off"][2],
                 seed_dev=self.seed_dev), sm)
-            wgrads = []
+            wgrads, colsums = [], []         # colsums: bias gradients off the chain, issued wherever the layer's weight gradients go
 
             def emit(dgrad, wgrad):
                 """dgrad on the chain; its weight-gradient twin either into the layer's grouped launch (default) or into the
@@ -801,7 +801,7 @@ class EncoderStack:
                                 out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=None if sep_dbias else fl.g(nm["b1"]),
                                 nt_out=self.nt_wgrad, **wg_tile, **gs.sumsq_args(nm["w1"], I, H))
             if sep_dbias:
-                plan.add_callable(lambda _du=s_du, _g=fl.g(nm["b1"]): ops.colsum(_du, _g), sm)
+                colsums.append(lambda _du=s_du, _g=fl.g(nm["b1"]): ops.colsum(_du, _g))
             emit(_gemm_desc(dt, s_du, I, fl.wop(nm["w1"]), H, T, H, I, trans_b=1, out32=da, ldc=H,
                             residual=dz, ldr=H, ksplit=self.ksplit_for(I)), w_ffn1)
             # attention-output LayerNorm / dropout backward (BertSelfOutput, module_bert.py:207-211)
@@ -823,17 +823,19 @@ class EncoderStack:
                                dbias=None if sep_dbias else fl.g_fused(nm["qkv_b"]), nt_out=self.nt_wgrad, **wg_tile,
                                **gs.sumsq_args(nm["qkv_w"], H, H))
             if sep_dbias:
-                plan.add_callable(lambda _d=dqkv, _g=fl.g_fused(nm["qkv_b"]): ops.colsum(_d, _g.view(-1)), sm)
+                colsums.append(lambda _d=dqkv, _g=fl.g_fused(nm["qkv_b"]): ops.colsum(_d, _g.view(-1)))
             dx = self.garena[l, 1]
             emit(_gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["qkv_w"]), H, T, H, 3 * H, trans_b=1,
                             out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ksplit_for(3 * H)), w_qkv)
             # the layer's four weight-gradient GEMMs only consume tensors the chain above produced (dxd, du, dxd2, dqkv
             # are distinct buffers): one grouped launch, after which the scratch may be reused by the next layer
+            ws_stream = sm
             if not wgrads:
                 pass                                    # self.ride: every weight gradient went out with its dgrad
             elif off:
                 plan.fork(sm, self.s_off)               # the other stack's stream picks them up once this chain got here
                 plan.add_gemm_group(wgrads, self.s_off)
+                ws_stream = self.s_off
             elif sw is None:
                 plan.add_gemm_group(wgrads, sm)
             else:                                       # beside the next layer's chain, on at most wg_blocks workgroups
@@ -841,6 +843,9 @@ class EncoderStack:
                 # the weight gradients of layers l, l+2, ... when the chain of layer l-2 asks for its scratch set back
                 plan.fork(sm, sw + (l % 2))
                 plan.add_gemm_group(wgrads, sw + (l % 2), max_blocks=self.wg_blocks)
+                ws_stream = sw + (l % 2)
+            for f in colsums:                           # read du / dqkv like the group does: same stream, same scratch lifetime
+                plan.add_callable(f, ws_stream)
             gin = dx
             if layer_hook is not None:
                 layer_hook(plan, self.prefix, l, sm)
