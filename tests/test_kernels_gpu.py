@@ -4,6 +4,7 @@ replaces (oracle/univl_oracle.py), on seeded inputs.  Needs a real MI355X (`-m g
 Tolerances: fp32 mode 1e-3 absolute on O(1) quantities as BASELINE.json's north_star states (observed ~1e-5);
 bf16 mode 1e-2 on quantities of O(1) after normalising by the tensor's scale (bf16 operands, fp32 accumulate)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -752,12 +753,17 @@ def test_tanh_gelu_simdense_colsum(dtype):
     cs = torch.ones(1024, device=DEV)
     ops.colsum(m, cs)
     assert rel_err(cs, m.double().cpu().sum(0) + 1) < 1e-5
-    big = gen(777, 1040, seed=9).to(DEV, dtype)            # 16-byte path on a strided view, rows not a multiple of anything; then the
-    for lo, hi in ((8, 1008), (3, 1003)):                  # element-per-lane fallback on a misaligned one
-        view = big[:, lo:hi]
-        cs = torch.full((hi - lo,), 2.0, device=DEV)
-        ops.colsum(view, cs)
-        assert rel_err(cs, view.double().cpu().sum(0) + 2) < 1e-5, (lo, hi)
+    big = gen(777, 1040, seed=9).to(DEV, dtype)            # both kernels (UNIVL_COLSUM_VEC is read per call): an aligned strided view,
+    for vec in ("0", "1"):                                 # rows not a multiple of anything, and a misaligned view (element-per-lane
+        os.environ["UNIVL_COLSUM_VEC"] = vec               # kernel either way)
+        try:
+            for lo, hi in ((8, 1008), (3, 1003)):
+                view = big[:, lo:hi]
+                cs = torch.full((hi - lo,), 2.0, device=DEV)
+                ops.colsum(view, cs)
+                assert rel_err(cs, view.double().cpu().sum(0) + 2) < 1e-5, (vec, lo, hi)
+        finally:
+            os.environ.pop("UNIVL_COLSUM_VEC", None)
     z = gen(50, 64, seed=8).to(DEV, dtype)
     ref = z.double().cpu() * 0.25
     ops.scale_ct(z, torch.tensor([0.25], device=DEV))

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, long ld, int ro
 
 // The same for 16-byte aligned rows (the bias gradients of FFN1 / QKV at thousands of tokens, engine.EncoderStack): a wave covers
 // 64 x (8 bf16 | 4 f32) columns with 16-byte loads, the workgroup's four waves take every fourth row with four loads in flight,
-// and meet in LDS in a fixed order.  (The element-per-lane kernel above moved 37.7 MB in 24 us at 6144 x 3072.)
+// and meet in LDS in a fixed order.  (The element-per-lane kernel above moves 37.7 MB in 24 us at 6144 x 3072.)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* x, long ld, int rows, int n, float* out, int rows_per_block) {
     constexpr int V = 16 / (int)sizeof(T);
@@ -472,7 +472,10 @@ extern "C" int univl_colsum(int32_t dtype, const void* x, int64_t ld, int32_t ro
     UNIVL_CHECK_ARG(x && out && rows > 0 && n > 0, UNIVL_EINVAL, "univl_colsum: bad argument");
     const int rpb = univl_deterministic() ? rows : 64;
     const int vec = dtype == UNIVL_DT_BF16 ? 8 : 4;
-    static const bool wide = !(getenv("UNIVL_COLSUM_VEC") && atoi(getenv("UNIVL_COLSUM_VEC")) == 0);
+    // opt-in (UNIVL_COLSUM_VEC=1, read per call so that a test can run both forms): at 128 pairs the step did not get faster with
+    // it (12.70 vs 12.59 ms, profiles/r03z3_ab_colsum_b128.txt) -- the column sums are not what the chain waits for
+    const char* vec_env = getenv("UNIVL_COLSUM_VEC");
+    const bool wide = vec_env && atoi(vec_env) == 1;
     if (wide && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ld % vec == 0 && n % vec == 0 && rows >= 16) {
         dim3 vgrid((n / vec + 63) / 64, (rows + rpb - 1) / rpb);
         if (dtype == UNIVL_DT_BF16)

@@ -777,7 +777,7 @@ class EncoderStack:
                 dt, T, H, gamma=fl.w32(nm["ln2_g"]), y=ws["y2"], stats=ws["st2"], dout=gin, dx32=dz, dxd16=s_dxd,
                 dgamma=fl.g(nm["ln2_g"]), dbeta=fl.g(nm["ln2_b"]), dbias=fl.g(nm["b2"]), p_pre=p, off_pre=ws["off"][2],
                 seed_dev=self.seed_dev), sm)
-            wgrads, colsums = [], []         # colsums: bias gradients off the chain, issued wherever the layer's weight gradients go
+            wgrads, colsums = [], []         # colsums: the bias gradients a big-tile group does not carry (issued after the group)
 
             def emit(dgrad, wgrad):
                 """dgrad on the chain; its weight-gradient twin either into the layer's grouped launch (default) or into the
@@ -844,8 +844,10 @@ class EncoderStack:
                 plan.fork(sm, sw + (l % 2))
                 plan.add_gemm_group(wgrads, sw + (l % 2), max_blocks=self.wg_blocks)
                 ws_stream = sw + (l % 2)
-            for f in colsums:                           # read du / dqkv like the group does: same stream, same scratch lifetime
-                plan.add_callable(f, ws_stream)
+            # on the chain (default; measured at 128 pairs, interleaved: 12.61 / 12.62 ms per step) or with the layer's weight
+            # gradients on their stream (UNIVL_COLSUM_ON_CHAIN=0: 12.72 / 12.76 -- there they delay the group the step ends on)
+            for f in colsums:
+                plan.add_callable(f, sm if os.environ.get("UNIVL_COLSUM_ON_CHAIN", "1") == "1" else ws_stream)
             gin = dx
             if layer_hook is not None:
                 layer_hook(plan, self.prefix, l, sm)
