@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 3, last session: the 128-pair plan with the big-tile grouped weight gradients + column-sum bias gradients
-# (engine.EncoderStack, UNIVL_WGRAD_BIG_MIN) -- the 128-pair parity tests, an interleaved A/B against the former plan, the
+# (engine.EncoderStack, UNIVL_WGRAD_BIG_MIN: 2048 at the time of this session, tied to the no-pair regime since) -- the 128-pair parity tests, an interleaved A/B against the former plan, the
 # data-parallel form, and a kernel trace of the new plan.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"

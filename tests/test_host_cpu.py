@@ -305,3 +305,48 @@ def test_word_table_chunks_start_on_row_boundaries_and_plan_ops_are_capturable()
         p.add_callable(lambda: None)
     assert [k for k, _ in p1.segments()] == ["graph"]
     assert [k for k, _ in p2.segments()] == ["graph", "eager", "graph"]
+
+
+def test_deep_weight_gradients_take_the_big_tile_without_fused_bias_gradients(monkeypatch):
+    """engine.EncoderStack where every dgrad product of a layer is on the 128 tile (>= 256 tiles of 128 x 128 for an H-wide output:
+    5462 tokens at H = 768 -- the weight gradients cannot ride with their dgrad there; UNIVL_WGRAD_BIG_MIN = tokens overrides), bf16:
+    the layer's grouped weight gradients ask for the 128 tile on two stages and 4 waves and carry no bias gradient; the two bias
+    gradients they used to carry (FFN1, QKV) are column-sum launches.  Below, the plan is the former one (pairs).  Built on the CPU:
+    the same weight-gradient outputs either way."""
+    from univl_amd.steps import build_step
+    m, cfg = _model("bf16")
+    fl = FlatParams(list(m.named_parameters()), "cpu", torch.bfloat16)
+    m._flat, m._seed_dev = fl, torch.zeros(1, dtype=torch.int64)
+    m.train()
+    B, W = 352, 16                                       # 5632 tokens in the text and in the video stack
+    layers = cfg.text_num_hidden_layers + cfg.visual_num_hidden_layers
+
+    def groups(plan):
+        out, lambdas, pairs = [], 0, 0
+        for i, op in enumerate(plan.ops):
+            if op[0] == "group":
+                out.append(plan.descs[i])
+            elif op[0] == "pair":
+                pairs += 1
+            elif op[0] == "py" and op[3] == "<lambda>":
+                lambdas += 1
+        return out, lambdas, pairs
+
+    monkeypatch.setenv("UNIVL_WGRAD_BIG_MIN", "1000000000")
+    old, old_py, old_pairs = groups(build_step(m, "joint", B, W, W, True).backward_plan(True))
+    monkeypatch.delenv("UNIVL_WGRAD_BIG_MIN")
+    new, new_py, new_pairs = groups(build_step(m, "joint", B, W, W, True).backward_plan(True))
+    assert len(old) == len(new) == layers and old_pairs == new_pairs == 0      # no pair launches at this size either way
+    assert new_py - old_py == 2 * layers
+    for go, gn in zip(old, new):
+        assert len(go) == len(gn) == 4
+        assert sorted(d.C32 for d in go) == sorted(d.C32 for d in gn)           # the same four matrices
+        assert sum(1 for d in go if d.dbias) == 2 and not any(d.dbias for d in gn)
+        for d in go:
+            assert (d.tile, d.stages, d.waves) == (0, 0, 0)
+        for d in gn:
+            assert (d.tile, d.stages, d.waves) == (128, 2, 4) and d.trans_a and d.trans_b and d.K == B * W
+            assert d.sumsq_rows % 128 == 0                # the fused gradient norms stay legal on the 128 tile
+    # 2048 tokens: the weight gradients of the H-wide dgrad products still ride with them -- the former plan, untouched
+    mid, mid_py, mid_pairs = groups(build_step(m, "joint", 128, 16, 16, True).backward_plan(True))
+    assert mid_pairs > 0 and all((d.tile, d.stages, d.waves) == (0, 0, 0) for g in mid for d in g)

@@ -761,7 +761,11 @@ class EncoderStack:
         # a deep contraction they are the stragglers the whole launch waits for -- isolated at 6144 tokens a layer's group runs
         # 231 us (64 tile, fused bias gradients, the former plan), 185 us (64 tile without them), 138 us (128 tile, 2 stages,
         # 4 waves, without them): profiles/r03w_gemm_group_variants_b128.txt, r03y2_gemm_group_variants_nodbias_b128.txt.
-        big_wgrad = self.bf and T >= int(os.environ.get("UNIVL_WGRAD_BIG_MIN", "2048"))
+        # From where on: by default exactly where the weight gradients stop riding with their dgrad products anyway -- every dgrad of
+        # the layer on the 128 tile (>= 256 tiles for the narrowest output, H columns: 5462 tokens at H = 768; gemm.hip choose /
+        # univl_gemm_pair) -- which is the regime the measurements cover (6144 and 12288 tokens); UNIVL_WGRAD_BIG_MIN = tokens overrides.
+        big_min = os.environ.get("UNIVL_WGRAD_BIG_MIN")
+        big_wgrad = self.bf and (T >= int(big_min) if big_min else ((T + 127) // 128) * ((H + 127) // 128) >= 256)
         wg_tile = dict(tile=128, stages=2, waves=4) if big_wgrad else {}
         for l in range(self.L - 1, -1, -1):
             ws, nm = self.layers[l], self._names(l)
