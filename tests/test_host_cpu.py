@@ -127,7 +127,8 @@ def test_gemm_workgroup_to_tile_maps_are_bijections(gm):
     """The XCD-aware / L2-blocked tile order of gemm.hip only re-orders the tiles: every tile of the grid is computed by
     exactly one workgroup, for every grid shape the plans produce (row tiles 1..96, split-K 1..8) and for ragged ones."""
     shapes = [(36, 3, 1), (12, 3, 2), (12, 3, 8), (48, 3, 1), (6, 1, 1), (5, 3, 1), (1, 3, 8), (18, 12, 1), (6, 48, 1),
-              (24, 96, 1), (239, 4, 1), (7, 13, 3), (3, 9, 2), (477, 1, 1), (2, 2, 2), (16, 1, 1), (1, 17, 1), (6, 47, 2)]
+              (24, 96, 1), (239, 4, 1), (7, 13, 3), (3, 9, 2), (477, 1, 1), (2, 2, 2), (16, 1, 1), (1, 17, 1), (6, 47, 2),
+              (6, 96, 1), (12, 48, 1), (6, 192, 1)]      # the last three: half-width tiles (64 x 128, 128 x 64) at 6144 / 12288 rows
     for nx, ny, nz in shapes:
         total = nx * ny * nz
         # plain grid (gemm_kernel): hardware (x, y, z) -> tile
