@@ -393,6 +393,10 @@ int univl_cast_bf16(const float* p, void* p16, int64_t n, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------- hardware probes */
 int univl_probe_layouts(float* out, int32_t n_out, hipStream_t stream);
+/* Measurement node: *out = the device's constant-rate wall clock (wall_clock64, 100 MHz on gfx950) when a one-thread kernel enqueued on
+ * `stream` runs.  Placed between the nodes of a captured step it gives GPU-side start / end times of the step's branches WITHOUT a
+ * profiler attached (scripts/probe_branches.py: rocprofv3 changes how the two branches of the step graph overlap). */
+int univl_stamp(uint64_t* out, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -337,6 +337,16 @@ extern "C" int univl_bump_counter(uint64_t* ctr, hipStream_t stream) {
     return UNIVL_OK;
 }
 
+__global__ void stamp_kernel(uint64_t* out) { out[0] = wall_clock64(); }
+
+extern "C" int univl_stamp(uint64_t* out, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    UNIVL_CHECK_ARG(out != nullptr, UNIVL_EINVAL, "univl_stamp: null");
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, stream, out);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
 extern "C" int univl_cast_bf16(const float* p, void* p16, int64_t n, hipStream_t stream) {
     UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(p && p16 && n > 0 && aligned16(p) && ((((uintptr_t)p16) & 7) == 0), UNIVL_EINVAL, "univl_cast_bf16: bad argument");

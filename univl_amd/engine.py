@@ -624,6 +624,9 @@ class EncoderStack:
         # is complete before anybody reads the layer.
         self.adam_ride = ((getattr(flat, "adam_ride", False) or os.environ.get("UNIVL_ADAM_RIDE", "") == "1")
                           and flat.compute_dtype == torch.bfloat16 and prefix in ("bert", "visual", "cross"))
+        # UNIVL_PROBE_SKIP=<prefix> (measurement only, scripts/probe_branches.py): this stack emits NO layer kernels, forward or
+        # backward -- what the step costs without one of its two encoder branches (results are meaningless)
+        self.probe_skip = os.environ.get("UNIVL_PROBE_SKIP", "") == prefix
         self.T = B * S
         self.key_mask = key_mask            # int64 [B,S] device tensor (static buffer)
         self.p = float(p_drop)
@@ -697,6 +700,8 @@ class EncoderStack:
         fl, dt, T, H, I, S, B = self.flat, self.flat.dt, self.T, self.H, self.I, self.S, self.B
         sm = self.sm
         p = self.p if training else 0.0
+        if self.probe_skip:
+            return
         if self.ks_h > 1 and zero_arena:
             plan.add_callable(self.yarena.zero_, stream=sm)
         for l, ws in enumerate(self.layers):
@@ -752,6 +757,9 @@ class EncoderStack:
         fl, dt, T, H, I, S, B = self.flat, self.flat.dt, self.T, self.H, self.I, self.S, self.B
         sm = self.sm
         p = self.p if training else 0.0
+        self.bwd_out = gin
+        if self.probe_skip:
+            return
         if self.ks_h > 1 and zero_arena:
             plan.add_callable(self.garena.zero_, stream=sm)
         sw = self.sw

@@ -317,6 +317,11 @@ def cast_bf16(src, dst):
     _lib.check(_lib.lib().univl_cast_bf16(_p(src), _p(dst), src.numel(), _stream()), "cast_bf16")
 
 
+def stamp(out):
+    """out: one int64 / uint64 device word <- the device wall clock when this node runs (measurement, include/univl_hip.h)."""
+    _lib.check(_lib.lib().univl_stamp(_p(out), _stream()), "stamp")
+
+
 def bump_counter(ctr):
     _lib.check(_lib.lib().univl_bump_counter(_p(ctr), _stream()), "bump_counter")
 

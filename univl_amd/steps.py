@@ -40,6 +40,19 @@ class Ctx:
         self.sites = _SiteCounter()
         self.e = _e(self.dev)
         self.red = model._reducer
+        # UNIVL_STAMPS=1 (measurement, scripts/probe_branches.py): device wall-clock stamps between the nodes of the step, so that the
+        # start / end of the two encoder branches inside a captured replay can be read WITHOUT a profiler attached
+        self.stamps = {} if os.environ.get("UNIVL_STAMPS", "0") == "1" else None
+        if self.stamps is not None:
+            self.stamp_buf = torch.zeros(64, dtype=torch.int64, device=self.dev)
+            model._stamps = (self.stamps, self.stamp_buf)
+
+    def stamp(self, plan, name, stream=0):
+        if self.stamps is None:
+            return
+        slot = self.stamps.setdefault(name, len(self.stamps))
+        buf = self.stamp_buf
+        plan.add_callable(lambda: ops.stamp(buf[slot:slot + 1]), stream)
 
 
 def stage_input(dst, src):
@@ -125,7 +138,9 @@ class EncoderPass:
         W32, p, B, W, F, D, Tv = fl.w32, cx.p, self.B, self.W, self.F, self.D, self.Tv
         ST, SV = self.ST, self.SV
         fwd.add_zeros([st.yarena for st in (self.text, self.vis) if st.ks_h > 1], ST)      # split-K accumulation targets
+        cx.stamp(fwd, "f_fork", ST)
         fwd.fork(ST, SV)           # the video encoder runs concurrently with the text encoder
+        cx.stamp(fwd, "f_vis_start", SV)
         if self.normalized_input:
             if bf:
                 fwd.add_callable(lambda: ops.cast_bf16(self.vn32, self.vn_op), SV)
@@ -138,13 +153,17 @@ class EncoderPass:
             dt, Tv, H, x=self.ve, pos=W32(n["vpos"]), pos_period=F, gamma=W32(n["vlg"]), beta=W32(n["vlb"]), y=self.ve,
             stats=self.vest, out32=self.v0_32, out16=self.v0_16 if bf else None, p_post=p, seed=cx.seed, off_post=self.off_v,
             seed_dev=cx.seed_dev), SV)
+        cx.stamp(fwd, "f_text_start", ST)
         fwd.add("univl_embed_text_fwd", ops.embed_text_desc(
             dt, B, W, self.ids, W32(n["bw"]), W32(n["bp"]), W32(n["blg"]), W32(n["blb"]), type_ids=self.type_ids,
             type_emb=W32(n["bt"]), y=self.te, stats=self.test, out32=self.t0_32, out16=self.t0_16 if bf else None, p_post=p,
             seed=cx.seed, off_post=self.off_t, seed_dev=cx.seed_dev), ST)
         self.vis.build_forward(fwd, self.v0_32, self.v0_16, cx.training, zero_arena=False)
+        cx.stamp(fwd, "f_vis_end", SV)
         self.text.build_forward(fwd, self.t0_32, self.t0_16, cx.training, zero_arena=False)
+        cx.stamp(fwd, "f_text_end", ST)
         fwd.join(SV, ST)
+        cx.stamp(fwd, "f_join", ST)
 
     def zero_list(self):
         """Accumulation buffers a backward clears before anything adds into them."""
@@ -155,7 +174,10 @@ class EncoderPass:
         cx, n, fl, dt = self.cx, self.N, self.cx.fl, self.cx.dt
         W32, G, p, B, W, F, D, Tv = fl.w32, fl.g, cx.p, self.B, self.W, self.F, self.D, self.Tv
         ST, SV = self.ST, self.SV
+        cx.stamp(bwd, "b_fork", ST)
         bwd.fork(ST, SV)
+        cx.stamp(bwd, "b_vis_start", SV)
+        cx.stamp(bwd, "b_text_start", ST)
         # The two stacks are independent until the join below and run on two streams; they are emitted INTERLEAVED
         # (text layers : video layers in the ratio of their depths) so that plan order follows time order -- gradient
         # exchange points and hipGraph segment cuts (Plan.run_graphed) then fall between layers of both stacks.
@@ -168,10 +190,13 @@ class EncoderPass:
                 if not done_t and next(gt, None) is None:
                     done_t = True
                     self._text_tail(bwd, self.text.bwd_out)
+                    cx.stamp(bwd, "b_text_end", ST)
             if not done_v and next(gv, None) is None:
                 done_v = True
                 self._video_tail(bwd, gs, self.vis.bwd_out)
+                cx.stamp(bwd, "b_vis_end", SV)
         bwd.join(SV, ST)
+        cx.stamp(bwd, "b_join", ST)
 
     # From this many rows per position the position-table gradients are built by a gather over the per-token gradient rows
     # (univl_rows_gather_sum) instead of B atomics per table element inside the fused kernels (128 pairs: embed_bwd 173 us, the video
@@ -683,6 +708,7 @@ def build_step(model, kind, B, W, F, training):
     fwd = st.fwd
     fwd.external = model._param_events          # events of an optimizer update still in flight (univl_amd.graphed)
     fwd.wait_point("base")                      # embedding tables, every vector, the matrices outside the layer stacks
+    cx.stamp(fwd, "f_begin")
     if cx.p > 0:
         fwd.add_callable(lambda: ops.bump_counter(cx.seed_dev))
     st.enc = enc = EncoderPass(cx, B, W, F, normalized_input=(kind == "features_shaped"))
@@ -736,6 +762,7 @@ def build_step(model, kind, B, W, F, training):
         pass                                   # encoders only (get_sequence_visual_output on a stage-two model)
     else:
         raise ValueError(kind)
+    cx.stamp(fwd, "f_end")
     if st.loss_terms:
         st.finish_forward()
     else:
@@ -784,6 +811,7 @@ def build_step(model, kind, B, W, F, training):
                 zeros += r.zero_list()
         if st.run_heads is not None:
             zeros.append(st.run_heads.dpostype)
+        cx.stamp(bwd, "b_begin")
         bwd.add_zeros(zeros)
         g = st.gout
         if st.pooler is not None:
@@ -830,6 +858,7 @@ def build_step(model, kind, B, W, F, training):
                     bwd.add_callable(lambda: ops.rows_append(ids_all.view(-1), lst, meta, fresh, fl.word_ever))
             st.exchange_points = list(sched[0].cuts)
         gs.finish(bwd)
+        cx.stamp(bwd, "b_end")
         bwd.fused_names = frozenset(gs.covered)
         bwd.rows_mode = rows_mode
         return bwd
