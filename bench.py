@@ -362,7 +362,9 @@ def main():
     if not args.no_graph:
         from univl_amd.graphed import GraphedTrainStep
         # one process, bf16: the BertAdam update of iteration t rides with the forward of iteration t + 1 (default; --no-pipeline)
-        pipe = args.pipeline or (not args.no_pipeline and args.dtype == "bf16" and model._reducer is None)
+        # ... and, with a captured gradient exchange, as two graphs (forward with riders | backward with collectives + clip)
+        pipe = args.pipeline or (not args.no_pipeline and args.dtype == "bf16" and not args.shard_optimizer
+                                 and (model._reducer is None or model._reducer.capturable))
         gstep = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=0, pipeline_optimizer=pipe,
                                  persistent_inputs=True)     # the bench contract: the batch is resident in HBM, refilled in place
         ok = 1

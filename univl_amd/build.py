@@ -22,7 +22,11 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, trace=False):
+    """trace=True: the measurement build (-DUNIVL_TRACE, csrc/gemm.hip) -> lib/libunivl_hip_trace.so, objects under lib/trace/; load it
+    with UNIVL_LIB=<path> (scripts/mb_trace_gemm.py).  Never the product library."""
+    if trace:
+        return _build_variant("trace", ["-DUNIVL_TRACE"], force, verbose)
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
@@ -56,5 +60,34 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def _build_variant(tag, extra, force, verbose):
+    odir = os.path.join(LIBDIR, tag)
+    os.makedirs(odir, exist_ok=True)
+    lib = os.path.join(LIBDIR, "libunivl_hip_%s.so" % tag)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
+    objs, jobs = [], []
+    for s in srcs:
+        o = os.path.join(odir, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            jobs.append((s, o))
+
+    def cc(job):
+        r = subprocess.run([HIPCC] + FLAGS + extra + ["-c", job[0], "-o", job[1]], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (job[0], r.stdout, r.stderr))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(cc, jobs))
+    if jobs or not os.path.exists(lib):
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose:
+            print("[build] linked", lib)
+    return lib
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, trace="--trace" in sys.argv)

@@ -24,6 +24,29 @@
 #include "univl_hip.h"
 #include "adam_body.h"
 
+// -DUNIVL_TRACE (a second, measurement-only build: univl_amd/build.py trace=True -> lib/libunivl_hip_trace.so, never the product library): thread 0
+// of every workgroup of a GEMM-family kernel writes the device wall clock (100 MHz) at kernel entry, when its first staged tile has
+// landed, after its K loop and after its epilogue into a buffer registered with univl_trace_set -- where the ~9 us of a 192-row
+// product go (scripts/mb_trace_gemm.py), without a profiler attached.
+#ifdef UNIVL_TRACE
+__device__ unsigned long long* g_univl_trace = nullptr;
+__device__ int g_univl_trace_cap = 0;
+#define UNIVL_TRACE_AT(phase)                                                                              \
+    do {                                                                                                   \
+        if (threadIdx.x == 0 && g_univl_trace != nullptr) {                                                \
+            const int w__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                \
+            if (w__ < g_univl_trace_cap) g_univl_trace[w__ * 4 + (phase)] = wall_clock64();                \
+        }                                                                                                  \
+    } while (0)
+extern "C" int univl_trace_set(unsigned long long* buf, int cap_workgroups) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_univl_trace), &buf, sizeof(buf)) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_univl_trace_cap), &cap_workgroups, sizeof(int)) != hipSuccess) return 1;
+    return 0;
+}
+#else
+#define UNIVL_TRACE_AT(phase)
+#endif
+
 namespace {
 
 struct GemmArgs {
@@ -211,6 +234,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     const int nfull = (kend - kbeg) / BK;              // full K tiles: no masking at all
     const int krem = (kend - kbeg) - nfull * BK;       // > 0: one partial tile at the end
 
+    UNIVL_TRACE_AT(0);
     f32x4_t acc[MI][NI];
 #pragma unroll
     for (int a = 0; a < MI; ++a)
@@ -316,6 +340,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         TileA::advance(pa, stepA);
         TileB::advance(pb, stepB);
         __syncthreads();
+        UNIVL_TRACE_AT(1);
         for (int t = 0; t < nfull; ++t) {
             const int cur = t & 1;
             if (t + 1 < nfull) {
@@ -338,6 +363,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     }
     }
 
+    UNIVL_TRACE_AT(2);
     // ------------------------------------------------------------------------------------------ epilogue
     // All epilogue INPUTS (bias, residual, saved pre-activation, old C) are fetched first, in flag-uniform groups
     // of back-to-back loads from clamped (always valid) addresses; only the stores are predicated.  A per-element
@@ -464,6 +490,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
             else p.dbias[row] = dbias_acc;
         }
     }
+    UNIVL_TRACE_AT(3);
 }
 
 // XCD-aware, L2-blocked workgroup -> tile map.  The dispatcher deals workgroups round-robin over the 8 XCDs (linear id % 8,

@@ -72,13 +72,16 @@ class GraphedTrainStep:
         # (profiles/r03b_ab_adam_ride.txt): 2.53 vs 2.74 ms per step at 4 pairs, 3.79 vs 4.23 at 16; bit-identical parameters
         # (tests/test_model_gpu.py::test_adam_update_riding_with_the_next_forward_matches_eager).
         fl = model.flat
-        # Not with a gradient exchange: rider launches and captured RCCL nodes in ONE graph pass the world-size-1 test on a small model
-        # but crash hipGraphLaunch at the benchmark shape (profiles/r03g: segmentation fault inside replay; with the collectives
-        # left out -- UNIVL_DP_DRYRUN=1 -- the same graph runs at 2.61 ms per step): UNIVL_ADAM_RIDE=force tries it anyway.
+        # With a captured gradient exchange (library-held RCCL communicator) the iteration is captured as TWO graphs -- forward with its
+        # riders | backward with its collectives + clip -- launched back to back: rider launches and RCCL's kernel nodes in ONE graph
+        # pass the world-size-1 test on a small model but crash hipGraphLaunch at the benchmark shape (profiles/r03g_dp_ride_crash.txt:
+        # segmentation fault inside the replay; cause open).  One extra graph launch per iteration keeps the riding update in the
+        # data-parallel step.  UNIVL_ADAM_RIDE=force: one graph anyway (the crashing form, for reproducing it); =0: no riders.
         red = getattr(model, "_reducer", None)
         env = os.environ.get("UNIVL_ADAM_RIDE", "1")
+        self._ride_env = env
         self.ride = (self.pipeline and env != "0" and fl.compute_dtype == torch.bfloat16
-                     and (red is None or (env == "force" and red.capturable)) and getattr(fl, "shard_reducer", None) is None)
+                     and (red is None or red.capturable) and getattr(fl, "shard_reducer", None) is None)
         if self.ride and not getattr(fl, "adam_ride", False):
             fl.adam_ride = True
             model._steps = {}            # the forward plans are rebuilt with rider slots (engine.EncoderStack.build_forward)
@@ -227,12 +230,19 @@ class GraphedTrainStep:
                 _lib.check(_lib.lib().univl_gemm_rider_prime(C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm_rider_prime")
             red0 = getattr(self.model, "_reducer", None)
             one_graph = red0 is None or red0.capturable      # no exchange, or an exchange that is part of the plan (univl_amd.rccl)
-            if one_graph and self.async_loss:
+            if self.ride and red0 is not None and not red0.capturable:
+                # the riders were planned before a gradient exchange through torch's process group appeared (enable_data_parallel or
+                # the DDP wrapper AFTER this object was built): that combination was never validated
+                raise RuntimeError("GraphedTrainStep: a gradient exchange that cannot be captured was enabled after construction; build "
+                                   "the GraphedTrainStep after enable_data_parallel() / the DistributedDataParallel wrap")
+            split = self.async_loss or (self.ride and red0 is not None and self._ride_env != "force")
+            if one_graph and split:
                 # two graphs from one memory pool: forward | backward + clip + BertAdam
                 self._g_fwd, self._g_rest = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with no_gc(), torch.cuda.graph(self._g_fwd):
+                # thread_local: with a captured gradient exchange the process group's watchdog thread may query events meanwhile
+                with no_gc(), torch.cuda.graph(self._g_fwd, capture_error_mode="thread_local"):
                     self.loss = self._forward_pipelined(sa, sk) if self.pipeline else self.model(*sa, **sk)
-                with no_gc(), torch.cuda.graph(self._g_rest, pool=self._g_fwd.pool()):
+                with no_gc(), torch.cuda.graph(self._g_rest, pool=self._g_fwd.pool(), capture_error_mode="thread_local"):
                     self.loss.backward()
                     self._clip_and_step(defer=self.pipeline)
                     if self.pipeline:
@@ -259,7 +269,8 @@ class GraphedTrainStep:
         if self.mode == "whole":
             if self._g_rest is not None:
                 self._g_fwd.replay()
-                self._read_back_loss()
+                if self.async_loss:
+                    self._read_back_loss()
                 self._g_rest.replay()
             else:
                 self._g_all.replay()

@@ -61,30 +61,55 @@ class BucketReducer:
         self.timings = dict(collective_ms=0.0, exposed_ms=0.0, bytes=0, steps=0)
         self._ev = []
 
+    def _agree(self, ok):
+        """MIN over the ranks of a local 0 / 1 outcome, through the torch process group (never through the communicator under test)."""
+        if self.world > 1:
+            flag = torch.tensor([1 if ok else 0], device="cuda", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+            ok = int(flag)
+        return bool(ok)
+
     def enable_capture(self):
-        """RCCL backend only.  Collective over the group (creates the communicator)."""
-        from .rccl import RcclComm
+        """RCCL backend only.  Collective over the group (creates the communicator).  Every step whose failure could be LOCAL to
+        one rank (librccl not loadable, ncclGetUniqueId, the self-test) ends in an agreement over the process group before any rank
+        acts on it, so that either every rank takes the captured path or every rank raises -- a rank that fell back alone would leave
+        the others hanging in the next collective of the path it left."""
+        from . import rccl as _r
         if not self._avg or self.loopback or self.bf16 or self.partition is not None:
             return False
-        self.rccl = RcclComm(self.pg)
+        err = None
+        try:
+            _r._rccl()
+        except Exception as ex:      # noqa: BLE001
+            err = ex
+        if not self._agree(err is None):
+            raise RuntimeError("librccl is not loadable on at least one rank (%s)" % (err,))
+        # RcclComm: rank 0's unique id (or None, if ncclGetUniqueId failed there) is broadcast to everybody -- a consistent outcome --
+        # and ncclCommInitRank is RCCL's own collective
+        self.rccl = _r.RcclComm(self.pg)
         self._cstream = torch.cuda.Stream()
-        ok = 1
+        err = None
         try:
             self._capture_selftest()
         except Exception as ex:      # noqa: BLE001 -- an RCCL build that refuses stream capture reports it here, before any training step
             import sys
             print("[univl_amd] rank %d: captured RCCL all-reduce self-test failed (%s: %s)" % (self.rank, type(ex).__name__, ex), file=sys.stderr)
-            ok = 0
-        if self.world > 1:           # every rank takes the same path
-            flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
-            ok = int(flag)
-        if not ok:
-            self.rccl.destroy()
-            self.rccl, self._cstream = None, None
+            err = ex
+        if not self._agree(err is None):
+            self.disable_capture()
             raise RuntimeError("captured RCCL all-reduce self-test failed on at least one rank")
         self.capturable = True
         return True
+
+    def disable_capture(self):
+        """Back to the process-group form; the library-held communicator and its stream are released."""
+        self.capturable = False
+        if self.rccl is not None:
+            try:
+                torch.cuda.synchronize()
+                self.rccl.destroy()
+            finally:
+                self.rccl, self._cstream, self._inflight = None, None, False
 
     def _capture_selftest(self):
         """A small all-reduce through the new communicator: once eagerly (connection set-up happens outside any capture), once
@@ -214,7 +239,7 @@ class BucketReducer:
     # all-reduce, and the 30 B/param optimizer stream shrinks by the world size.
     def set_partition(self, partition):
         if partition is not None:
-            self.capturable = False          # the sharded path issues host-synchronous collectives (norm all-reduce): segmented graphs
+            self.disable_capture()           # the sharded path issues host-synchronous collectives (norm all-reduce): segmented graphs
         self.partition = list(partition) if partition is not None else None
         self.owned = owned_ranges(self.partition, self.world, self.rank) if partition is not None else None
 

@@ -74,12 +74,16 @@ class RcclComm:
         self.rank = dist.get_rank(process_group)
         self.world = dist.get_world_size(process_group)
         uid = _Uid()
+        box = [None]
         if self.rank == 0:
-            _check(G.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        box = [C.string_at(C.byref(uid), 128) if self.rank == 0 else None]      # all 128 bytes (a c_char array field reads as a C string)
+            rc = G.ncclGetUniqueId(C.byref(uid))
+            # a failure here travels to every rank as None: all of them raise below, nobody is left waiting in ncclCommInitRank
+            box = [C.string_at(C.byref(uid), 128) if rc == 0 else None]      # all 128 bytes (a c_char array field reads as a C string)
         if self.world > 1:
             dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
                                        group=process_group)
+        if box[0] is None:
+            raise RuntimeError("RCCL ncclGetUniqueId failed on rank 0")
         C.memmove(C.byref(uid), box[0], 128)
         self.comm = C.c_void_p()
         _check(G.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
