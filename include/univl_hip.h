@@ -86,8 +86,8 @@ int univl_allreduce_bucket(void* buf, size_t n, int dtype, int average, void* co
 #define UNIVL_GEMM_GELU_BWD 4     /* result *= gelu'(aux)                                                  */
 #define UNIVL_GEMM_ATOMIC 8       /* internal: split-K atomics                                             */
 #define UNIVL_GEMM_DBIAS_ATOMIC 16 /* dbias accumulated with atomics (several row tiles share a bias)       */
-#define UNIVL_GEMM_XCD_MAP 64      /* internal: XCD-aware workgroup -> tile map (UNIVL_GEMM_XCD=0 turns it off)              */
-#define UNIVL_GEMM_PROBE_NOSTORE 128 /* internal, measurement only (UNIVL_GEMM_PROBE=1): the epilogue computes but does not store -- bounds what a faster epilogue could buy; results are garbage */
+#define UNIVL_GEMM_XCD_MAP 64      /* internal: XCD-aware workgroup -> tile map (always on since round 4) */
+#define UNIVL_GEMM_PROBE_NOSTORE 128 /* internal, only in the -DUNIVL_TRACE measurement build (UNIVL_GEMM_PROBE=1 there): the epilogue computes but does not store; the product library never sets or tests it */
 #define UNIVL_GEMM_NT_OUT 32       /* fp32 output written with non-temporal stores: a weight gradient is read next by the optimizer, a whole backward later */
 typedef struct UnivlGemm {
     int32_t dtype, trans_a, trans_b;
@@ -106,18 +106,18 @@ typedef struct UnivlGemm {
     float alpha;
     int32_t flags;
     int32_t ksplit;        /* >1: split the contraction over gridDim.z, fp32 atomics into pre-zeroed C32 */
-    int32_t tile;          /* 0 auto; 64 (64x64, 4 waves), 128 (128x128, 4 waves), 256 (256x128, 8 waves; bf16, else 128);
+    int32_t tile;          /* 0 auto; 64 (64x64), 128 (128x128);
                             * 12864 / 64128 (128x64 / 64x128; bf16, K-major A, no sumsq / dbias, univl_gemm only -- else 128) */
     /* optional, no split-K: every wave stores the sum of squares of the FINAL values it wrote to
      *   sumsq[(m0 / sumsq_rows) * sumsq_stride + (((m0 % sumsq_rows) / tile) * tiles_x + tile_x) * waves + wave]
      * (sumsq_rows = 0: the whole output is one tensor).  Partial sums, no atomics: thousands of workgroups adding to one
      * address serialise in L2.  univl_sumsq_finish folds them into per-tensor sums.  Lets the weight-gradient GEMMs
      * produce the gradient norms clip_grad_norm_ (main_task_retrieval.py:347) and BertAdam's per-parameter clip
-     * (optimization.py:135-136) need, instead of a separate 4 B/param pass.  sumsq_rows must be a multiple of 128 (of 256 for the
-     * 256-row tile, which is otherwise replaced by the 128 tile).  At most rows x N / 1024 partial sums per tensor. */
+     * (optimization.py:135-136) need, instead of a separate 4 B/param pass.  sumsq_rows must be a multiple of 128.
+     * At most rows x N / 1024 partial sums per tensor. */
     float* sumsq; int32_t sumsq_rows; int32_t sumsq_stride;
-    int32_t stages;        /* LDS pipeline depth: 0 auto, 2 (double buffer), 3 (ring with counted DMA waits; bf16, else 2) */
-    int32_t waves;         /* waves per workgroup on the 64 / 128 tiles: 0 auto, 4, 8 (bf16, else 4); the 256 tile always runs 8 */
+    int32_t stages;        /* LDS pipeline depth: 0 or 2 (double buffer, the only form since round 4; the field keeps the ABI layout) */
+    int32_t waves;         /* waves per workgroup on the 64 / 128 tiles: 0 auto, 4, 8 (bf16, else 4) */
 } UnivlGemm;
 int univl_gemm(const UnivlGemm* desc, hipStream_t stream);
 /* n (1..UNIVL_GEMM_GROUP_MAX) independent problems with the same dtype / trans_a / trans_b in ONE launch: the four

@@ -20,8 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from univl_amd import ops  # noqa: E402
 
 DEV = "cuda"
-VARIANTS = [(64, 2, 4), (64, 3, 4), (64, 2, 8), (64, 3, 8), (128, 2, 4), (128, 3, 4), (128, 2, 8), (128, 3, 8), (256, 2, 8), (256, 3, 8),
-            (12864, 2, 8), (12864, 2, 4), (64128, 2, 8), (64128, 2, 4)]   # tile, stages, waves (12864 = 128 x 64, 64128 = 64 x 128: K-major A only)
+VARIANTS = [(64, 2, 4), (64, 2, 8), (128, 2, 4), (128, 2, 8), (12864, 2, 8), (12864, 2, 4), (64128, 2, 8), (64128, 2, 4)]   # tile, stages, waves (12864 = 128 x 64, 64128 = 64 x 128: K-major A only)
 REPS, NW, NA = 24, 8, 4
 # one encoder layer, hidden 768: (name, out columns, contraction) of the forward products; dgrad swaps them; wgrad contracts tokens
 LINEAR = [("qkv", 2304, 768), ("attn_out", 768, 768), ("ffn1", 3072, 768), ("ffn2", 768, 3072)]
@@ -64,7 +63,7 @@ def main():
     bf = torch.bfloat16
     results = []
     for M in [int(x) for x in a.rows.split(",") if x]:
-        variants = [v for v in VARIANTS if not (M < 512 and v[0] == 256)]
+        variants = list(VARIANTS)
         print("rows M = %d   (us per launch | TFLOP/s)   variants (tile,stages,waves): %s" % (M, variants))
         for name, N, K in LINEAR:
             X = [torch.randn(M, K, device=DEV).to(bf) for _ in range(NA)]           # layer input
@@ -123,7 +122,7 @@ def main():
         dbs = {n_: torch.zeros(N, device=DEV) for n_, N, K in LINEAR}
         flops = sum(2.0 * T * N * K for _, N, K in LINEAR)
         row = dict(rows=T, linear="layer", kind="wgrad_group", us={}, err={})
-        for tile, stages, waves in [(0, 0, 0)] + [v for v in VARIANTS if v[0] <= 256]:
+        for tile, stages, waves in [(0, 0, 0)] + [v for v in VARIANTS if v[0] <= 128]:
             def fn(i, tile=tile, stages=stages, waves=waves):
                 ops.gemm_group([ops.gemm_desc(dYs[n_][i % 2], Xs[n_][i % 2], N, K, T, trans_a=True, trans_b=True, out32=dWs[n_],
                                               dbias=dbs[n_] if (a.group_dbias and n_ in ("qkv", "ffn1")) else None, tile=tile, stages=stages, waves=waves)

@@ -186,16 +186,15 @@ def test_gemm_group_wgrads(dtype, T):
         ops.gemm_group(mixed)                              # different operand layouts
 
 
-GEMM_VARIANTS = [(64, 3, 4), (64, 2, 8), (64, 3, 8), (128, 3, 4), (128, 2, 8), (128, 3, 8), (256, 2, 8), (256, 3, 8)]   # UnivlGemm.tile, .stages, .waves
+GEMM_VARIANTS = [(64, 2, 4), (64, 2, 8), (128, 2, 8)]   # UnivlGemm.tile, .stages, .waves (reference: 128 / 2 / 4)
 
 
 @pytest.mark.parametrize("M,N,K", [(700, 1000, 768), (6144, 768, 3072), (300, 264, 100), (256, 128, 64), (260, 130, 200),
                                     (1024, 2304, 1096)])
-def test_gemm_ring_and_wide_tile_forward_dgrad(M, N, K):
-    """The three-stage ring (counted DMA waits), the 8-wave workgroups and the 256 x 128 tile against the 128-tile / 4-wave
-    double-buffered kernel: BIT-identical (every output element contracts the same 32-deep chunks in the same order in every
-    variant), and the double-buffered kernel against fp64.  Shapes: ragged rows / columns, contraction shorter than the ring
-    (K = 64, 100), a partial last K tile (K = 200, 1096), the MFMA-bound shape of bs 128 (6144 x 768 x 3072)."""
+def test_gemm_tile_and_wave_variants_forward_dgrad(M, N, K):
+    """The 64 tile and the 8-wave workgroups against the 128-tile / 4-wave kernel: BIT-identical (every output element contracts the
+    same 32-deep chunks in the same order in every variant), and that kernel against fp64.  Shapes: ragged rows / columns, short
+    contractions (K = 64, 100), a partial last K tile (K = 200, 1096), the MFMA-bound shape of bs 128 (6144 x 768 x 3072)."""
     dtype = torch.bfloat16
     Kp = (K + 7) // 8 * 8
     A = torch.zeros(M, Kp); A[:, :K] = gen(M, K, seed=1)
@@ -219,7 +218,7 @@ def test_gemm_ring_and_wide_tile_forward_dgrad(M, N, K):
     ref = dYd.double().cpu()[:, :N] @ Wd.double().cpu()[:N] + res.double().cpu()
     assert rel_err(dbase, ref) < 2e-3
     for tile, stages, waves in GEMM_VARIANTS:
-        for rep in range(3):                               # a race in the ring would come and go
+        for rep in range(2):                               # a race between the stages would come and go
             out = torch.zeros(M, ldc, device=DEV)
             o16 = torch.zeros(M, ldc, device=DEV, dtype=dtype)
             ops.gemm(Ad, Bd, M, N, K, out32=out, out16=o16, bias=bias, tile=tile, stages=stages, waves=waves)
@@ -232,7 +231,7 @@ def test_gemm_ring_and_wide_tile_forward_dgrad(M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(6144, 768, 3072), (700, 1000, 768), (300, 264, 100), (130, 70, 64)])
 def test_gemm_half_width_tiles_forward_dgrad(M, N, K):
-    """UnivlGemm.tile = 12864 / 64128 (128 x 64 and 64 x 128 tiles on 4 or 8 waves; opt-in, UNIVL_GEMM_RECT): BIT-identical to the
+    """UnivlGemm.tile = 12864 / 64128 (128 x 64 and 64 x 128 tiles on 4 or 8 waves; chosen by slot fill from ~2000 rows on): BIT-identical to the
     128 tile (same 64-deep K steps, same chunk order per output element) for the two layouts they serve -- forward
     (K-major x K-major, bias, fp32 + bf16 outputs) and dgrad (K-major x T-major, fp32 residual); a weight-gradient
     descriptor (T-major A) falls back to the 128 tile."""
@@ -272,7 +271,7 @@ def test_gemm_half_width_tiles_forward_dgrad(M, N, K):
 
 
 @pytest.mark.parametrize("T", [192, 1000, 6144])
-def test_gemm_ring_and_wide_tile_wgrad(T):
+def test_gemm_tile_and_wave_variants_wgrad(T):
     """Weight-gradient layout (both operands T-major) with the fused bias gradient, accumulate, the per-tensor sum of squares
     (three tensors of 768 rows in one launch) and the grouped launch: every variant against the double-buffered 128 tile."""
     dtype = torch.bfloat16
@@ -753,17 +752,12 @@ def test_tanh_gelu_simdense_colsum(dtype):
     cs = torch.ones(1024, device=DEV)
     ops.colsum(m, cs)
     assert rel_err(cs, m.double().cpu().sum(0) + 1) < 1e-5
-    big = gen(777, 1040, seed=9).to(DEV, dtype)            # both kernels (UNIVL_COLSUM_VEC is read per call): an aligned strided view,
-    for vec in ("0", "1"):                                 # rows not a multiple of anything, and a misaligned view (element-per-lane
-        os.environ["UNIVL_COLSUM_VEC"] = vec               # kernel either way)
-        try:
-            for lo, hi in ((8, 1008), (3, 1003)):
-                view = big[:, lo:hi]
-                cs = torch.full((hi - lo,), 2.0, device=DEV)
-                ops.colsum(view, cs)
-                assert rel_err(cs, view.double().cpu().sum(0) + 2) < 1e-5, (vec, lo, hi)
-        finally:
-            os.environ.pop("UNIVL_COLSUM_VEC", None)
+    big = gen(777, 1040, seed=9).to(DEV, dtype)            # an aligned strided view, rows not a multiple of anything, and a misaligned view
+    for lo, hi in ((8, 1008), (3, 1003)):
+        view = big[:, lo:hi]
+        cs = torch.full((hi - lo,), 2.0, device=DEV)
+        ops.colsum(view, cs)
+        assert rel_err(cs, view.double().cpu().sum(0) + 2) < 1e-5, (lo, hi)
     z = gen(50, 64, seed=8).to(DEV, dtype)
     ref = z.double().cpu() * 0.25
     ops.scale_ct(z, torch.tensor([0.25], device=DEV))

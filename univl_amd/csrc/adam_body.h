@@ -5,6 +5,8 @@
 #include "common.h"
 #include "univl_hip.h"
 
+bool univl_adam_nt();      // optim.hip: UNIVL_ADAM_NT (default 1): non-temporal loads / stores of the 28 fp32 bytes per parameter
+
 template <bool NT> __device__ __forceinline__ f32x4_t adam_ld4(const float* p, int i) {
     const f32x4_t* q = reinterpret_cast<const f32x4_t*>(p) + i;
     if (NT) return __builtin_nontemporal_load(q);

@@ -148,57 +148,6 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, long ld, int ro
     else unsafeAtomicAdd(out + c, acc);
 }
 
-// The same for 16-byte aligned rows (the bias gradients of FFN1 / QKV at thousands of tokens, engine.EncoderStack): a wave covers
-// 64 x (8 bf16 | 4 f32) columns with 16-byte loads, the workgroup's four waves take every fourth row with four loads in flight,
-// and meet in LDS in a fixed order.  (The element-per-lane kernel above moves 37.7 MB in 24 us at 6144 x 3072.)
-template <typename T>
-__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* x, long ld, int rows, int n, float* out, int rows_per_block) {
-    constexpr int V = 16 / (int)sizeof(T);
-    __shared__ float red[4][64 * V];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c0 = (blockIdx.x * 64 + lane) * V;
-    const bool live = c0 < n;                                   // n % V == 0 (host)
-    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-    float acc[V];
-#pragma unroll
-    for (int v = 0; v < V; ++v) acc[v] = 0.f;
-    auto add = [&](const u32x4_t q) {
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            if constexpr (sizeof(T) == 2) {
-                acc[2 * d] += __uint_as_float(q[d] << 16);
-                acc[2 * d + 1] += __uint_as_float(q[d] & 0xFFFF0000u);
-            } else {
-                acc[d] += __uint_as_float(q[d]);
-            }
-        }
-    };
-    if (live) {
-        const T* p = x + c0;
-        int r = r0 + w;
-        for (; r + 12 < r1; r += 16) {
-            const u32x4_t a = *reinterpret_cast<const u32x4_t*>(p + (long)r * ld);
-            const u32x4_t b = *reinterpret_cast<const u32x4_t*>(p + (long)(r + 4) * ld);
-            const u32x4_t c = *reinterpret_cast<const u32x4_t*>(p + (long)(r + 8) * ld);
-            const u32x4_t d = *reinterpret_cast<const u32x4_t*>(p + (long)(r + 12) * ld);
-            add(a); add(b); add(c); add(d);
-        }
-        for (; r < r1; r += 4) add(*reinterpret_cast<const u32x4_t*>(p + (long)r * ld));
-    }
-#pragma unroll
-    for (int v = 0; v < V; ++v) red[w][lane * V + v] = acc[v];
-    __syncthreads();
-    if (w == 0 && live) {
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-            const int k = lane * V + v;
-            const float t = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
-            if (gridDim.y == 1) out[c0 + v] += t;               // deterministic mode: one workgroup per column strip
-            else unsafeAtomicAdd(out + c0 + v, t);
-        }
-    }
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void scale_ct_kernel(T* x, long n, const float* s) {
     const float k = s[0];
@@ -471,20 +420,8 @@ extern "C" int univl_colsum(int32_t dtype, const void* x, int64_t ld, int32_t ro
     UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(x && out && rows > 0 && n > 0, UNIVL_EINVAL, "univl_colsum: bad argument");
     const int rpb = univl_deterministic() ? rows : 64;
-    const int vec = dtype == UNIVL_DT_BF16 ? 8 : 4;
-    // opt-in (UNIVL_COLSUM_VEC=1, read per call so that a test can run both forms): at 128 pairs the step did not get faster with
-    // it (12.70 vs 12.59 ms, profiles/r03z3_ab_colsum_b128.txt) -- the column sums are not what the chain waits for
-    const char* vec_env = getenv("UNIVL_COLSUM_VEC");
-    const bool wide = vec_env && atoi(vec_env) == 1;
-    if (wide && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ld % vec == 0 && n % vec == 0 && rows >= 16) {
-        dim3 vgrid((n / vec + 63) / 64, (rows + rpb - 1) / rpb);
-        if (dtype == UNIVL_DT_BF16)
-            hipLaunchKernelGGL((colsum_vec_kernel<__bf16>), vgrid, dim3(256), 0, stream, reinterpret_cast<const __bf16*>(x), (long)ld, rows, n, out, rpb);
-        else
-            hipLaunchKernelGGL((colsum_vec_kernel<float>), vgrid, dim3(256), 0, stream, reinterpret_cast<const float*>(x), (long)ld, rows, n, out, rpb);
-        UNIVL_LAUNCH_CHECK();
-        return UNIVL_OK;
-    }
+    // (a 16-byte-vector form of this kernel was measured at 128 pairs and removed: 12.70 vs 12.59 ms per step,
+    // profiles/r03z3_ab_colsum_b128.txt -- the column sums are not what the chain waits for)
     dim3 grid((n + 255) / 256, (rows + rpb - 1) / rpb);
     if (dtype == UNIVL_DT_BF16)
         hipLaunchKernelGGL((colsum_kernel<__bf16>), grid, dim3(256), 0, stream, reinterpret_cast<const __bf16*>(x), (long)ld, rows, n, out, rpb);

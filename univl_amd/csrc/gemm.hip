@@ -196,18 +196,10 @@ template <typename T, bool TR, int ROWS, int BK, int NT = 256> struct Tile {
     }
 };
 
-// BURST = 0: two LDS stages, tile t+1 streams in while tile t is multiplied (one wait + barrier per K step).
-// BURST = n: up to n stages, ALL of the workgroup's K steps are issued before the first wait and multiplied after ONE
-// barrier.  At M <= a few hundred rows the K loop is a chain of dependent DMA round trips, not MFMA work: a workgroup
-// whose whole contraction slice (<= n x BK) fits the 160 KB LDS pays one round trip instead of K / BK of them.
-//
-// D = 2: the two-stage loop above.  D = 3 / 4: a ring of D stages with COUNTED waits -- the tiles of the next D - 2 K steps stay
-// in flight across the barrier (s_waitcnt vmcnt(pieces of the younger tiles) instead of vmcnt(0)), so a workgroup that is
-// alone on its compute unit (the 256x128 tile: 8 waves, 144 KB of LDS) still has two DMA round trips under way while it
-// multiplies.  WGM x WGN waves; every wave owns a (BM / WGM) x (BN / WGN) sub-tile.
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC, int BURST = 0, int WGM = 2, int WGN = 2>
+// Two LDS stages: tile t+1 streams in while tile t is multiplied (one wait + barrier per K step).  WGM x WGN waves; every wave owns a
+// (BM / WGM) x (BN / WGN) sub-tile.  (Measured and removed in round 4, numbers in DESIGN.md section 8: a three-stage ring with counted
+// waits, a 256 x 128 tile on that ring, a "burst" form with the whole contraction slice in one DMA burst.)
+template <typename T, bool TA, bool TB, int BM, int BN, int NC, int WGM = 2, int WGN = 2>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const int by, const int bz, const int nz) {
     constexpr int CH = Mma<T>::CH;
     constexpr int BK = NC * CH;          // contraction depth of one LDS stage (NC chunks of CH)
@@ -216,14 +208,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     using TileB = Tile<T, TB, BN, BK, NT>;
     constexpr int WM = BM / WGM, WN = BN / WGN;      // per-wave sub-tile
     constexpr int MI = WM / 16, NI = WN / 16;
-    static_assert(D >= 2 && D <= 4, "two LDS stages, or a ring of three / four");
+    constexpr int D = 2;
     static_assert(BM <= NT, "the bias-gradient pass uses one thread per tile row");
 
     // ONE dynamic LDS object (a second __shared__ object makes hipcc drain vmcnt(0) before every ds_read)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* sA = smem_raw;
     unsigned char* sB = sA + D * TileA::BYTES;
-    constexpr int STAGE = TileA::BYTES + TileB::BYTES;       // BURST layout: stage s = [A_s | B_s] at smem_raw + s * STAGE
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -278,60 +269,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         TileA::load_tail(ta, pa, stepA * nfull, p.lda, krem, tid);
         TileB::load_tail(tb, pb, stepB * nfull, p.ldb, krem, tid);
     }
-    if constexpr (BURST > 0) {
-        for (int t = 0; t < nfull; ++t) {
-            TileA::issue(pa, smem_raw + t * STAGE, tid);
-            TileB::issue(pb, smem_raw + t * STAGE + TileA::BYTES, tid);
-            TileA::advance(pa, stepA);
-            TileB::advance(pb, stepB);
-        }
-        if (krem > 0) {
-            TileA::store_tail(ta, smem_raw + nfull * STAGE, krem, tid);
-            TileB::store_tail(tb, smem_raw + nfull * STAGE + TileA::BYTES, krem, tid);
-        }
-        __syncthreads();                                     // carries the vmcnt(0) for every DMA issued above
-        const int nst = nfull + (krem > 0 ? 1 : 0);
-        for (int t = 0; t < nst; ++t) compute(smem_raw + t * STAGE, smem_raw + t * STAGE + TileA::BYTES);
-    } else if constexpr (D > 2) {
-        // ring of D stages: tile t lives in stage t % D; tiles t+1 .. t+D-2 are in flight while tile t is multiplied
-        constexpr int PIECES = TileA::PER_THREAD + TileB::PER_THREAD;      // DMA instructions per wave and tile
-        const int npre = min(D - 1, nfull);
-        for (int s = 0; s < npre; ++s) {
-            TileA::issue(pa, sA + s * TileA::BYTES, tid);
-            TileB::issue(pb, sB + s * TileB::BYTES, tid);
-            TileA::advance(pa, stepA);
-            TileB::advance(pb, stepB);
-        }
-        int cur = 0, nxt = (D - 1) % D;           // stage of tile t / of tile t + D - 1 (= the stage tile t - 1 just left)
-        for (int t = 0; t < nfull; ++t) {
-            // this wave's pieces of tile t have landed once at most the pieces of the younger tiles are outstanding
-            const int young = min(D - 2, nfull - 1 - t);
-            if (young >= 2) wait_vm<2 * PIECES>();
-            else if (young == 1) wait_vm<PIECES>();
-            else wait_vm<0>();
-            // ... and behind the barrier everybody's have; every wave has also retired its reads of stage (t - 1) % D
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (t + D - 1 < nfull) {
-                TileA::issue(pa, sA + nxt * TileA::BYTES, tid);
-                TileB::issue(pb, sB + nxt * TileB::BYTES, tid);
-                TileA::advance(pa, stepA);
-                TileB::advance(pb, stepB);
-            }
-            compute(sA + cur * TileA::BYTES, sB + cur * TileB::BYTES);
-            cur = (cur + 1 == D) ? 0 : cur + 1;
-            nxt = (nxt + 1 == D) ? 0 : nxt + 1;
-        }
-        if (krem > 0) {
-            // stage nfull % D: last read D - 1 barriers ago (or never), no DMA targets it
-            unsigned char* cA = sA + cur * TileA::BYTES;
-            unsigned char* cB = sB + cur * TileB::BYTES;
-            TileA::store_tail(ta, cA, krem, tid);
-            TileB::store_tail(tb, cB, krem, tid);
-            __syncthreads();
-            compute(cA, cB);
-        }
-    } else {
     if (nfull > 0) {
         // double-buffered LDS-DMA pipeline: tile t+1 streams into the other stage while tile t is multiplied; the
         // __syncthreads() at the end of a step carries the vmcnt(0) that makes tile t+1 visible and releases stage t.
@@ -360,7 +297,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         TileB::store_tail(tb, cB, krem, tid);
         __syncthreads();
         compute(cA, cB);
-    }
     }
 
     UNIVL_TRACE_AT(2);
@@ -455,7 +391,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (!(vrow[a][r] && vcol[b])) continue;
-                if ((p.flags & UNIVL_GEMM_PROBE_NOSTORE) && ev[b][r] != 12345.678f) continue;      // measurement probe: no stores
+#ifdef UNIVL_TRACE
+                if ((p.flags & UNIVL_GEMM_PROBE_NOSTORE) && ev[b][r] != 12345.678f) continue;      // measurement build only: no stores
+#endif
                 const long o = orow[a][r] * p.ldc + ocol[b];
                 if (atomic) {
                     unsafeAtomicAdd(p.C32 + o, ev[b][r]);
@@ -542,33 +480,11 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz, int gm) {
 
 // (hipcc: the second launch bound is WAVES PER SIMD.)  The half-width tiles (128 x 64 / 64 x 128, 48 KB of LDS) are built for THREE
 // resident workgroups per compute unit: 6 waves per SIMD (<= 80 VGPRs) on 8 waves, 3 on 4 waves.
-template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC, int WGM, int WGN>
+template <typename T, bool TA, bool TB, int BM, int BN, int NC, int WGM, int WGN>
 __global__ __launch_bounds__(64 * WGM * WGN, (BM != BN && BM * BN == 128 * 64) ? (WGM * WGN == 8 ? 6 : 3) : 2) void gemm_kernel(GemmArgs p) {
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (p.flags & UNIVL_GEMM_XCD_MAP) xcd_tile(bx, by, bz, p.gm);
-    gemm_tile<T, TA, TB, BM, BN, D, NC, 0, WGM, WGN>(p, bx, by, bz, gridDim.z);
-}
-
-template <typename T, bool TA, bool TB, int BM, int BN, int NC, int BURST>
-__global__ __launch_bounds__(256) void gemm_burst_kernel(GemmArgs p) {
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (p.flags & UNIVL_GEMM_XCD_MAP) xcd_tile(bx, by, bz, p.gm);
-    gemm_tile<T, TA, TB, BM, BN, 2, NC, BURST>(p, bx, by, bz, gridDim.z);
-}
-
-template <typename T, bool TA, bool TB, int BM, int BN, int NC, int BURST>
-int launch_burst(const GemmArgs& a, int ksplit, hipStream_t stream) {
-    constexpr int BK = NC * Mma<T>::CH;
-    using TileA = Tile<T, TA, BM, BK>;
-    using TileB = Tile<T, TB, BN, BK>;
-    const int nst = (a.ksplit_len + BK - 1) / BK;                      // stages this launch really needs (<= BURST)
-    const size_t smem = (size_t)nst * (TileA::BYTES + TileB::BYTES);
-    static bool attr_done[UNIVL_MAX_DEVICES] = {};
-    univl_allow_lds(gemm_burst_kernel<T, TA, TB, BM, BN, NC, BURST>, (size_t)BURST * (TileA::BYTES + TileB::BYTES), attr_done);
-    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, ksplit);
-    hipLaunchKernelGGL((gemm_burst_kernel<T, TA, TB, BM, BN, NC, BURST>), grid, dim3(256), smem, stream, a);
-    UNIVL_LAUNCH_CHECK();
-    return UNIVL_OK;
+    gemm_tile<T, TA, TB, BM, BN, NC, WGM, WGN>(p, bx, by, bz, gridDim.z);
 }
 
 // Up to UNIVL_GEMM_GROUP_MAX independent problems of the same operand layout in ONE launch (the four weight-gradient
@@ -583,7 +499,7 @@ struct GroupArgs {
 // A grid smaller than the number of tiles walks them with stride gridDim.x: the "background" form of the layer's
 // weight-gradient launch (engine.EncoderStack, UNIVL_WGRAD_BLOCKS) occupies only that many workgroups while the next
 // layer's latency-bound dgrad chain runs beside it on another stream.
-template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC, int WGM, int WGN>
+template <typename T, bool TA, bool TB, int BM, int BN, int NC, int WGM, int WGN>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_group_kernel(GroupArgs g) {
   const int total = g.first[UNIVL_GEMM_GROUP_MAX];
   const bool remap = (g.p[0].flags & UNIVL_GEMM_XCD_MAP) && gridDim.x >= total && total >= 16;   // one workgroup per tile
@@ -608,23 +524,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_group_kernel(GroupArgs
         by = rem / nx;
         bx = rem - by * nx;
     }
-    gemm_tile<T, TA, TB, BM, BN, D, NC, 0, WGM, WGN>(p, bx, by, bz, nz);
+    gemm_tile<T, TA, TB, BM, BN, NC, WGM, WGN>(p, bx, by, bz, nz);
     if (gridDim.x < total) __syncthreads();           // the next tile's DMA reuses the LDS stages
   }
 }
 
-template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC, int WGM = 2, int WGN = 2>
+template <typename T, bool TA, bool TB, int BM, int BN, int NC, int WGM = 2, int WGN = 2>
 int launch_group(const GroupArgs& g, int max_blocks, hipStream_t stream) {
     constexpr int BK = NC * Mma<T>::CH, NT = 64 * WGM * WGN;
     using TileA = Tile<T, TA, BM, BK, NT>;
     using TileB = Tile<T, TB, BN, BK, NT>;
     // NC == 6 is the one-K-step variant: only stage 0 of B is ever touched (A keeps the two-stage offset layout)
-    const size_t smem = NC == 6 ? 2 * TileA::BYTES + TileB::BYTES : D * (TileA::BYTES + TileB::BYTES);
+    const size_t smem = NC == 6 ? 2 * TileA::BYTES + TileB::BYTES : 2 * (TileA::BYTES + TileB::BYTES);
     static bool attr_done[UNIVL_MAX_DEVICES] = {};   // per instantiation, per device
-    if (smem > 48 * 1024) univl_allow_lds(gemm_group_kernel<T, TA, TB, BM, BN, D, NC, WGM, WGN>, smem, attr_done);
+    if (smem > 48 * 1024) univl_allow_lds(gemm_group_kernel<T, TA, TB, BM, BN, NC, WGM, WGN>, smem, attr_done);
     const int total = g.first[UNIVL_GEMM_GROUP_MAX];
     const int grid = (max_blocks > 0 && max_blocks < total) ? max_blocks : total;
-    hipLaunchKernelGGL((gemm_group_kernel<T, TA, TB, BM, BN, D, NC, WGM, WGN>), dim3(grid), dim3(NT), smem, stream, g);
+    hipLaunchKernelGGL((gemm_group_kernel<T, TA, TB, BM, BN, NC, WGM, WGN>), dim3(grid), dim3(NT), smem, stream, g);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
@@ -662,10 +578,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pair_kernel(PairArgs a) {
     if (w0 < a.nd_pad) {
         if (w0 >= a.nd) return;                                  // padding workgroup (whole block: no barrier is skipped)
         pair_tile(w0, a.nd, a.dnx, a.dny, a.dnz, a.d.flags, a.d.gm, bx, by, bz);
-        gemm_tile<__bf16, false, true, 64, 64, 2, 4, 0, 2, 4>(a.d, bx, by, bz, a.dnz);
+        gemm_tile<__bf16, false, true, 64, 64, 4, 2, 4>(a.d, bx, by, bz, a.dnz);
     } else {
         pair_tile(w0 - a.nd_pad, a.nw, a.wnx, a.wny, a.wnz, a.w.flags, a.w.gm, bx, by, bz);
-        gemm_tile<__bf16, true, true, 64, 64, 2, NCW, 0, 2, 4>(a.w, bx, by, bz, a.wnz);
+        gemm_tile<__bf16, true, true, 64, 64, NCW, 2, 4>(a.w, bx, by, bz, a.wnz);
     }
 }
 
@@ -697,34 +613,34 @@ __global__ __launch_bounds__(512, 2) void gemm_adam_kernel(GemmArgs g, int nd, i
         if (w0 >= nd) return;                                  // padding workgroup
         int bx, by, bz;
         pair_tile(w0, nd, nx, ny, nz, g.flags, g.gm, bx, by, bz);
-        gemm_tile<__bf16, false, false, 64, 64, 2, 4, 0, 2, 4>(g, bx, by, bz, nz);
+        gemm_tile<__bf16, false, false, 64, 64, 4, 2, 4>(g, bx, by, bz, nz);
     } else {
         const int nb = (int)gridDim.x - nd_pad;
         for (int c = c0 + (w0 - nd_pad); c < c1; c += nb) adam_chunk<NT, 512>(a, c);
     }
 }
 
-template <typename T, bool TA, bool TB, int BM, int BN, int D, int NC, int WGM = 2, int WGN = 2>
+template <typename T, bool TA, bool TB, int BM, int BN, int NC, int WGM = 2, int WGN = 2>
 int launch(const GemmArgs& a, int ksplit, hipStream_t stream) {
     constexpr int BK = NC * Mma<T>::CH, NT = 64 * WGM * WGN;
     using TileA = Tile<T, TA, BM, BK, NT>;
     using TileB = Tile<T, TB, BN, BK, NT>;
     // NC == 6 is the one-K-step variant: only stage 0 of B is ever touched (A keeps the two-stage offset layout)
-    const size_t smem = NC == 6 ? 2 * TileA::BYTES + TileB::BYTES : D * (TileA::BYTES + TileB::BYTES);
+    const size_t smem = NC == 6 ? 2 * TileA::BYTES + TileB::BYTES : 2 * (TileA::BYTES + TileB::BYTES);
     static bool attr_done[UNIVL_MAX_DEVICES] = {};   // per instantiation, per device
-    if (smem > 48 * 1024) univl_allow_lds(gemm_kernel<T, TA, TB, BM, BN, D, NC, WGM, WGN>, smem, attr_done);
+    if (smem > 48 * 1024) univl_allow_lds(gemm_kernel<T, TA, TB, BM, BN, NC, WGM, WGN>, smem, attr_done);
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, ksplit);
-    hipLaunchKernelGGL((gemm_kernel<T, TA, TB, BM, BN, D, NC, WGM, WGN>), grid, dim3(NT), smem, stream, a);
+    hipLaunchKernelGGL((gemm_kernel<T, TA, TB, BM, BN, NC, WGM, WGN>), grid, dim3(NT), smem, stream, a);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
 
-template <typename T, int BM, int BN, int D, int NC, int WGM = 2, int WGN = 2>
+template <typename T, int BM, int BN, int NC, int WGM = 2, int WGN = 2>
 int dispatch_trans(const GemmArgs& a, int ta, int tb, int ksplit, hipStream_t s) {
-    if (!ta && !tb) return launch<T, false, false, BM, BN, D, NC, WGM, WGN>(a, ksplit, s);
-    if (!ta && tb) return launch<T, false, true, BM, BN, D, NC, WGM, WGN>(a, ksplit, s);
-    if (ta && tb) return launch<T, true, true, BM, BN, D, NC, WGM, WGN>(a, ksplit, s);
-    return launch<T, true, false, BM, BN, D, NC, WGM, WGN>(a, ksplit, s);
+    if (!ta && !tb) return launch<T, false, false, BM, BN, NC, WGM, WGN>(a, ksplit, s);
+    if (!ta && tb) return launch<T, false, true, BM, BN, NC, WGM, WGN>(a, ksplit, s);
+    if (ta && tb) return launch<T, true, true, BM, BN, NC, WGM, WGN>(a, ksplit, s);
+    return launch<T, true, false, BM, BN, NC, WGM, WGN>(a, ksplit, s);
 }
 
 }  // namespace
@@ -757,61 +673,52 @@ __global__ __launch_bounds__(256) void dot_kernel(GemmArgs p) {
 }
 
 // validation + kernel arguments shared by the single and the grouped entry point.
-// Tile geometry (UnivlGemm.tile, 0 = chosen here) and pipeline depth (UnivlGemm.stages, 0 = chosen here):
-//   64   64 x 64,  4 waves, BK = 128 bf16   -- everything below ~256 big tiles: parallelism over tile efficiency
-//   128  128 x 128, 4 waves, BK = 64        -- two workgroups per compute unit
-//   256  256 x 128, 8 waves (4 x 2), BK = 64, bf16 only -- 85 flop per staged byte instead of 64; one workgroup per compute
-//        unit, which is what the three-stage ring is for
+// Tile geometry (UnivlGemm.tile, 0 = chosen here); the two-stage pipeline is the only one (UnivlGemm.stages: 0 or 2):
+//   64   64 x 64,  BK = 128 bf16 (64 for the deep grouped weight gradients, 192 for the one-step weight gradients at 192 tokens)
+//        -- everything below 256 big tiles: parallelism over tile efficiency
+//   128  128 x 128, BK = 64 -- two workgroups per compute unit
 //   12864 / 64128  128 x 64 / 64 x 128, 8 waves, BK = 64, bf16, K-major A (forward / dgrad), no sumsq / dbias, univl_gemm only
 //        (else 128): 48 KB of LDS and <= 80 VGPRs, i.e. THREE workgroups per compute unit (768 slots) instead of two (512).
-//        Picked instead of the 128 tile where it fills its slots better (UNIVL_GEMM_RECT = 2 | 1: 64 x 128 | 128 x 64, 0: never):
-//        a 6144 x 768 output is 288 tiles of 128 x 128 in 512 slots -- 32 units run two workgroups, 224 run one -- but 576 half
-//        tiles in 768 slots; 6144 x 3072 is 2.25 rounds of 512 slots against exactly 3 rounds of 768; 6144 x 2304 (1.69 rounds
-//        against 2.25) stays on the 128 tile.  Per-shape table at 6144 rows: profiles/r03u_gemm_variants_b128.txt (+3..13 % per
-//        product where picked; bit-identical results: same 64-deep K steps, same chunk order per output element).
-// stages = 2: the double-buffered loop; 3: ring with counted waits (bf16 only).  waves = 4 | 8 (tiles 64 / 128, bf16 only).
-struct Choice { int tile, nc, stages, waves; };
+//        Picked instead of the 128 tile where it fills its slots better: a 6144 x 768 output is 288 tiles of 128 x 128 in 512 slots
+//        -- 32 units run two workgroups, 224 run one -- but 576 half tiles in 768 slots; 6144 x 3072 is 2.25 rounds of 512 slots
+//        against exactly 3 rounds of 768; 6144 x 2304 (1.69 rounds against 2.25) stays on the 128 tile.  Per-shape table at 6144
+//        rows: profiles/r03u_gemm_variants_b128.txt (+3..13 % per product where picked; bit-identical results: same 64-deep K
+//        steps, same chunk order per output element).
+// waves = 4 | 8 (tiles 64 / 128, bf16 only; 0 = 8 where the kernel form allows it).
+// Every choice is a function of the descriptor alone: no environment switches (round 4; the A/B history is in DESIGN.md section 8).
+struct Choice { int tile, nc, waves; };
 
-static inline long env_long(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
+constexpr long GEMM_BIG_MIN = 256;      // 128 x 128 tiles from this many of them on (measured: +6 % at 128 pairs over 384, same at 16)
+constexpr int GEMM_GM = 8;              // row tiles per L2 band of the tile order (xcd map)
+constexpr long GEMM_NC64_MIN = 1024;    // grouped weight gradients contracting over at least this many tokens: 64-deep K steps, 4 waves
 
 static Choice choose(const UnivlGemm* d, int forced_tile, int forced_nc = 0, bool allow_rect = false) {
-    static const long big_min = env_long("UNIVL_GEMM_BIG_MIN", 256L);
-    static const long t256_min = env_long("UNIVL_GEMM_T256_MIN", 0L);              // 0: never picked automatically
-    static const int stages_dflt = (int)env_long("UNIVL_GEMM_STAGES", 2L);         // tiles 64 / 128
-    static const int stages256 = (int)env_long("UNIVL_GEMM_STAGES256", 3L);
-    static const int one_step = (int)env_long("UNIVL_GEMM_ONESTEP", 1L);
     const bool bf16 = d->dtype == UNIVL_BF16;
     const int want = forced_tile ? forced_tile : d->tile;
     const long tiles128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
-    const long tiles256 = (long)((d->M + 255) / 256) * ((d->N + 127) / 128);
-    static const int rect = (int)env_long("UNIVL_GEMM_RECT", 2L);                  // 0 off | 1: 128 x 64 | 2: 64 x 128
     const bool rect_ok = allow_rect && bf16 && !d->trans_a && !d->sumsq && !d->dbias;      // univl_gemm only (single launch)
     Choice c;
     if (want == 12864 || want == 64128) {
         c.tile = rect_ok ? want : 128;
         c.nc = 2;
-        c.stages = 2;
         c.waves = !rect_ok ? 4 : (d->waves ? d->waves : 8);
         return c;
     }
-    c.tile = (want >= 128 || (want == 0 && tiles128 >= big_min)) ? 128 : 64;
-    if (rect && want == 0 && c.tile == 128 && rect_ok && d->stages == 0 && d->waves == 0) {
+    c.tile = (want >= 128 || (want == 0 && tiles128 >= GEMM_BIG_MIN)) ? 128 : 64;
+    if (want == 0 && c.tile == 128 && rect_ok && d->waves == 0) {
         // fill of the resident-workgroup slots in the last round: tiles / (rounds x slots)
-        const long tiles_r = rect == 2 ? (long)((d->M + 63) / 64) * ((d->N + 127) / 128) : (long)((d->M + 127) / 128) * ((d->N + 63) / 64);
+        const long tiles_r = (long)((d->M + 63) / 64) * ((d->N + 127) / 128);
         const double fill128 = (double)tiles128 / (double)(((tiles128 + 511) / 512) * 512);
         const double fill_r = (double)tiles_r / (double)(((tiles_r + 767) / 768) * 768);
         // measured (6144 rows): with T-major B (dgrad) the half tile wins at equal fill and above; with K-major B (forward) it
         // needs a clear fill advantage (0.75 vs 0.84: -7 %; 1.0 vs 0.75: +1 %; 0.75 vs 0.56: +3..9 %)
         if (fill_r >= fill128 * (d->trans_b ? 1.0 : 1.2)) {
-            c.tile = rect == 2 ? 64128 : 12864;
+            c.tile = 64128;
             c.nc = 2;
-            c.stages = 2;
             c.waves = 8;
             return c;
         }
     }
-    if (bf16 && (want == 256 || (want == 0 && c.tile == 128 && t256_min > 0 && tiles256 >= t256_min))) c.tile = 256;
-    if (c.tile == 256 && d->sumsq && d->sumsq_rows % 256 != 0) c.tile = 128;     // a tile must not straddle two tensors
     c.nc = c.tile == 64 ? 4 : 2;
     // forced_nc = 2 (the grouped launch of deep weight-gradient products, univl_gemm_group_limited): 64-deep K steps instead of
     // 128-deep ones -- half the LDS per workgroup (32 KB), i.e. four workgroups per compute unit instead of two to hide the DMA
@@ -821,15 +728,11 @@ static Choice choose(const UnivlGemm* d, int forced_tile, int forced_nc = 0, boo
     const int ksplit = (d->ksplit < 1 || univl_deterministic()) ? 1 : d->ksplit;
     // weight gradients at 4 pairs x 48 tokens contract over exactly 192 rows: one 192-deep stage = ONE DMA round trip
     // per workgroup, no partial tile through registers (the 128-deep stage needs a 128-step plus a masked 64-tail)
-    if (one_step && c.tile == 64 && bf16 && d->trans_a && d->trans_b && d->K == 192 && ksplit == 1) c.nc = 6;
-    c.stages = d->stages ? d->stages : (c.tile == 256 ? stages256 : stages_dflt);
-    if (c.stages < 2 || c.stages > 3 || !bf16 || c.nc == 6) c.stages = 2;
+    if (c.tile == 64 && bf16 && d->trans_a && d->trans_b && d->K == 192 && ksplit == 1) c.nc = 6;
     // 8 waves on the 64 / 128 tiles: the same tile cut into twice as many wave sub-tiles.  Less MFMA work per fragment read, but
-    // twice as many waves issuing LDS-DMA -- a wave sustains ~25 GB/s of DMA, and below a few hundred rows that, not MFMA, is
-    // what a K step waits for.
-    static const int waves_dflt = (int)env_long("UNIVL_GEMM_WAVES", 8L);          // measured (profiles/README.md, round 2): -2 % per step at 4 pairs, -5 % at 128
-    c.waves = c.tile == 256 ? 8 : (d->waves ? d->waves : waves_dflt);
-    if (c.waves != 8 || !bf16 || c.nc == 6 || (d->sumsq && c.tile == 64)) c.waves = c.tile == 256 ? 8 : 4;   // sumsq: rows x N / 1024 slots
+    // twice as many waves issuing LDS-DMA (measured, round 2: -2 % per step at 4 pairs, -5 % at 128)
+    c.waves = d->waves ? d->waves : 8;
+    if (c.waves != 8 || !bf16 || c.nc == 6 || (d->sumsq && c.tile == 64)) c.waves = 4;   // sumsq: rows x N / 1024 slots
     return c;
 }
 
@@ -838,9 +741,9 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int 
     UNIVL_CHECK_ARG(d->dtype == UNIVL_F32 || d->dtype == UNIVL_BF16, UNIVL_EUNSUPPORTED, "univl_gemm: dtype %d", d->dtype);
     UNIVL_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, UNIVL_EINVAL, "univl_gemm: empty problem %dx%dx%d", d->M, d->N, d->K);
     UNIVL_CHECK_ARG(d->A && d->B && (d->C32 || d->C16), UNIVL_EINVAL, "univl_gemm: null operand");
-    UNIVL_CHECK_ARG(d->tile == 0 || d->tile == 64 || d->tile == 128 || d->tile == 256 || d->tile == 12864 || d->tile == 64128, UNIVL_EINVAL,
-                    "univl_gemm: tile %d (0, 64, 128, 256, 12864, 64128)", d->tile);
-    UNIVL_CHECK_ARG(d->stages == 0 || d->stages == 2 || d->stages == 3, UNIVL_EINVAL, "univl_gemm: stages %d (0, 2, 3)", d->stages);
+    UNIVL_CHECK_ARG(d->tile == 0 || d->tile == 64 || d->tile == 128 || d->tile == 12864 || d->tile == 64128, UNIVL_EINVAL,
+                    "univl_gemm: tile %d (0, 64, 128, 12864, 64128)", d->tile);
+    UNIVL_CHECK_ARG(d->stages == 0 || d->stages == 2, UNIVL_EINVAL, "univl_gemm: stages %d (0, 2)", d->stages);
     UNIVL_CHECK_ARG(d->waves == 0 || d->waves == 4 || d->waves == 8, UNIVL_EINVAL, "univl_gemm: waves %d (0, 4, 8)", d->waves);
     const int epc = d->dtype == UNIVL_BF16 ? 8 : 4;
     UNIVL_CHECK_ARG(aligned16(d->A) && aligned16(d->B) && d->lda % epc == 0 && d->ldb % epc == 0, UNIVL_EALIGN,
@@ -870,13 +773,14 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int 
     a.A = d->A; a.B = d->B; a.lda = d->lda; a.ldb = d->ldb; a.M = d->M; a.N = d->N; a.K = d->K;
     a.C32 = d->C32; a.C16 = d->C16; a.ldc = d->ldc; a.bias = d->bias; a.R = d->R; a.ldr = d->ldr;
     a.aux = d->aux; a.ldaux = d->ldaux; a.dbias = d->dbias; a.alpha = d->alpha;
-    static const int xcd_map = (int)env_long("UNIVL_GEMM_XCD", 1L);
-    static const int probe = (int)env_long("UNIVL_GEMM_PROBE", 0L);
-    a.flags = flags | (ksplit > 1 ? UNIVL_GEMM_ATOMIC : 0) | (xcd_map ? UNIVL_GEMM_XCD_MAP : 0) | ((probe & 1) ? UNIVL_GEMM_PROBE_NOSTORE : 0);
+    a.flags = flags | (ksplit > 1 ? UNIVL_GEMM_ATOMIC : 0) | UNIVL_GEMM_XCD_MAP;
+#ifdef UNIVL_TRACE
+    static const bool probe = getenv("UNIVL_GEMM_PROBE") && atoi(getenv("UNIVL_GEMM_PROBE")) != 0;      // measurement build only
+    if (probe) a.flags |= UNIVL_GEMM_PROBE_NOSTORE;
+#endif
     a.ksplit_len = klen;
     a.sumsq = d->sumsq; a.sumsq_rows = d->sumsq_rows; a.sumsq_stride = d->sumsq_stride;
-    static const int gm = (int)env_long("UNIVL_GEMM_GM", 8L);
-    a.gm = gm;
+    a.gm = GEMM_GM;
     return UNIVL_OK;
 }
 
@@ -912,50 +816,30 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
     }
     const int ta = d->trans_a, tb = d->trans_b;
     if (d->dtype == UNIVL_BF16) {
-        if (c.tile == 256) {
-            if (c.stages == 3) return dispatch_trans<__bf16, 256, 128, 3, 2, 4, 2>(a, ta, tb, ksplit, stream);
-            return dispatch_trans<__bf16, 256, 128, 2, 2, 4, 2>(a, ta, tb, ksplit, stream);
-        }
         if (c.tile == 12864) {                       // K-major A only (choose): forward and dgrad products
-            if (c.waves == 8) return tb ? launch<__bf16, false, true, 128, 64, 2, 2, 4, 2>(a, ksplit, stream)
-                                        : launch<__bf16, false, false, 128, 64, 2, 2, 4, 2>(a, ksplit, stream);
-            return tb ? launch<__bf16, false, true, 128, 64, 2, 2, 2, 2>(a, ksplit, stream) : launch<__bf16, false, false, 128, 64, 2, 2, 2, 2>(a, ksplit, stream);
+            if (c.waves == 8) return tb ? launch<__bf16, false, true, 128, 64, 2, 4, 2>(a, ksplit, stream)
+                                        : launch<__bf16, false, false, 128, 64, 2, 4, 2>(a, ksplit, stream);
+            return tb ? launch<__bf16, false, true, 128, 64, 2, 2, 2>(a, ksplit, stream) : launch<__bf16, false, false, 128, 64, 2, 2, 2>(a, ksplit, stream);
         }
         if (c.tile == 64128) {
-            if (c.waves == 8) return tb ? launch<__bf16, false, true, 64, 128, 2, 2, 2, 4>(a, ksplit, stream)
-                                        : launch<__bf16, false, false, 64, 128, 2, 2, 2, 4>(a, ksplit, stream);
-            return tb ? launch<__bf16, false, true, 64, 128, 2, 2, 2, 2>(a, ksplit, stream) : launch<__bf16, false, false, 64, 128, 2, 2, 2, 2>(a, ksplit, stream);
-        }
-        if (c.tile == 128 && c.waves == 8) {
-            if (c.stages == 3) return dispatch_trans<__bf16, 128, 128, 3, 2, 2, 4>(a, ta, tb, ksplit, stream);
-            return dispatch_trans<__bf16, 128, 128, 2, 2, 2, 4>(a, ta, tb, ksplit, stream);
+            if (c.waves == 8) return tb ? launch<__bf16, false, true, 64, 128, 2, 2, 4>(a, ksplit, stream)
+                                        : launch<__bf16, false, false, 64, 128, 2, 2, 4>(a, ksplit, stream);
+            return tb ? launch<__bf16, false, true, 64, 128, 2, 2, 2>(a, ksplit, stream) : launch<__bf16, false, false, 64, 128, 2, 2, 2>(a, ksplit, stream);
         }
         if (c.tile == 128) {
-            if (c.stages == 3) return dispatch_trans<__bf16, 128, 128, 3, 2>(a, ta, tb, ksplit, stream);
-            return dispatch_trans<__bf16, 128, 128, 2, 2>(a, ta, tb, ksplit, stream);
+            if (c.waves == 8) return dispatch_trans<__bf16, 128, 128, 2, 2, 4>(a, ta, tb, ksplit, stream);
+            return dispatch_trans<__bf16, 128, 128, 2>(a, ta, tb, ksplit, stream);
         }
-        if (c.nc == 6) return launch<__bf16, true, true, 64, 64, 2, 6>(a, ksplit, stream);
-        // small-M forward / dgrad products whose contraction slice (the host's split-K choice) is at most 6 x 128 deep:
-        // the whole slice in one LDS-DMA burst, half-width tiles (64x32 forward, 32x64 dgrad) so that twice as many
-        // compute units share the operand traffic (UNIVL_GEMM_BURST=1; measured no better than the two-stage kernel, off)
-        static const int burst = (int)env_long("UNIVL_GEMM_BURST", 0L);
-        if (burst && d->tile == 0 && !d->trans_a && a.ksplit_len <= 6 * 128 && !d->sumsq) {
-            if (!d->trans_b) return launch_burst<__bf16, false, false, 64, 32, 4, 6>(a, ksplit, stream);
-            return launch_burst<__bf16, false, true, 32, 64, 4, 6>(a, ksplit, stream);
-        }
+        if (c.nc == 6) return launch<__bf16, true, true, 64, 64, 6>(a, ksplit, stream);
         if (c.nc == 2) {
-            if (c.waves == 8) return dispatch_trans<__bf16, 64, 64, 2, 2, 2, 4>(a, ta, tb, ksplit, stream);
-            return dispatch_trans<__bf16, 64, 64, 2, 2>(a, ta, tb, ksplit, stream);
+            if (c.waves == 8) return dispatch_trans<__bf16, 64, 64, 2, 2, 4>(a, ta, tb, ksplit, stream);
+            return dispatch_trans<__bf16, 64, 64, 2>(a, ta, tb, ksplit, stream);
         }
-        if (c.waves == 8) {
-            if (c.stages == 3) return dispatch_trans<__bf16, 64, 64, 3, 4, 2, 4>(a, ta, tb, ksplit, stream);
-            return dispatch_trans<__bf16, 64, 64, 2, 4, 2, 4>(a, ta, tb, ksplit, stream);
-        }
-        if (c.stages == 3) return dispatch_trans<__bf16, 64, 64, 3, 4>(a, ta, tb, ksplit, stream);
-        return dispatch_trans<__bf16, 64, 64, 2, 4>(a, ta, tb, ksplit, stream);
+        if (c.waves == 8) return dispatch_trans<__bf16, 64, 64, 4, 2, 4>(a, ta, tb, ksplit, stream);
+        return dispatch_trans<__bf16, 64, 64, 4>(a, ta, tb, ksplit, stream);
     }
-    if (c.tile == 128) return dispatch_trans<float, 128, 128, 2, 2>(a, ta, tb, ksplit, stream);
-    return dispatch_trans<float, 64, 64, 2, 4>(a, ta, tb, ksplit, stream);
+    if (c.tile == 128) return dispatch_trans<float, 128, 128, 2>(a, ta, tb, ksplit, stream);
+    return dispatch_trans<float, 64, 64, 4>(a, ta, tb, ksplit, stream);
 }
 
 extern "C" int univl_gemm_pair(const UnivlGemm* dgrad, const UnivlGemm* wgrad, int32_t dry_run, hipStream_t stream) {
@@ -1010,7 +894,7 @@ extern "C" int univl_gemm_rider(const UnivlGemm* gemm, const UnivlAdam* adam, in
     const int nx = (gemm->N + 63) / 64, ny = (gemm->M + 63) / 64;
     const int nd = nx * ny * ks, nd_pad = (nd + 7) / 8 * 8;
     const int nb = (max_blocks > 0 && max_blocks < chunk_count) ? max_blocks : chunk_count;
-    static const int nt = (int)env_long("UNIVL_ADAM_NT", 1L);
+    const bool nt = univl_adam_nt();              // optim.hip: the one switch of the update's cache policy (UNIVL_ADAM_NT)
     rider_allow_lds();
     if (nt) {
         hipLaunchKernelGGL(gemm_adam_kernel<true>, dim3(nd_pad + nb), dim3(512), RIDER_SMEM, stream, a, nd, nd_pad, nx, ny, ks, *adam,
@@ -1041,75 +925,32 @@ extern "C" int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_block
                     UNIVL_GEMM_GROUP_MAX);
     if (n == 1 && max_blocks <= 0) return univl_gemm(d, stream);
     GroupArgs g;
-    // the group runs one kernel instantiation: the smallest tile / shallowest pipeline any member would pick alone
-    int tile_all = 256, stages_all = 3, waves_all = 8;
+    // the group runs one kernel instantiation: the smallest tile / fewest waves any member would pick alone
+    int tile_all = 128, waves_all = 8;
     for (int i = 0; i < n; ++i) {
         UNIVL_CHECK_ARG(d[i].dtype == d[0].dtype && d[i].trans_a == d[0].trans_a && d[i].trans_b == d[0].trans_b, UNIVL_EINVAL,
                         "univl_gemm_group: members must share dtype and operand layouts");
         const Choice ci = choose(&d[i], 0);
         tile_all = ci.tile < tile_all ? ci.tile : tile_all;
-        stages_all = ci.stages < stages_all ? ci.stages : stages_all;
         waves_all = ci.waves < waves_all ? ci.waves : waves_all;
-    }
-    // Members too small for the 128 tile on their own (a layer's weight gradients: 36-144 tiles each) fill the chip TOGETHER:
-    // with a deep contraction (thousands of tokens) the 64 tile moves twice the operand bytes per flop through every compute
-    // unit and the fabric, so the group takes the 128 tile once it has UNIVL_GEMM_GROUP_BIG_MIN of them (0: never).
-    static const long group_big_min = env_long("UNIVL_GEMM_GROUP_BIG_MIN", 0L);
-    if (group_big_min > 0 && tile_all == 64) {
-        long sum = 0;
-        bool deep = true;
-        for (int i = 0; i < n; ++i) {
-            sum += (long)((d[i].M + 127) / 128) * ((d[i].N + 127) / 128);
-            deep = deep && d[i].K >= 1024 && d[i].tile == 0;
-        }
-        if (deep && sum >= group_big_min) {
-            tile_all = 128; stages_all = 3; waves_all = 8;
-            for (int i = 0; i < n; ++i) {
-                const Choice ci = choose(&d[i], 128);
-                stages_all = ci.stages < stages_all ? ci.stages : stages_all;
-                waves_all = ci.waves < waves_all ? ci.waves : waves_all;
-            }
-        }
-    }
-    // UNIVL_GEMM_GROUP_T256_MINK = k (0: never): a group of bf16 weight-gradient products (both operands T-major) whose contractions
-    // are all at least k deep takes the 256 x 128 tile on the three-stage ring.  A layer's four weight gradients at 6144 tokens are
-    // 1728 tiles of 64 x 64, each pulling 2 x 6144 x 64 x 2 B = 1.5 MB of operand panels through the L2 (2.7 GB per layer and
-    // launch), with 6 transpose reads per 2 MFMAs per wave; they are 216 tiles of 256 x 128 (one round on 256 compute units, 96 K
-    // steps each -- the regime the tile and the ring were built for) pulling 1.0 GB with 16 reads per 16 MFMAs.
-    static const long group_t256_mink = env_long("UNIVL_GEMM_GROUP_T256_MINK", 0L);
-    if (group_t256_mink > 0 && tile_all == 64 && d[0].dtype == UNIVL_BF16 && d[0].trans_a && d[0].trans_b) {
-        bool deep = true;
-        for (int i = 0; i < n; ++i)
-            deep = deep && d[i].K >= group_t256_mink && d[i].tile == 0 && d[i].ksplit <= 1 && !(d[i].sumsq && d[i].sumsq_rows % 256 != 0);
-        if (deep) {
-            tile_all = 256; stages_all = 3; waves_all = 8;
-            for (int i = 0; i < n; ++i) {
-                const Choice ci = choose(&d[i], 256);
-                stages_all = ci.stages < stages_all ? ci.stages : stages_all;
-            }
-        }
     }
     // Weight gradients over thousands of tokens on the 64 tile (the members are too small for the 128 tile): 64-deep K steps, four
     // workgroups per compute unit.  Measured at 128 pairs x 48 tokens (profiles/r03i_ab_summary.txt): 13.55 / 13.49 vs 14.01 / 14.04 ms
-    // per step.  UNIVL_GEMM_NC64_MIN: contraction length from which it applies (0: never).
-    static const long nc64_min = env_long("UNIVL_GEMM_NC64_MIN", 1024L);
+    // per step.
     int forced_nc = 0;
-    if (nc64_min > 0 && tile_all == 64 && d[0].dtype == UNIVL_BF16 && d[0].trans_a && d[0].trans_b) {
+    if (tile_all == 64 && d[0].dtype == UNIVL_BF16 && d[0].trans_a && d[0].trans_b) {
         forced_nc = 2;
-        for (int i = 0; i < n; ++i) if (d[i].K < nc64_min || (d[i].ksplit > 1)) forced_nc = 0;
+        for (int i = 0; i < n; ++i) if (d[i].K < GEMM_NC64_MIN || (d[i].ksplit > 1)) forced_nc = 0;
         // ... on 4 waves (2 x 2, a 32 x 32 sub-tile each: 4 transpose-read fragments per 4 MFMAs) instead of 8 (32 x 16: 3 per 2):
         // isolated, a layer's group at 6144 tokens runs 231 vs 286 us (profiles/r03w_gemm_group_variants_b128.txt)
-        // (the single-GPU step always ran this group on 4 waves -- its fused sum of squares asks for them; this is the same choice
-        // for the data-parallel and pretrain plans, whose weight gradients carry no sum of squares)
-        static const long nc64_waves = env_long("UNIVL_GEMM_NC64_WAVES", 4L);
-        if (forced_nc == 2 && nc64_waves == 4) {
+        if (forced_nc == 2) {
             bool plain = true;
             for (int i = 0; i < n; ++i) plain = plain && d[i].waves == 0;
             if (plain) waves_all = 4;
         }
     }
     int total = 0, nc_all = 0;
-    const int bm = tile_all, bn = tile_all == 256 ? 128 : tile_all;
+    const int bm = tile_all, bn = tile_all;
     for (int i = 0; i < UNIVL_GEMM_GROUP_MAX; ++i) {
         g.first[i] = total;
         if (i >= n) { g.p[i] = g.p[0]; g.nx[i] = g.nxy[i] = g.nz[i] = 1; continue; }
@@ -1126,27 +967,23 @@ extern "C" int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_block
     }
     g.first[UNIVL_GEMM_GROUP_MAX] = total;
     const bool ta = d[0].trans_a, tb = d[0].trans_b;
-    const int D = nc_all == 6 ? 2 : stages_all;
-#define UNIVL_GROUP_CASE(T, BMV, BNV, DV, NCV, WM_, WN_)                                                               \
+#define UNIVL_GROUP_CASE(T, BMV, BNV, NCV, WM_, WN_)                                                                   \
     do {                                                                                                               \
-        if (!ta && !tb) return launch_group<T, false, false, BMV, BNV, DV, NCV, WM_, WN_>(g, max_blocks, stream);      \
-        if (!ta && tb) return launch_group<T, false, true, BMV, BNV, DV, NCV, WM_, WN_>(g, max_blocks, stream);        \
-        if (ta && tb) return launch_group<T, true, true, BMV, BNV, DV, NCV, WM_, WN_>(g, max_blocks, stream);          \
-        return launch_group<T, true, false, BMV, BNV, DV, NCV, WM_, WN_>(g, max_blocks, stream);                       \
+        if (!ta && !tb) return launch_group<T, false, false, BMV, BNV, NCV, WM_, WN_>(g, max_blocks, stream);          \
+        if (!ta && tb) return launch_group<T, false, true, BMV, BNV, NCV, WM_, WN_>(g, max_blocks, stream);            \
+        if (ta && tb) return launch_group<T, true, true, BMV, BNV, NCV, WM_, WN_>(g, max_blocks, stream);              \
+        return launch_group<T, true, false, BMV, BNV, NCV, WM_, WN_>(g, max_blocks, stream);                           \
     } while (0)
     UNIVL_CHECK_ARG(nc_all > 0, UNIVL_EINVAL, "univl_gemm_group: members disagree on the K-step depth (mixed contraction lengths)");
     if (d[0].dtype == UNIVL_BF16) {
-        if (tile_all == 256) { if (D == 3) UNIVL_GROUP_CASE(__bf16, 256, 128, 3, 2, 4, 2); UNIVL_GROUP_CASE(__bf16, 256, 128, 2, 2, 4, 2); }
         const bool w8 = waves_all == 8 && nc_all != 6;
-        if (tile_all == 128 && w8) { if (D == 3) UNIVL_GROUP_CASE(__bf16, 128, 128, 3, 2, 2, 4); UNIVL_GROUP_CASE(__bf16, 128, 128, 2, 2, 2, 4); }
-        if (tile_all == 128) { if (D == 3) UNIVL_GROUP_CASE(__bf16, 128, 128, 3, 2, 2, 2); UNIVL_GROUP_CASE(__bf16, 128, 128, 2, 2, 2, 2); }
-        if (nc_all == 6) return launch_group<__bf16, true, true, 64, 64, 2, 6>(g, max_blocks, stream);
-        if (nc_all == 2 && tile_all == 64) { if (w8) UNIVL_GROUP_CASE(__bf16, 64, 64, 2, 2, 2, 4); UNIVL_GROUP_CASE(__bf16, 64, 64, 2, 2, 2, 2); }
-        if (w8) { if (D == 3) UNIVL_GROUP_CASE(__bf16, 64, 64, 3, 4, 2, 4); UNIVL_GROUP_CASE(__bf16, 64, 64, 2, 4, 2, 4); }
-        if (D == 3) UNIVL_GROUP_CASE(__bf16, 64, 64, 3, 4, 2, 2);
-        UNIVL_GROUP_CASE(__bf16, 64, 64, 2, 4, 2, 2);
+        if (tile_all == 128) { if (w8) UNIVL_GROUP_CASE(__bf16, 128, 128, 2, 2, 4); UNIVL_GROUP_CASE(__bf16, 128, 128, 2, 2, 2); }
+        if (nc_all == 6) return launch_group<__bf16, true, true, 64, 64, 6>(g, max_blocks, stream);
+        if (nc_all == 2) { if (w8) UNIVL_GROUP_CASE(__bf16, 64, 64, 2, 2, 4); UNIVL_GROUP_CASE(__bf16, 64, 64, 2, 2, 2); }
+        if (w8) UNIVL_GROUP_CASE(__bf16, 64, 64, 4, 2, 4);
+        UNIVL_GROUP_CASE(__bf16, 64, 64, 4, 2, 2);
     }
-    if (tile_all == 128) UNIVL_GROUP_CASE(float, 128, 128, 2, 2, 2, 2);
-    UNIVL_GROUP_CASE(float, 64, 64, 2, 4, 2, 2);
+    if (tile_all == 128) UNIVL_GROUP_CASE(float, 128, 128, 2, 2, 2);
+    UNIVL_GROUP_CASE(float, 64, 64, 4, 2, 2);
 #undef UNIVL_GROUP_CASE
 }
