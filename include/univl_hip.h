@@ -390,6 +390,8 @@ int univl_gemm_rider_prime(hipStream_t stream);
 int univl_bump_counter(uint64_t* ctr, hipStream_t stream);
 /* p16 <- bf16(p) over n elements */
 int univl_cast_bf16(const float* p, void* p16, int64_t n, hipStream_t stream);
+/* p <- fp32(p16) over n elements (the bf16 gradient exchange brings its buckets back into the fp32 gradient buffer) */
+int univl_cast_f32(const void* p16, float* p, int64_t n, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------- hardware probes */
 int univl_probe_layouts(float* out, int32_t n_out, hipStream_t stream);

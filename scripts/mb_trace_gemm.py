@@ -173,6 +173,31 @@ def main():
             run("pair FFN1 (dgrad ks%d + wgrad+dbias) [%s]" % (ks(I), part), pair_ffn1, split=pad8(mt * (H // 64) * ks(I)), rot=24)
             run("pair QKV (dgrad ks%d + wgrad) [%s]" % (ks(3 * H), part), pair_qkv, split=pad8(mt * (H // 64) * ks(3 * H)), rot=24)
         os.environ["MB_PART"] = "all"
+        if M >= 512:
+            # what the default plan does NOT do at this size: split-K of the deep N = 768 products, half-width tiles
+            for k2 in (2, 3):
+                run("fwd FFN2 N768 K3072 FORCED ks%d" % k2, lambda i, st, k2=k2: (touch(f), st(), ops.gemm(f, W2[i % len(W2)], M, H, I, out32=y32, bias=biasH, ksplit=k2)), rot=24)
+            for tile in (64128, 12864, 128):
+                run("fwd FFN1 N3072 K768 gelu tile %d" % tile, lambda i, st, tile=tile: (touch(x), st(), ops.gemm(x, W1[i % len(W1)], M, I, H, out16=fo, bias=biasI, aux=u, gelu="fwd", tile=tile)), rot=24)
+                run("fwd QKV N2304 K768 tile %d" % tile, lambda i, st, tile=tile: (touch(x), st(), ops.gemm(x, Wq[i % len(Wq)], M, 3 * H, H, out16=qkv, bias=bias3, tile=tile)), rot=24)
+                run("dgrad FFN2 N3072 K768 gelu' tile %d" % tile, lambda i, st, tile=tile: (touch(dxd), st(), ops.gemm(dxd, W2[i % len(W2)], M, I, H, trans_b=True, out16=du, aux=u, gelu="bwd", tile=tile)), rot=24)
+
+            def pair_ffn1_ks(i, st, k2):
+                touch(du)
+                st()
+                d = ops.gemm_desc(du, W1[i % len(W1)], M, H, I, trans_b=True, out32=dx32, residual=res, ksplit=k2)
+                w = ops.gemm_desc(du, x, I, H, M, trans_a=True, trans_b=True, out32=gW1, dbias=db1, dbias_atomic=True)
+                assert ops.gemm_pair(d, w)
+
+            def pair_qkv_ks(i, st, k2):
+                touch(dqkv)
+                st()
+                d = ops.gemm_desc(dqkv, Wq[i % len(Wq)], M, H, 3 * H, trans_b=True, out32=dx32, residual=res, ksplit=k2)
+                w = ops.gemm_desc(dqkv, x, 3 * H, H, M, trans_a=True, trans_b=True, out32=gWq)
+                assert ops.gemm_pair(d, w)
+            for k2 in (2, 3):
+                run("pair FFN1 dgrad FORCED ks%d [all]" % k2, lambda i, st, k2=k2: pair_ffn1_ks(i, st, k2), rot=24)
+                run("pair QKV dgrad FORCED ks%d [all]" % k2, lambda i, st, k2=k2: pair_qkv_ks(i, st, k2), rot=24)
         # reference points: an empty boundary (two stamps back to back) and a trivial elementwise kernel between stamps
         run_empty()
 

@@ -267,6 +267,100 @@ def test_reducer_on_rccl_world_size_one():
     assert out["graph"]["mode"] == "whole" and out["graph_pg"]["mode"] == "segmented"
 
 
+# ------------------------------------------------------------------------------------------------ riding update + captured exchange
+def _worker_ride(port, q):
+    """bf16 compute, deterministic mode, RCCL world size 1 (forced-active reducer): the captured data-parallel iteration WITH the
+    riding BertAdam update -- two graphs, forward with riders | backward with collectives + clip (graphed.GraphedTrainStep) -- against
+    the single-process captured step; the same with async_loss; and UNIVL_GRAD_EXCHANGE=bf16 (captured: cast, all-reduce of half
+    the bytes, cast back) with its own gate on the exchanged gradients."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ["UNIVL_DETERMINISTIC"] = "1"
+        os.environ["UNIVL_DP_CAPTURE"] = "1"
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        _setup_path()
+        import univl_oracle as O
+        from make_golden import case_config
+        from test_model_gpu import build
+        from univl_amd import BertAdam
+        from univl_amd.graphed import GraphedTrainStep
+        cfg, _, dseed = case_config(CASE)
+        full = O.synthetic_batch(cfg, ROWS, seed=dseed)
+        b = {k: v.to("cuda") for k, v in full.items()}
+        args = (b["input_ids"], b["token_type_ids"], b["attention_mask"], b["video"], b["video_mask"])
+        kw = dict(pairs_masked_text=b["pairs_masked_text"], pairs_token_labels=b["pairs_token_labels"],
+                  masked_video=b["masked_video"], video_labels_index=b["video_labels_index"])
+
+        def train(dp, async_loss=False, exchange="fp32"):
+            os.environ["UNIVL_GRAD_EXCHANGE"] = exchange
+            model, _ = build(cfg, torch.bfloat16)
+            model.train()
+            if dp:
+                model.enable_data_parallel(force=True)
+                assert model._reducer is not None and model._reducer.capturable and model._reducer.bf16 == (exchange == "bf16")
+            opt = BertAdam(model.parameters(), lr=1e-4, warmup=-1, t_total=-1, weight_decay=0.01, max_grad_norm=1.0)
+            gs = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=1, pipeline_optimizer=True, async_loss=async_loss)
+            losses = [float(gs(*args, **kw)) for _ in range(STEPS + 2)]
+            gs.flush()
+            names = _probe_names(model)
+            final = {n: model.flat.w32(n).detach().float().cpu().numpy().copy() for n in names}
+            return dict(losses=losses, final=final, mode=gs.mode, ride=gs.ride, two=gs._g_rest is not None,
+                        calls=0 if model._reducer is None else model._reducer.calls)
+
+        def grads(dp, exchange):
+            os.environ["UNIVL_GRAD_EXCHANGE"] = exchange
+            model, _ = build(cfg, torch.bfloat16)
+            model.train()
+            if dp:
+                model.enable_data_parallel(force=True)
+            model(*args, **kw).backward()
+            torch.cuda.synchronize()
+            return model.flat.g32.detach().double().cpu()
+
+        out = {"ref": train(False)}
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        out["dp"] = train(True)
+        out["dp_async"] = train(True, async_loss=True)
+        out["dp_bf16"] = train(True, exchange="bf16")
+        g32, g16 = grads(True, "fp32"), grads(True, "bf16")
+        out["bf16_global"] = float((g16 - g32).norm() / g32.norm())
+        nz = g32.abs() > 1e-12
+        out["bf16_elem"] = float(((g16 - g32).abs()[nz] / g32.abs()[nz]).max())
+        os.environ["UNIVL_GRAD_EXCHANGE"] = "fp32"
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        q.put(("ok", out))
+    except Exception as ex:      # noqa: BLE001
+        import traceback
+        q.put(("error", "%s: %s\n%s" % (type(ex).__name__, ex, traceback.format_exc())))
+
+
+def test_riding_update_with_captured_exchange_and_bf16_exchange_gate():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_ride, args=(_free_port(), q))
+    p.start()
+    status, out = q.get(timeout=900)
+    p.join(timeout=120)
+    assert status == "ok", out
+    ref = out["ref"]
+    assert ref["ride"] and ref["mode"] == "whole" and not ref["two"]
+    for kind in ("dp", "dp_async", "dp_bf16"):
+        r = out[kind]
+        # the riding update stays on under a captured exchange, as two graphs (forward with riders | backward with collectives)
+        assert r["ride"] and r["mode"] == "whole" and r["two"] and r["calls"] > 0, (kind, r["ride"], r["mode"], r["two"])
+        tol_l, tol_p = (2e-3, 2e-4) if kind == "dp_bf16" else (2e-4, 5e-5)
+        assert max(abs(a - b) for a, b in zip(r["losses"], ref["losses"])) < tol_l * max(1.0, abs(ref["losses"][0])), (kind, r["losses"], ref["losses"])
+        for n in ref["final"]:
+            assert float(abs(r["final"][n] - ref["final"][n]).max()) < tol_p, (kind, n)
+    # UNIVL_GRAD_EXCHANGE=bf16: every exchanged element is the fp32 gradient rounded to 8 mantissa bits (world size 1: the mean of
+    # one rank): <= 2^-9 per element, ~2^-9 / sqrt(3) in the global norm
+    assert out["bf16_elem"] <= 2.0 ** -8 and out["bf16_global"] <= 3e-3, (out["bf16_elem"], out["bf16_global"])
+
+
 def _worker_cabi(q):
     """univl_allreduce_bucket (include/univl_hip.h) with a communicator the HOST created through RCCL's C API."""
     try:

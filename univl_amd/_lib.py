@@ -132,6 +132,7 @@ def lib():
     L.univl_clip_coef.argtypes = [vp, vp, i32, f32, vp, vp]
     L.univl_scale_grads.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
     L.univl_cast_bf16.argtypes = [vp, vp, i64, vp]
+    L.univl_cast_f32.argtypes = [vp, vp, i64, vp]
     L.univl_bert_adam_range.argtypes = [vp, i32, i32, i32, i32, vp]
     L.univl_bump_counter.argtypes = [vp, vp]
     L.univl_probe_layouts.argtypes = [vp, i32, vp]
@@ -164,7 +165,7 @@ EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_dev
             "univl_rows_sumsq", "univl_zero_many", "univl_copy_many", "univl_pool_fwd", "univl_pool_bwd", "univl_pool_pair_fwd", "univl_pool_pair_bwd",
             "univl_maxmargin_loss", "univl_crossen_loss", "univl_milnce_loss", "univl_rank_counts", "univl_gather_rows", "univl_log_softmax_rows", "univl_scale_by_device_scalar", "univl_pair_concat_fwd", "univl_pair_concat_bwd", "univl_postype_fwd", "univl_postype_bwd", "univl_tanh_fwd",
             "univl_tanh_bwd", "univl_gelu_bwd", "univl_colsum", "univl_scale_ct_by_device_scalar", "univl_simdense_fwd", "univl_simdense_bwd", "univl_ce_loss", "univl_mfm_nce_loss", "univl_grad_sumsq", "univl_sumsq_finish",
-            "univl_clip_coef", "univl_scale_grads", "univl_bert_adam", "univl_bert_adam_range", "univl_cast_bf16", "univl_bump_counter", "univl_probe_layouts", "univl_stamp"]
+            "univl_clip_coef", "univl_scale_grads", "univl_bert_adam", "univl_bert_adam_range", "univl_cast_bf16", "univl_cast_f32", "univl_bump_counter", "univl_probe_layouts", "univl_stamp"]
 
 
 def check(rc, what=""):

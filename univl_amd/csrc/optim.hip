@@ -234,6 +234,15 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* p, __bf16* o, in
     if (blockIdx.x == 0) for (int64_t i = nv * 4 + threadIdx.x; i < n; i += 256) o[i] = (__bf16)p[i];
 }
 
+__global__ __launch_bounds__(256) void uncast_kernel(const __bf16* p, float* o, int64_t n) {
+    const int64_t nv = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        const bf16x4_t w = reinterpret_cast<const bf16x4_t*>(p)[i];
+        reinterpret_cast<float4*>(o)[i] = make_float4((float)w[0], (float)w[1], (float)w[2], (float)w[3]);
+    }
+    if (blockIdx.x == 0) for (int64_t i = nv * 4 + threadIdx.x; i < n; i += 256) o[i] = (float)p[i];
+}
+
 }  // namespace
 
 bool univl_adam_nt() {
@@ -355,6 +364,17 @@ extern "C" int univl_cast_bf16(const float* p, void* p16, int64_t n, hipStream_t
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(cast_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, reinterpret_cast<__bf16*>(p16), n);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+extern "C" int univl_cast_f32(const void* p16, float* p, int64_t n, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    UNIVL_CHECK_ARG(p && p16 && n > 0 && aligned16(p) && ((((uintptr_t)p16) & 7) == 0), UNIVL_EINVAL, "univl_cast_f32: bad argument");
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(uncast_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const __bf16*>(p16), p, n);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }

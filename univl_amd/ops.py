@@ -317,6 +317,10 @@ def cast_bf16(src, dst):
     _lib.check(_lib.lib().univl_cast_bf16(_p(src), _p(dst), src.numel(), _stream()), "cast_bf16")
 
 
+def cast_f32(src16, dst):
+    _lib.check(_lib.lib().univl_cast_f32(_p(src16), _p(dst), src16.numel(), _stream()), "cast_f32")
+
+
 def stamp(out):
     """out: one int64 / uint64 device word <- the device wall clock when this node runs (measurement, include/univl_hip.h)."""
     _lib.check(_lib.lib().univl_stamp(_p(out), _stream()), "stamp")

@@ -75,7 +75,7 @@ class BucketReducer:
         acts on it, so that either every rank takes the captured path or every rank raises -- a rank that fell back alone would leave
         the others hanging in the next collective of the path it left."""
         from . import rccl as _r
-        if not self._avg or self.loopback or self.bf16 or self.partition is not None:
+        if not self._avg or self.loopback or self.partition is not None:
             return False
         err = None
         try:
@@ -177,7 +177,20 @@ class BucketReducer:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(self._cstream)
-            if not self.dryrun:
+            if self.bf16:
+                # UNIVL_GRAD_EXCHANGE=bf16 on the communication stream: round the bucket to bf16, all-reduce HALF the bytes, widen the
+                # mean back into the fp32 gradient buffer -- three enqueues, all capturable
+                from . import ops
+                if self._g16 is None:
+                    self._g16 = torch.empty_like(self.g, dtype=torch.bfloat16)
+                t16 = self._g16[start:end]
+                with torch.cuda.stream(self._cstream):
+                    ops.cast_bf16(t, t16)
+                if not self.dryrun:
+                    self.rccl.all_reduce(t16, True, self._cstream)
+                with torch.cuda.stream(self._cstream):
+                    ops.cast_f32(t16, t)
+            elif not self.dryrun:
                 self.rccl.all_reduce(t, True, self._cstream)
             if timed:
                 e1.record(self._cstream)
@@ -225,11 +238,16 @@ class BucketReducer:
             w = dist.all_gather([out[r] for r in range(self.world)], t, group=self.pg, async_op=True)
         self.pending.append((w, None, None))
 
-    def reduce_ranges(self, ranges, after=None):
+    def reduce_ranges(self, ranges, after=None, then=None):
+        """then: callable enqueued on the communication stream BEHIND the collectives of these ranges (captured exchange only) -- the
+        per-tensor gradient norms of a bucket are taken there, while the backward is still running (steps._ddp_hook)."""
         if self.partition is not None:
             return self.reduce_scatter_ranges(ranges)
         for s0, e0 in ranges:
             self.reduce_slice(s0, e0, after)
+        if then is not None and self.capturable and self.active and self._inflight:
+            with torch.cuda.stream(self._cstream):
+                then()
 
     # ------------------------------------------------------------------------------- sharded optimizer (ZeRO-1 style)
     # With `partition` set (shard_partition below) every exchanged range is REDUCE-SCATTERED instead of all-reduced: rank r
