@@ -238,16 +238,11 @@ class BucketReducer:
             w = dist.all_gather([out[r] for r in range(self.world)], t, group=self.pg, async_op=True)
         self.pending.append((w, None, None))
 
-    def reduce_ranges(self, ranges, after=None, then=None):
-        """then: callable enqueued on the communication stream BEHIND the collectives of these ranges (captured exchange only) -- the
-        per-tensor gradient norms of a bucket are taken there, while the backward is still running (steps._ddp_hook)."""
+    def reduce_ranges(self, ranges, after=None):
         if self.partition is not None:
             return self.reduce_scatter_ranges(ranges)
         for s0, e0 in ranges:
             self.reduce_slice(s0, e0, after)
-        if then is not None and self.capturable and self.active and self._inflight:
-            with torch.cuda.stream(self._cstream):
-                then()
 
     # ------------------------------------------------------------------------------- sharded optimizer (ZeRO-1 style)
     # With `partition` set (shard_partition below) every exchanged range is REDUCE-SCATTERED instead of all-reduced: rank r

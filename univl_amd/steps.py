@@ -683,46 +683,20 @@ def _ddp_hook(cx, fl, model, kind):
     buckets = layer_buckets(fl, model.used_parameter_names(kind))
     sched = BucketSchedule(float(os.environ.get("UNIVL_BUCKET_MB", "80")) * 2 ** 20)
 
-    # Per-tensor gradient norms of an exchanged bucket, taken ON THE COMMUNICATION STREAM right behind its all-reduce (captured
-    # exchange only): after an all-reduce the local sums of the weight-gradient epilogues are not the norms of the averaged
-    # gradients, so the data-parallel step used to stream all 615 MB of gradients once more after the join, on the critical path
-    # (~0.1 ms at 4 pairs).  Bucket by bucket behind the collectives that pass overlaps the backward; the clip then only measures
-    # what no exchange point covered.  UNIVL_DP_BUCKET_NORMS=0: the streaming pass after the join.
-    bucket_norms = red.capturable and os.environ.get("UNIVL_DP_BUCKET_NORMS", "1") != "0"
-    covered = []
-    extents = sorted((fl.index[n][0], fl.index[n][0] + fl.index[n][1], n) for n in model.used_parameter_names(kind))
-
-    def norms_for(ranges):
-        if not bucket_norms:
-            return None
-        names = [n for lo, hi, n in extents if any(s0 <= lo and hi <= e0 for s0, e0 in ranges)]
-        names = [n for n in names if n not in covered]
-        if not names:
-            return None
-        from .optimization import _Tables
-        tb = _Tables(fl, {n: (0.0, 0.0, 0.0, 1) for n in names})
-        if tb.nchunk == 0:
-            return None
-        covered.extend(names)
-        import ctypes as C
-
-        def measure():
-            _lib.check(_lib.lib().univl_grad_sumsq(fl.g32.data_ptr(), tb.segs.data_ptr(), tb.nseg, tb.chunk_seg.data_ptr(),
-                                                   tb.chunk_off.data_ptr(), tb.chunk_len.data_ptr(), tb.nchunk, fl.sumsq.data_ptr(),
-                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "grad_sumsq")
-        return measure
-
+    # (Round 4, measured and removed: the per-tensor gradient norms of every exchanged bucket taken on the communication stream right
+    # behind its all-reduce, instead of one streaming pass over the gradients after the join.  The data-parallel schedule on one GPU
+    # went from 2.56 to 3.16 ms per step at 4 pairs and from 3.87 to 4.60 at 16 (profiles/r04c_dp_bucket_norms_bf16_exchange.txt): a
+    # second stream that fills the chip with 2600-workgroup streaming kernels delays every kernel of the latency-bound backward chain
+    # by more than the 0.1 ms pass it hides -- the same lesson as the side-stream optimizer update of round 2.)
     def emit(plan):
         ranges = sched.take()
         if ranges:
             # host-issued between captured segments (torch's process group), or -- with a library-held RCCL communicator
             # (parallel.BucketReducer.enable_capture) -- an ordinary, capturable part of the plan
             if red.capturable:
-                then = norms_for(ranges)
-                plan.add_callable(lambda streams: red.reduce_ranges(ranges, after=streams, then=then), with_streams=True)
+                plan.add_callable(lambda streams: red.reduce_ranges(ranges, after=streams), with_streams=True)
             else:
                 plan.add_callable(lambda: red.reduce_ranges(ranges), eager=True)
-    emit.covered = covered
 
     def hook(plan, prefix, l, stream):
         key = (prefix, l)
@@ -825,8 +799,6 @@ def build_step(model, kind, B, W, F, training):
                      and (cx.red is None or sparse)        # a dense all-reduce of the table fills rows nobody listed
                      and enc.Tt * (world if sparse else 1) <= fl.WORD_ROWS_CAP)
         zeros = [fl.sumsq, fl.partials] if fuse else []
-        if cx.red is not None and cx.red.capturable and os.environ.get("UNIVL_DP_BUCKET_NORMS", "1") != "0":
-            zeros.append(fl.sumsq)            # the exchange points add their buckets' sums of squares into it (_ddp_hook)
         enc.word_rows = None
         if rows_mode:
             lst, meta = fl.word_rows()
@@ -892,7 +864,7 @@ def build_step(model, kind, B, W, F, training):
             st.exchange_points = list(sched[0].cuts)
         gs.finish(bwd)
         cx.stamp(bwd, "b_end")
-        bwd.fused_names = frozenset(gs.covered) | frozenset(sched[1].covered if sched is not None else ())
+        bwd.fused_names = frozenset(gs.covered)
         bwd.rows_mode = rows_mode
         return bwd
 
