@@ -386,6 +386,30 @@ def test_default_atomic_mode_matches_deterministic(name, dtype):
     assert rel < (1e-4 if f32 else 4e-2), (name, rel)
 
 
+def test_large_batch_backward_paths_match_the_default_ones(monkeypatch):
+    """Two backward forms that only switch on at large per-GPU batch -- position-table gradients by a gather over per-token rows
+    (UNIVL_DPOS_GATHER_MIN, default 32 rows per position) and the grouped weight gradients on the 128 tile with their bias gradients
+    taken by column-sum workgroups of the same launch (UNIVL_WGRAD_BIG_MIN, default 5462 tokens) -- forced on at the size of the
+    golden case: every gradient tensor equals the default path's up to fp32 summation order (deterministic mode: the products
+    themselves are bit-identical), and the golden gates hold."""
+    ref = _grads_and_loss("joint_full", torch.bfloat16)
+    monkeypatch.setenv("UNIVL_DPOS_GATHER_MIN", "1")
+    monkeypatch.setenv("UNIVL_WGRAD_BIG_MIN", "1")
+    new = _grads_and_loss("joint_full", torch.bfloat16)
+    cfg, rows, dseed = case_config("joint_full")
+    model, _ = build(cfg, torch.bfloat16)
+    model.train()
+    call(model, O.synthetic_batch(cfg, rows, seed=dseed)).backward()
+    st = next(iter(model._steps.values()))
+    kinds = [op[3] for op in st.backward_plan(True).ops]
+    assert kinds.count("univl_gemm_pair") == 0 and kinds.count("univl_gemm_group") >= cfg.text_num_hidden_layers + cfg.visual_num_hidden_layers
+    assert ref.keys() == new.keys()
+    assert float(ref["__loss__"]) == float(new["__loss__"])
+    for k, v in ref.items():
+        d, n = float((v.double() - new[k].double()).norm()), float(v.double().norm())
+        assert d <= 2e-5 * n + 1e-9, (k, d, n)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_joint_full_gradients_vs_oracle_elementwise(dtype):
     """Full-tensor comparison of every gradient with the oracle (autograd on CPU) for a 2+1 layer model."""

@@ -49,6 +49,8 @@ extern "C" int univl_trace_set(unsigned long long* buf, int cap_workgroups) {
 
 namespace {
 
+extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
 struct GemmArgs {
     const void* A; const void* B;
     long lda, ldb;
@@ -211,8 +213,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     constexpr int D = 2;
     static_assert(BM <= NT, "the bias-gradient pass uses one thread per tile row");
 
-    // ONE dynamic LDS object (a second __shared__ object makes hipcc drain vmcnt(0) before every ds_read)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // ONE dynamic LDS object, declared once at namespace scope (a second __shared__ object makes hipcc drain vmcnt(0) before every ds_read)
     unsigned char* sA = smem_raw;
     unsigned char* sB = sA + D * TileA::BYTES;
 
@@ -487,6 +488,53 @@ __global__ __launch_bounds__(64 * WGM * WGN, (BM != BN && BM * BN == 128 * 64) ?
     gemm_tile<T, TA, TB, BM, BN, NC, WGM, WGN>(p, bx, by, bz, gridDim.z);
 }
 
+struct ColsumArgs {                  // out[c] (+)= sum over rows of x[r, c]: the bias gradient of a weight-gradient product whose A is x
+    const __bf16* x; long ld; int rows, n; float* out; int n_tiles, n_pad;
+};
+
+// Bias-gradient role of the carrier launches (round 4): one workgroup sums 64 columns of the upstream gradient over ALL its rows, in a
+// fixed order (8 column groups x NT / 8 row lanes, four 16-byte loads in flight per lane, the row lanes meet in LDS).  Before, the
+// column-0 workgroups of the weight-gradient product walked their staged A tile element by element (64 ds_read_u16 per thread per K
+// step): in the phase trace of the FFN1 pair at 192 tokens (profiles/r04b_trace_gemm_phases.txt) those 48 workgroups run 9.2 us
+// against 3.8 us for the others and, dispatched behind the dgrad tiles, end 4.6 us after the FFN2 pair that carries no bias gradient.
+template <int NT>
+__device__ __forceinline__ void colsum_tile(const ColsumArgs& c, int tile, unsigned char* smem) {
+    constexpr int RL = NT / 8;
+    const int tid = threadIdx.x, cg = tid & 7, r0 = tid >> 3;
+    const int c0 = tile * 64, col = c0 + cg * 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    auto add = [&](const u32x4_t q) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            acc[2 * d] += __uint_as_float(q[d] << 16);
+            acc[2 * d + 1] += __uint_as_float(q[d] & 0xFFFF0000u);
+        }
+    };
+    if (col < c.n) {                                   // n % 8 == 0 (host)
+        const __bf16* p = c.x + col;
+        int r = r0;
+        for (; r + 3 * RL < c.rows; r += 4 * RL) {
+            const u32x4_t q0 = *reinterpret_cast<const u32x4_t*>(p + (long)r * c.ld);
+            const u32x4_t q1 = *reinterpret_cast<const u32x4_t*>(p + (long)(r + RL) * c.ld);
+            const u32x4_t q2 = *reinterpret_cast<const u32x4_t*>(p + (long)(r + 2 * RL) * c.ld);
+            const u32x4_t q3 = *reinterpret_cast<const u32x4_t*>(p + (long)(r + 3 * RL) * c.ld);
+            add(q0); add(q1); add(q2); add(q3);
+        }
+        for (; r < c.rows; r += RL) add(*reinterpret_cast<const u32x4_t*>(p + (long)r * c.ld));
+    }
+    float* red = reinterpret_cast<float*>(smem);       // [RL][64]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[r0 * 64 + cg * 8 + j] = acc[j];
+    __syncthreads();
+    if (tid < 64 && c0 + tid < c.n) {
+        float sum = 0.f;
+        for (int r = 0; r < RL; ++r) sum += red[r * 64 + tid];
+        c.out[c0 + tid] += sum;                        // the only writer of these 64 entries in this launch; the buffer is zeroed per backward
+    }
+}
+
 // Up to UNIVL_GEMM_GROUP_MAX independent problems of the same operand layout in ONE launch (the four weight-gradient
 // GEMMs of an encoder layer: each alone covers a fraction of the 256 CUs for one or two K steps, and four dependent
 // launches cost four launch latencies).  Workgroups are numbered problem by problem; x fastest, then y, then z.
@@ -494,6 +542,10 @@ struct GroupArgs {
     GemmArgs p[UNIVL_GEMM_GROUP_MAX];
     int first[UNIVL_GEMM_GROUP_MAX + 1];      // first workgroup of problem i; first[n..] = total
     int nx[UNIVL_GEMM_GROUP_MAX], nxy[UNIVL_GEMM_GROUP_MAX], nz[UNIVL_GEMM_GROUP_MAX];
+    // bias-gradient roles in FRONT of the tiles (colsum_tile: they stream their 64 columns over every token and are the longest
+    // workgroups of the launch at thousands of tokens): member i's column tiles are workgroups [cs_first[i], cs_first[i + 1])
+    ColsumArgs cs[UNIVL_GEMM_GROUP_MAX];
+    int cs_first[UNIVL_GEMM_GROUP_MAX + 1];   // cs_first[n..] = number of role workgroups, a multiple of 8 (XCD relation of the tiles)
 };
 
 // A grid smaller than the number of tiles walks them with stride gridDim.x: the "background" form of the layer's
@@ -502,8 +554,23 @@ struct GroupArgs {
 template <typename T, bool TA, bool TB, int BM, int BN, int NC, int WGM, int WGN>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_group_kernel(GroupArgs g) {
   const int total = g.first[UNIVL_GEMM_GROUP_MAX];
-  const bool remap = (g.p[0].flags & UNIVL_GEMM_XCD_MAP) && gridDim.x >= total && total >= 16;   // one workgroup per tile
-  for (int w0 = blockIdx.x; w0 < total; w0 += gridDim.x) {
+  const int ncs = g.cs_first[UNIVL_GEMM_GROUP_MAX];
+  const bool remap = (g.p[0].flags & UNIVL_GEMM_XCD_MAP) && (int)gridDim.x >= total + ncs && total >= 16;   // one workgroup per tile
+  for (int v0 = blockIdx.x; v0 < total + ncs; v0 += gridDim.x) {
+    if (sizeof(T) == 2 && v0 < ncs) {                   // roles exist for bf16 groups only (host: cs_roles)
+        int m = 0;
+#pragma unroll
+        for (int i = 1; i < UNIVL_GEMM_GROUP_MAX; ++i) m += (v0 >= g.cs_first[i]) ? 1 : 0;
+        ColsumArgs c = g.cs[0];
+        int cf = g.cs_first[0];
+#pragma unroll
+        for (int i = 1; i < UNIVL_GEMM_GROUP_MAX; ++i)
+            if (m == i) { c = g.cs[i]; cf = g.cs_first[i]; }
+        if constexpr (sizeof(T) == 2) { if (v0 - cf < c.n_tiles) colsum_tile<64 * WGM * WGN>(c, v0 - cf, smem_raw); }
+        if ((int)gridDim.x < total + ncs) __syncthreads();
+        continue;
+    }
+    const int w0 = v0 - ncs;
     const int w = remap ? xcd_run(w0, total) : w0;
     int idx = 0;
 #pragma unroll
@@ -525,7 +592,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_group_kernel(GroupArgs
         bx = rem - by * nx;
     }
     gemm_tile<T, TA, TB, BM, BN, NC, WGM, WGN>(p, bx, by, bz, nz);
-    if (gridDim.x < total) __syncthreads();           // the next tile's DMA reuses the LDS stages
+    if ((int)gridDim.x < total + ncs) __syncthreads();           // the next tile's DMA reuses the LDS stages
   }
 }
 
@@ -538,7 +605,7 @@ int launch_group(const GroupArgs& g, int max_blocks, hipStream_t stream) {
     const size_t smem = NC == 6 ? 2 * TileA::BYTES + TileB::BYTES : 2 * (TileA::BYTES + TileB::BYTES);
     static bool attr_done[UNIVL_MAX_DEVICES] = {};   // per instantiation, per device
     if (smem > 48 * 1024) univl_allow_lds(gemm_group_kernel<T, TA, TB, BM, BN, NC, WGM, WGN>, smem, attr_done);
-    const int total = g.first[UNIVL_GEMM_GROUP_MAX];
+    const int total = g.first[UNIVL_GEMM_GROUP_MAX] + g.cs_first[UNIVL_GEMM_GROUP_MAX];
     const int grid = (max_blocks > 0 && max_blocks < total) ? max_blocks : total;
     hipLaunchKernelGGL((gemm_group_kernel<T, TA, TB, BM, BN, NC, WGM, WGN>), dim3(grid), dim3(NT), smem, stream, g);
     UNIVL_LAUNCH_CHECK();
@@ -557,6 +624,7 @@ struct PairArgs {
     GemmArgs d, w;
     int nd, nd_pad, nw;
     int dnx, dny, dnz, wnx, wny, wnz;
+    ColsumArgs cs;
 };
 
 __host__ __device__ __forceinline__ void pair_tile(int t, int total, int nx, int ny, int nz, int flags, int gm, int& bx, int& by, int& bz) {
@@ -571,30 +639,47 @@ __host__ __device__ __forceinline__ void pair_tile(int t, int total, int nx, int
     }
 }
 
-template <int NCW>
-__global__ __launch_bounds__(512, 2) void gemm_pair_kernel(PairArgs a) {
+// Two forms of the launch, both bodies on 8 waves:
+//   square (RECT = false): 64 x 64 tiles for both products, 128-deep K steps for the dgrad body, NCW x 32-deep ones (128, or the single
+//     192-deep step at 192 tokens) for the weight-gradient body; 72 KB of LDS, two workgroups per compute unit.  A few hundred tokens: the
+//     dgrad product is a latency chain and wants as many workgroups as there are compute units.
+//   rectangular (RECT = true, from 384 tokens on): 64 x 128 tiles for the dgrad product (tokens x in-features), 128 x 64 tiles for the
+//     weight gradient (out-features x in-features), 64-deep K steps, 48 KB of LDS and <= 80 VGPRs: THREE workgroups per compute unit.
+//     At 768 tokens both products are bound by what a compute unit can pull through LDS-DMA (~45 GB/s: the phase trace,
+//     profiles/r04c_trace_gemm_768_variants.txt), i.e. by the bytes the tiles stage: an FFN pair stages 226 MB as 1152 square tiles
+//     (2.25 rounds of 512 slots, 33 us) but 170 MB as 576 rectangular ones -- one round of 768 slots.
+template <int NCW, bool RECT>
+__global__ __launch_bounds__(512, RECT ? 6 : 2) void gemm_pair_kernel(PairArgs a) {
     const int w0 = blockIdx.x;
     int bx, by, bz;
     if (w0 < a.nd_pad) {
         if (w0 >= a.nd) return;                                  // padding workgroup (whole block: no barrier is skipped)
         pair_tile(w0, a.nd, a.dnx, a.dny, a.dnz, a.d.flags, a.d.gm, bx, by, bz);
-        gemm_tile<__bf16, false, true, 64, 64, 4, 2, 4>(a.d, bx, by, bz, a.dnz);
+        if constexpr (RECT) gemm_tile<__bf16, false, true, 64, 128, 2, 2, 4>(a.d, bx, by, bz, a.dnz);
+        else gemm_tile<__bf16, false, true, 64, 64, 4, 2, 4>(a.d, bx, by, bz, a.dnz);
+    } else if (w0 < a.nd_pad + a.cs.n_pad) {
+        const int t = w0 - a.nd_pad;
+        if (t >= a.cs.n_tiles) return;
+        colsum_tile<512>(a.cs, t, smem_raw);
     } else {
-        pair_tile(w0 - a.nd_pad, a.nw, a.wnx, a.wny, a.wnz, a.w.flags, a.w.gm, bx, by, bz);
-        gemm_tile<__bf16, true, true, 64, 64, NCW, 2, 4>(a.w, bx, by, bz, a.wnz);
+        pair_tile(w0 - a.nd_pad - a.cs.n_pad, a.nw, a.wnx, a.wny, a.wnz, a.w.flags, a.w.gm, bx, by, bz);
+        if constexpr (RECT) gemm_tile<__bf16, true, true, 128, 64, 2, 4, 2>(a.w, bx, by, bz, a.wnz);
+        else gemm_tile<__bf16, true, true, 64, 64, NCW, 2, 4>(a.w, bx, by, bz, a.wnz);
     }
 }
 
-template <int NCW>
+template <int NCW, bool RECT>
 int launch_pair(const PairArgs& a, hipStream_t stream) {
     using TA_d = Tile<__bf16, false, 64, 4 * 32, 512>;
     using TA_w = Tile<__bf16, true, 64, NCW * 32, 512>;
     const size_t smem_d = 2 * (size_t)(TA_d::BYTES + TA_d::BYTES);                 // A and B tiles are both 64 rows x BK
     const size_t smem_w = NCW == 6 ? 3 * (size_t)TA_w::BYTES : 4 * (size_t)TA_w::BYTES;   // one-step form: stage 0 of B only
-    const size_t smem = smem_d > smem_w ? smem_d : smem_w;
+    const size_t smem_sq = smem_d > smem_w ? smem_d : smem_w;
+    const size_t smem_rect = 2 * (size_t)(64 + 128) * 64 * sizeof(__bf16);         // two stages of a 64-row and a 128-row tile, BK = 64
+    const size_t smem = RECT ? smem_rect : smem_sq;
     static bool attr_done[UNIVL_MAX_DEVICES] = {};
-    univl_allow_lds(gemm_pair_kernel<NCW>, smem, attr_done);
-    hipLaunchKernelGGL((gemm_pair_kernel<NCW>), dim3(a.nd_pad + a.nw), dim3(512), smem, stream, a);
+    univl_allow_lds(gemm_pair_kernel<NCW, RECT>, smem, attr_done);
+    hipLaunchKernelGGL((gemm_pair_kernel<NCW, RECT>), dim3(a.nd_pad + a.cs.n_pad + a.nw), dim3(512), smem, stream, a);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
@@ -852,17 +937,43 @@ extern "C" int univl_gemm_pair(const UnivlGemm* dgrad, const UnivlGemm* wgrad, i
     if (rc != UNIVL_OK) return rc;
     rc = prepare(wgrad, a.w, ksw, cw);
     if (rc != UNIVL_OK) return rc;
-    // both bodies are the 64 x 64 bf16 tile; the dgrad body stages 128-deep K steps, the weight-gradient body 128- or 192-deep ones
+    // both products must be ones the single launch would run on the 64 tile (sizes below the big-tile regime)
     UNIVL_CHECK_ARG(dgrad->dtype == UNIVL_BF16 && wgrad->dtype == UNIVL_BF16 && !dgrad->trans_a && dgrad->trans_b && wgrad->trans_a &&
                         wgrad->trans_b && cd.tile == 64 && cw.tile == 64 && cd.nc == 4 && (cw.nc == 4 || cw.nc == 6) && !dgrad->sumsq,
                     UNIVL_EUNSUPPORTED, "univl_gemm_pair: needs a bf16 (K-major, T-major) product and a bf16 (T-major, T-major) product on the 64 tile");
-    a.dnx = (dgrad->N + 63) / 64; a.dny = (dgrad->M + 63) / 64; a.dnz = ksd;
-    a.wnx = (wgrad->N + 63) / 64; a.wny = (wgrad->M + 63) / 64; a.wnz = ksw;
+    // rectangular form from 384 tokens on (gemm_pair_kernel): the split of either contraction is re-derived for 64-deep K steps
+    const bool rect = dgrad->M >= 384 && dgrad->tile == 0 && wgrad->tile == 0;
+    if (rect) {
+        rc = prepare(dgrad, a.d, ksd, cd, 64, 2);
+        if (rc != UNIVL_OK) return rc;
+        rc = prepare(wgrad, a.w, ksw, cw, 64, 2);
+        if (rc != UNIVL_OK) return rc;
+        UNIVL_CHECK_ARG(cd.nc == 2 && cw.nc == 2, UNIVL_EUNSUPPORTED, "univl_gemm_pair: rectangular form needs 64-deep K steps");
+    }
+    const int dbn = rect ? 128 : 64, wbm = rect ? 128 : 64;
+    a.dnx = (dgrad->N + dbn - 1) / dbn; a.dny = (dgrad->M + 63) / 64; a.dnz = ksd;
+    a.wnx = (wgrad->N + 63) / 64; a.wny = (wgrad->M + wbm - 1) / wbm; a.wnz = ksw;
     a.nd = a.dnx * a.dny * a.dnz;
     a.nd_pad = (a.nd + 7) / 8 * 8;
     a.nw = a.wnx * a.wny * a.wnz;
+    // the weight gradient's bias gradient (column sums of its T-major A over the contraction) as workgroups of their own between the
+    // two products instead of an LDS walk inside the product's column-0 workgroups (colsum_tile); up to 2048 tokens -- beyond, the
+    // plans take their bias gradients elsewhere (engine.EncoderStack: big-tile weight gradients) and a 64-column workgroup would
+    // stream megabytes alone
+    a.cs = ColsumArgs{nullptr, 0, 0, 0, nullptr, 0, 0};
+    if (wgrad->dbias && wgrad->K <= 2048 && wgrad->M % 8 == 0) {
+        a.cs.x = reinterpret_cast<const __bf16*>(wgrad->A);
+        a.cs.ld = wgrad->lda;
+        a.cs.rows = wgrad->K;
+        a.cs.n = wgrad->M;
+        a.cs.out = wgrad->dbias;
+        a.cs.n_tiles = (wgrad->M + 63) / 64;
+        a.cs.n_pad = (a.cs.n_tiles + 7) / 8 * 8;
+        a.w.dbias = nullptr;
+    }
     if (dry_run) return UNIVL_OK;
-    return cw.nc == 6 ? launch_pair<6>(a, stream) : launch_pair<4>(a, stream);
+    if (rect) return launch_pair<2, true>(a, stream);
+    return cw.nc == 6 ? launch_pair<6, false>(a, stream) : launch_pair<4, false>(a, stream);
 }
 
 static const size_t RIDER_SMEM = 4 * (size_t)Tile<__bf16, false, 64, 128, 512>::BYTES;          // two stages of A and B
@@ -949,8 +1060,22 @@ extern "C" int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_block
             if (plain) waves_all = 4;
         }
     }
-    int total = 0, nc_all = 0;
+    int total = 0, nc_all = 0, cs_total = 0;
     const int bm = tile_all, bn = tile_all;
+    // On the 128 tile (weight gradients over thousands of tokens) a member's bias gradient is taken by column-sum workgroups in front
+    // of the tiles (colsum_tile) instead of the product's own column-0 workgroups, which were the stragglers of a one-round launch
+    // (322 vs 138 us per layer at 6144 tokens, profiles/r03w / r03y2); round 3 used a separate column-sum launch on the chain.
+    const bool cs_roles = tile_all == 128 && d[0].dtype == UNIVL_BF16 && d[0].trans_a;
+    for (int i = 0; i < UNIVL_GEMM_GROUP_MAX; ++i) {
+        g.cs_first[i] = cs_total;
+        g.cs[i] = ColsumArgs{nullptr, 0, 0, 0, nullptr, 0, 0};
+        if (i < n && cs_roles && d[i].dbias && d[i].M % 8 == 0) {
+            g.cs[i] = ColsumArgs{reinterpret_cast<const __bf16*>(d[i].A), d[i].lda, d[i].K, d[i].M, d[i].dbias, (d[i].M + 63) / 64, 0};
+            cs_total += g.cs[i].n_tiles;
+        }
+    }
+    cs_total = (cs_total + 7) / 8 * 8;
+    g.cs_first[UNIVL_GEMM_GROUP_MAX] = cs_total;
     for (int i = 0; i < UNIVL_GEMM_GROUP_MAX; ++i) {
         g.first[i] = total;
         if (i >= n) { g.p[i] = g.p[0]; g.nx[i] = g.nxy[i] = g.nz[i] = 1; continue; }
@@ -958,6 +1083,7 @@ extern "C" int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_block
         Choice ci;
         const int rc = prepare(&d[i], g.p[i], ksplit, ci, tile_all, forced_nc);
         if (rc != UNIVL_OK) return rc;
+        if (g.cs[i].x) g.p[i].dbias = nullptr;
         UNIVL_CHECK_ARG(ci.tile == tile_all, UNIVL_EINVAL, "univl_gemm_group: member %d cannot run the group's %d tile (sumsq_rows %d)", i, tile_all, d[i].sumsq_rows);
         nc_all = (i == 0) ? ci.nc : (nc_all == ci.nc ? ci.nc : -1);
         g.nx[i] = (d[i].N + bn - 1) / bn;

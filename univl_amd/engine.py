@@ -656,13 +656,26 @@ class EncoderStack:
         # weight gradients of layer l run while layer l-1's chain already produces its own.
         self.scr = [dict(dxd=e(T, H, dtype=ct), dxd2=e(T, H, dtype=ct), du=e(T, I, dtype=ct), dqkv=e(T, 3 * H, dtype=ct))
                     for _ in range(2 if self.sw is not None else 1 + self.n_off)]
-        # split-K for the N=768 products when the grid would not fill the chip: ~3 K-steps of 128 per workgroup
+        # split-K of the products with H-wide outputs (N = 768: attention output, FFN2, and the dgrads of QKV / FFN1):
+        #   * below 128 output tiles (a few hundred tokens) every one of them is split into ~384-deep slices -- the grid would not fill
+        #     the chip otherwise (UNIVL_SPLITK_TILES / _LEN / _MAXWG, measured in rounds 1-3);
+        #   * round 4, 128 .. 511 tiles (16 .. 56 pairs x 48 tokens), bf16: only the DEEP contractions (K = 2304, 3072) into three
+        #     slices.  The phase trace at 768 tokens (profiles/r04c_trace_gemm_768_variants.txt): the unsplit products run 144
+        #     workgroups through 18 - 24 dependent K steps (FFN2 forward 22.4 us -> 17.6 with three slices; the dgrad halves of the
+        #     FFN1 / QKV pair launches 23 / 17 us of K loop alone); K = 768 stays whole.  Round 3 had found NO gain from splitting at
+        #     this size (3.79 / 3.86 vs 3.69 / 3.71 ms per step) -- with the 64 x 64 pair launches of that round the extra dgrad
+        #     workgroups pushed the weight-gradient tiles into a third round; the rectangular pair form (gemm.hip) fits them in one.
         self.tiles = ((T + 63) // 64) * (H // 64)
         # UNIVL_SPLITK_TILES: split the contraction of the N = 768 products while the 64 x 64 output grid has fewer tiles than this
         self.splitk = splitk and self.tiles < int(os.environ.get("UNIVL_SPLITK_TILES", "128"))
-        self.ks_h = self.ksplit_for(H) if self.splitk else 1      # >1 <=> the zero-once arenas are needed
+        self.splitk_mid = (splitk and not self.splitk and self.bf and self.tiles < 512
+                           and os.environ.get("UNIVL_SPLITK_MID", "1") != "0")
+        self.ks_h = self.ksplit_for(H) if self.splitk else 1
+        self.any_split = self.splitk or self.splitk_mid      # <=> the zero-once arenas are needed
 
     def ksplit_for(self, K):
+        if self.splitk_mid:
+            return 3 if K >= 2304 else 1
         if not self.splitk:
             return 1
         per = int(os.environ.get("UNIVL_SPLITK_LEN", "384"))
@@ -702,7 +715,7 @@ class EncoderStack:
         p = self.p if training else 0.0
         if self.probe_skip:
             return
-        if self.ks_h > 1 and zero_arena:
+        if self.any_split and zero_arena:
             plan.add_callable(self.yarena.zero_, stream=sm)
         for l, ws in enumerate(self.layers):
             nm = self._names(l)
@@ -760,7 +773,7 @@ class EncoderStack:
         self.bwd_out = gin
         if self.probe_skip:
             return
-        if self.ks_h > 1 and zero_arena:
+        if self.any_split and zero_arena:
             plan.add_callable(self.garena.zero_, stream=sm)
         sw = self.sw
         # Weight gradients over thousands of tokens (UNIVL_WGRAD_BIG_MIN, bf16): the layer's grouped launch on the 128 x 128 tile
@@ -808,7 +821,10 @@ class EncoderStack:
             # du / dqkv, taken by the weight-gradient GEMM from the operand tiles it stages anyway.  UNIVL_DBIAS_COLSUM_MIN = n:
             # from n tokens on a separate column-sum kernel instead (measured at 6144 tokens, round 3: 13.88 / 13.93 vs 13.92 ms
             # per step -- the per-thread LDS walk of the column-0 workgroups is not what bounds that product; off).
-            sep_dbias = big_wgrad or T >= int(os.environ.get("UNIVL_DBIAS_COLSUM_MIN", "1000000000"))
+            # Round 4: on the big-tile plan the grouped launch takes them itself, as column-sum workgroups in front of its tiles
+            # (gemm.hip colsum_tile / GroupArgs.cs): the descriptors carry dbias again and the two column-sum launches per layer
+            # (24 us each on the chain at 6144 tokens, 0.87 ms per step) are gone.
+            sep_dbias = (not big_wgrad) and T >= int(os.environ.get("UNIVL_DBIAS_COLSUM_MIN", "1000000000"))
             w_ffn1 = _gemm_desc(dt, s_du, I, ws["a16"], H, I, H, T, trans_a=1, trans_b=1,
                                 out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=None if sep_dbias else fl.g(nm["b1"]),
                                 nt_out=self.nt_wgrad, **wg_tile, **gs.sumsq_args(nm["w1"], I, H))

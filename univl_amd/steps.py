@@ -137,7 +137,7 @@ class EncoderPass:
         cx, n, fl, dt, bf = self.cx, self.N, self.cx.fl, self.cx.dt, self.cx.bf
         W32, p, B, W, F, D, Tv = fl.w32, cx.p, self.B, self.W, self.F, self.D, self.Tv
         ST, SV = self.ST, self.SV
-        fwd.add_zeros([st.yarena for st in (self.text, self.vis) if st.ks_h > 1], ST)      # split-K accumulation targets
+        fwd.add_zeros([st.yarena for st in (self.text, self.vis) if st.any_split], ST)      # split-K accumulation targets
         cx.stamp(fwd, "f_fork", ST)
         fwd.fork(ST, SV)           # the video encoder runs concurrently with the text encoder
         cx.stamp(fwd, "f_vis_start", SV)
@@ -167,7 +167,7 @@ class EncoderPass:
 
     def zero_list(self):
         """Accumulation buffers a backward clears before anything adds into them."""
-        return [self.dseq, self.dvis, self.dvnorm] + [st.garena for st in (self.text, self.vis) if st.ks_h > 1]
+        return [self.dseq, self.dvis, self.dvnorm] + [st.garena for st in (self.text, self.vis) if st.any_split]
 
     def build_backward(self, bwd, gs, hook=None):
         """Consumes self.dseq / self.dvis (+ whatever was accumulated into self.dvnorm)."""
@@ -201,10 +201,9 @@ class EncoderPass:
     # From this many rows per position the position-table gradients are built by a gather over the per-token gradient rows
     # (univl_rows_gather_sum) instead of B atomics per table element inside the fused kernels (128 pairs: embed_bwd 173 us, the video
     # embedding's LayerNorm backward 189 us -- profiles/r03q_bench_b128_kernel_stats.csv).  UNIVL_DPOS_GATHER_MIN=0: never.
-    DPOS_GATHER_MIN = int(os.environ.get("UNIVL_DPOS_GATHER_MIN", "32"))
-
     def _gather_dpos(self):
-        return self.DPOS_GATHER_MIN > 0 and self.B >= self.DPOS_GATHER_MIN
+        thr = int(os.environ.get("UNIVL_DPOS_GATHER_MIN", "32"))        # read when the plan is built (a test lowers it)
+        return thr > 0 and self.B >= thr
 
     def _video_tail(self, bwd, gs, dxv):
         cx, n, fl, dt = self.cx, self.N, self.cx.fl, self.cx.dt
