@@ -659,7 +659,7 @@ class EncoderStack:
         # split-K of the products with H-wide outputs (N = 768: attention output, FFN2, and the dgrads of QKV / FFN1):
         #   * below 128 output tiles (a few hundred tokens) every one of them is split into ~384-deep slices -- the grid would not fill
         #     the chip otherwise (UNIVL_SPLITK_TILES / _LEN / _MAXWG, measured in rounds 1-3);
-        #   * round 4, 128 .. 511 tiles (16 .. 56 pairs x 48 tokens), bf16: only the DEEP contractions (K = 2304, 3072) into three
+        #   * round 4, 128 .. 255 tiles (16 .. 28 pairs x 48 tokens; at 32 pairs it loses: 5.80 vs 5.59 ms), bf16: only the DEEP contractions (K = 2304, 3072) into three
         #     slices.  The phase trace at 768 tokens (profiles/r04c_trace_gemm_768_variants.txt): the unsplit products run 144
         #     workgroups through 18 - 24 dependent K steps (FFN2 forward 22.4 us -> 17.6 with three slices; the dgrad halves of the
         #     FFN1 / QKV pair launches 23 / 17 us of K loop alone); K = 768 stays whole.  Round 3 had found NO gain from splitting at
@@ -668,7 +668,7 @@ class EncoderStack:
         self.tiles = ((T + 63) // 64) * (H // 64)
         # UNIVL_SPLITK_TILES: split the contraction of the N = 768 products while the 64 x 64 output grid has fewer tiles than this
         self.splitk = splitk and self.tiles < int(os.environ.get("UNIVL_SPLITK_TILES", "128"))
-        self.splitk_mid = (splitk and not self.splitk and self.bf and self.tiles < 512
+        self.splitk_mid = (splitk and not self.splitk and self.bf and self.tiles < int(os.environ.get("UNIVL_SPLITK_MID_TILES", "256"))
                            and os.environ.get("UNIVL_SPLITK_MID", "1") != "0")
         self.ks_h = self.ksplit_for(H) if self.splitk else 1
         self.any_split = self.splitk or self.splitk_mid      # <=> the zero-once arenas are needed
@@ -788,6 +788,7 @@ class EncoderStack:
         big_min = os.environ.get("UNIVL_WGRAD_BIG_MIN")
         big_wgrad = self.bf and (T >= int(big_min) if big_min else ((T + 127) // 128) * ((H + 127) // 128) >= 256)
         wg_tile = dict(tile=128, stages=2, waves=4) if big_wgrad else {}
+        pair_square = os.environ.get("UNIVL_PAIR_FORM", "") == "square"
         for l in range(self.L - 1, -1, -1):
             ws, nm = self.layers[l], self._names(l)
             xin32, xin16 = (x0_32, x0_16) if l == 0 else (self.layers[l - 1]["o32"], self.layers[l - 1]["o16"])
@@ -807,6 +808,8 @@ class EncoderStack:
             def emit(dgrad, wgrad):
                 """dgrad on the chain; its weight-gradient twin either into the layer's grouped launch (default) or into the
                 SAME launch (self.ride, where the C side accepts the pair: bf16, 64 x 64 tiles)."""
+                if pair_square:
+                    dgrad.tile = 64          # A/B switch UNIVL_PAIR_FORM=square: an explicit tile keeps the 64 x 64 form of the pair launch
                 if self.ride and _lib.lib().univl_gemm_pair(C.byref(dgrad), C.byref(wgrad), 1, None) == 0:
                     plan.add_gemm_pair(dgrad, wgrad, sm)
                 else:
