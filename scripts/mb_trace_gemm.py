@@ -88,6 +88,9 @@ def run(name, launch, split=0, reps=12, rot=1):
             wg_med=u((t3 - t0).median()), wg_max=u((t3 - t0).max()),
             span=u(t3.max() - t0.min()), out=u(s1 - t3.max()), total=u(s1 - s0)))
     rows = rows[2:] if len(rows) > 4 else rows
+    if not rows:
+        print("%-34s (no workgroups in this part)" % name)
+        return None
     m = {k: med([r[k] for r in rows]) for k in rows[0]}
     print("%-34s wgs %4d | in %4.1f skew %4.1f | tile1 %4.1f/%4.1f kloop %4.1f/%4.1f epi %4.1f/%4.1f wg %4.1f/%4.1f | span %5.1f out %4.1f | total %5.1f"
           % (name, m["nwg"], m["inn"], m["skew"], m["tile1_med"], m["tile1_max"], m["kloop_med"], m["kloop_max"], m["epi_med"], m["epi_max"],
@@ -167,11 +170,13 @@ def main():
 
         pad8 = lambda n: (n + 7) // 8 * 8
         mt = (M + 63) // 64
+        dbn = 128 if M >= 384 else 64                 # the pair launch's rectangular form: 64 x 128 dgrad tiles
+        csn = lambda cols: pad8((cols + 63) // 64)    # bias-gradient role workgroups sit between the two products
         for part in ("all", "a", "b"):          # a: the dgrad workgroups (first ids), b: the weight-gradient workgroups
             os.environ["MB_PART"] = part
-            run("pair FFN2 (dgrad + wgrad) [%s]" % part, pair_ffn2, split=pad8(mt * (I // 64)), rot=24)
-            run("pair FFN1 (dgrad ks%d + wgrad+dbias) [%s]" % (ks(I), part), pair_ffn1, split=pad8(mt * (H // 64) * ks(I)), rot=24)
-            run("pair QKV (dgrad ks%d + wgrad) [%s]" % (ks(3 * H), part), pair_qkv, split=pad8(mt * (H // 64) * ks(3 * H)), rot=24)
+            run("pair FFN2 (dgrad + wgrad) [%s]" % part, pair_ffn2, split=pad8(mt * (I // dbn)), rot=24)
+            run("pair FFN1 (dgrad ks%d + wgrad+dbias) [%s]" % (ks(I), part), pair_ffn1, split=pad8(mt * (H // dbn) * ks(I)) + csn(I), rot=24)
+            run("pair QKV (dgrad ks%d + wgrad) [%s]" % (ks(3 * H), part), pair_qkv, split=pad8(mt * (H // dbn) * ks(3 * H)), rot=24)
         os.environ["MB_PART"] = "all"
         if M >= 512:
             # what the default plan does NOT do at this size: split-K of the deep N = 768 products, half-width tiles
