@@ -311,6 +311,9 @@ extern "C" int univl_layernorm_bwd(const UnivlLayerNorm* d, hipStream_t stream) 
     // column-sum atomics per row)
     // (measured at 6144 rows, round 3: 1 / 2 rows per wave 14.57 / 14.11 vs 13.94 ms per step with this heuristic)
     int rpw = d->rows / 2048;
+#ifdef UNIVL_TRACE
+    if (const char* e = getenv("UNIVL_LN_RPW")) { if (atoi(e) > 0) rpw = atoi(e); }      // measurement build only (scripts/mb_ln_bwd.py)
+#endif
     rpw = rpw < 1 ? 1 : (rpw > LN_RPW ? LN_RPW : rpw);
     dim3 grid((d->rows + 4 * rpw - 1) / (4 * rpw)), block(256);
     const bool bf = d->dtype == UNIVL_DT_BF16;
