@@ -233,6 +233,50 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #pragma unroll
         for (int b = 0; b < NI; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // Epilogue INPUTS that exist before the launch (bias; for sub-tiles of at most two accumulator tiles also the fp32 residual and the
+    // saved pre-activation of the GELU' epilogue) are requested HERE, in front of the first staging round trip, from clamped (always
+    // valid) addresses: they land while the first tile is in flight.  Fetched after the K loop they cost the epilogue one more memory
+    // round trip (phase trace, profiles/r04b_trace_gemm_phases.txt: 1.4 us of epilogue behind a 4 us K loop at 192 rows).
+    const bool first_slice = (bz == 0);
+    constexpr bool PRE = (MI * NI <= 2);              // the 64 x 64 tile on 8 waves: 12 more live registers; larger sub-tiles would spill
+    constexpr int PM = PRE ? MI : 1;
+    float bv[NI];
+    float rpre[PM][NI][4];
+    T upre[PM][NI][4];
+    {
+        int pcol[NI];
+#pragma unroll
+        for (int b = 0; b < NI; ++b) pcol[b] = min(n0 + wn0 + 16 * b + i, p.N - 1);
+        if constexpr (PRE) {
+            if (p.bias && first_slice) {
+#pragma unroll
+                for (int b = 0; b < NI; ++b) bv[b] = p.bias[pcol[b]];
+            } else {
+#pragma unroll
+                for (int b = 0; b < NI; ++b) bv[b] = 0.0f;
+            }
+            const T* auxp = reinterpret_cast<const T*>(p.aux);
+            if (p.R && first_slice) {
+#pragma unroll
+                for (int a = 0; a < MI; ++a)
+#pragma unroll
+                    for (int b = 0; b < NI; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            rpre[a][b][r] = p.R[(long)min(m0 + wm0 + 16 * a + 4 * g + r, p.M - 1) * p.ldr + pcol[b]];
+            }
+            if (p.flags & UNIVL_GEMM_GELU_BWD) {
+#pragma unroll
+                for (int a = 0; a < MI; ++a)
+#pragma unroll
+                    for (int b = 0; b < NI; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            upre[a][b][r] = auxp[(long)min(m0 + wm0 + 16 * a + 4 * g + r, p.M - 1) * p.ldaux + pcol[b]];
+            }
+        }
+    }
+
     const bool want_dbias = TA && (p.dbias != nullptr) && (bx == 0);
     float dbias_acc = 0.0f;
 
@@ -302,12 +346,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 
     UNIVL_TRACE_AT(2);
     // ------------------------------------------------------------------------------------------ epilogue
-    // All epilogue INPUTS (bias, residual, saved pre-activation, old C) are fetched first, in flag-uniform groups
-    // of back-to-back loads from clamped (always valid) addresses; only the stores are predicated.  A per-element
-    // "if (flag) load" would serialise 16 dependent round trips per thread.
+    // The remaining epilogue inputs (old C; residual / pre-activation of the large sub-tiles) are fetched in flag-uniform groups of
+    // back-to-back loads from clamped (always valid) addresses; only the stores are predicated.  A per-element "if (flag) load"
+    // would serialise 16 dependent round trips per thread.  One 16-row slab of the wave's sub-tile at a time: keeps the live epilogue
+    // values to NI x 4 per input instead of MI x NI x 4 (the 128 x 128 tile would otherwise need > 256 VGPRs).
     const bool atomic = (p.flags & UNIVL_GEMM_ATOMIC) != 0;
     const bool nt_out = (p.flags & UNIVL_GEMM_NT_OUT) != 0;
-    const bool first_slice = (bz == 0);
     T* C16 = reinterpret_cast<T*>(p.C16);
     T* aux = reinterpret_cast<T*>(p.aux);
     long orow[MI][4];
@@ -327,15 +371,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         vcol[b] = col < p.N;
         ocol[b] = min(col, p.N - 1);
     }
-    // one 16-row slab of the wave's sub-tile at a time: keeps the live epilogue values to NI x 4 per input instead of
-    // MI x NI x 4 (the 128x128 tile would otherwise need > 256 VGPRs and drop to one wave per SIMD)
-    float bv[NI];
-    if (p.bias && first_slice) {
+    if constexpr (!PRE) {
+        if (p.bias && first_slice) {
 #pragma unroll
-        for (int b = 0; b < NI; ++b) bv[b] = p.bias[ocol[b]];
-    } else {
+            for (int b = 0; b < NI; ++b) bv[b] = p.bias[ocol[b]];
+        } else {
 #pragma unroll
-        for (int b = 0; b < NI; ++b) bv[b] = 0.0f;
+            for (int b = 0; b < NI; ++b) bv[b] = 0.0f;
+        }
     }
     float ssq = 0.0f;
 #pragma unroll
@@ -350,7 +393,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #pragma unroll
             for (int b = 0; b < NI; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rv[b][r] = p.R[orow[a][r] * p.ldr + ocol[b]];
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (PRE) rv[b][r] = rpre[a][b][r];
+                    else rv[b][r] = p.R[orow[a][r] * p.ldr + ocol[b]];
+                }
 #pragma unroll
             for (int b = 0; b < NI; ++b)
 #pragma unroll
@@ -370,7 +416,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #pragma unroll
             for (int b = 0; b < NI; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) uv[b][r] = aux[orow[a][r] * p.ldaux + ocol[b]];
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (PRE) uv[b][r] = upre[a][b][r];
+                    else uv[b][r] = aux[orow[a][r] * p.ldaux + ocol[b]];
+                }
 #pragma unroll
             for (int b = 0; b < NI; ++b)
 #pragma unroll

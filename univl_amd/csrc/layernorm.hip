@@ -307,10 +307,11 @@ extern "C" int univl_layernorm_bwd(const UnivlLayerNorm* d, hipStream_t stream) 
     UNIVL_CHECK_ARG(aligned16(d->dout) && aligned16(d->y) && aligned16(d->dx32) && aligned16(d->dxd32) &&
                         aligned16(d->dxd16) && aligned16(d->gamma),
                     UNIVL_EALIGN, "univl_layernorm_bwd: pointers must be 16-byte aligned");
-    // rows per wave: 1 while the grid is small (parallelism first), up to LN_RPW once it fills the chip (fewer
-    // column-sum atomics per row)
-    // (measured at 6144 rows, round 3: 1 / 2 rows per wave 14.57 / 14.11 vs 13.94 ms per step with this heuristic)
-    int rpw = d->rows / 2048;
+    // rows per wave: 1 while the grid is small (parallelism first), more once it fills the chip -- every workgroup issues 3 x N fp32
+    // atomics for its column sums, whatever the number of rows it walked.  Measured per launch (profiles/r04f_mb_ln_bwd_rows_per_wave.txt,
+    // 1 / 2 / 4 rows per wave): 192 rows 6.1 / 7.2 / 10.3 us; 768 rows 10.4 / 9.1 / 11.3; 1536 rows 17.6 / 13.3 / 12.9; 6144 rows
+    // 47.0 / 30.6 / 23.3 (the round-3 heuristic rows / 2048 gave 10.3 / 17.0 / 24.8 at 768 / 1536 / 6144 rows).
+    int rpw = d->rows < 640 ? 1 : (d->rows < 1280 ? 2 : 4);
 #ifdef UNIVL_TRACE
     if (const char* e = getenv("UNIVL_LN_RPW")) { if (atoi(e) > 0) rpw = atoi(e); }      // measurement build only (scripts/mb_ln_bwd.py)
 #endif

@@ -308,13 +308,6 @@ class Plan:
         self.rider_keys.add(key)
         self.ops.append(("rider", _lib.lib().univl_gemm_rider, (desc, key, int(slot), int(nslots)), "univl_gemm_rider", stream))
 
-    def add_update_slot(self, key, stream=0):
-        """While self.riders names a chunk range for `key` that no forward product carries (the first layer of a stack: nothing runs
-        before it on its stream), the range is launched HERE, on `stream`, as an ordinary univl_bert_adam_range -- so that the video
-        stack's first layer is updated on the video stack's stream, beside the text chain, instead of in front of both."""
-        self.rider_keys.add(key)
-        self.ops.append(("update", key, None, "univl_bert_adam_range", stream))
-
     def add(self, fn_name, desc, stream=0):
         fn = getattr(_lib.lib(), fn_name)
         self.keep.append(desc)
@@ -439,17 +432,6 @@ class Plan:
                     rc = a(C.byref(desc), C.byref(rd["desc"]), lo, hi - lo, int(rd.get("max_blocks", 0)), h)
                 if rc != 0:
                     _lib.check(rc, name)
-            elif kind == "update":
-                rd = self.riders
-                rng = rd["ranges"].get(a) if rd else None
-                if rng is not None and (a, "slot") not in rd["used"]:
-                    rd["used"].add((a, "slot"))
-                    h = handles.get(sidx)
-                    if h is None:
-                        h = handles[sidx] = C.c_void_p(self._stream(sidx, cur).cuda_stream)
-                    rc = _lib.lib().univl_bert_adam_range(C.byref(rd["desc"]), rng[0], rng[1], 0, int(rd.get("max_blocks", 0)), h)
-                    if rc != 0:
-                        _lib.check(rc, name)
             elif kind == "pair":
                 h = handles.get(sidx)
                 if h is None:
@@ -645,10 +627,9 @@ class EncoderStack:
         # UNIVL_PROBE_SKIP=<prefix> (measurement only, scripts/probe_branches.py): this stack emits NO layer kernels, forward or
         # backward -- what the step costs without one of its two encoder branches (results are meaningless)
         self.probe_skip = os.environ.get("UNIVL_PROBE_SKIP", "") == prefix
-        # riding optimizer update: the stack's FIRST layer (no forward product in front of it could carry its chunks) is updated by a
-        # launch on the stack's own stream at the head of the stack instead of in front of the whole forward -- for the video stack
-        # that takes 40 us off the text chain at 4 pairs (round 4).  The text stack's first layer stays where it was: same stream.
-        self.update_slot0 = prefix == "visual" and os.environ.get("UNIVL_UPDATE_SLOT0", "1") != "0"
+        # (Round 4, measured and removed: the video stack's first layer updated by a launch on the video stack's own stream instead of in
+        # front of the whole forward -- 2.391 / 2.391 / 2.427 vs 2.392 / 2.396 / 2.397 ms per step, profiles/r04f_ab_update_slot.txt: the
+        # prologue launches are HBM streams, two of them side by side each run at half speed.)
         self.T = B * S
         self.key_mask = key_mask            # int64 [B,S] device tensor (static buffer)
         self.p = float(p_drop)
@@ -739,8 +720,6 @@ class EncoderStack:
             return
         if self.any_split and zero_arena:
             plan.add_callable(self.yarena.zero_, stream=sm)
-        if self.adam_ride and self.update_slot0:
-            plan.add_update_slot(("layer", self.prefix, 0), sm)
         for l, ws in enumerate(self.layers):
             nm = self._names(l)
             plan.wait_point(("layer", self.prefix, l), sm)
