@@ -990,8 +990,12 @@ extern "C" int univl_gemm_pair(const UnivlGemm* dgrad, const UnivlGemm* wgrad, i
     UNIVL_CHECK_ARG(dgrad->dtype == UNIVL_BF16 && wgrad->dtype == UNIVL_BF16 && !dgrad->trans_a && dgrad->trans_b && wgrad->trans_a &&
                         wgrad->trans_b && cd.tile == 64 && cw.tile == 64 && cd.nc == 4 && (cw.nc == 4 || cw.nc == 6) && !dgrad->sumsq,
                     UNIVL_EUNSUPPORTED, "univl_gemm_pair: needs a bf16 (K-major, T-major) product and a bf16 (T-major, T-major) product on the 64 tile");
-    // rectangular form from 384 tokens on (gemm_pair_kernel): the split of either contraction is re-derived for 64-deep K steps
-    const bool rect = dgrad->M >= 384 && dgrad->tile == 0 && wgrad->tile == 0;
+    // rectangular form from 384 tokens on (gemm_pair_kernel) -- unless the dgrad slice is deeper than 1536: its workgroups then walk
+    // more than 24 of the 64-deep K steps alone (a 3072-deep unsplit dgrad: 48 steps, 42 us at 768 tokens against 22 us for the square
+    // form's 24 steps of 128; profiles/r04d_bench_lines.txt: +7 % per step on the caption / FT-Align configurations before this rule).
+    // The split of either contraction is re-derived for 64-deep K steps.
+    const long dslice = ((long)dgrad->K + ksd - 1) / ksd;
+    const bool rect = dgrad->M >= 384 && dslice <= 1536 && dgrad->tile == 0 && wgrad->tile == 0;
     if (rect) {
         rc = prepare(dgrad, a.d, ksd, cd, 64, 2);
         if (rc != UNIVL_OK) return rc;
