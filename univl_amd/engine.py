@@ -298,8 +298,6 @@ class Plan:
         self._side = {}
         self._segments = None
         self.rider_keys = set()      # chunk-group keys this plan can carry beside its forward products (add_gemm_rider)
-        self.prologue_slots = set()  # (key, slot, nslots): parts of those groups NO product can carry -- the first matrix of a stack's
-                                     # first layer; UniVL._start_riding_update launches them in front of the forward
         self.riders = None           # set for the duration of one run: dict(desc=UnivlAdam, ranges={key: (first, count)}, max_blocks=int)
 
     def add_gemm_rider(self, desc, key, slot, nslots, stream=0):
@@ -632,7 +630,6 @@ class EncoderStack:
         # (Round 4, measured and removed: the video stack's first layer updated by a launch on the video stack's own stream instead of in
         # front of the whole forward -- 2.391 / 2.391 / 2.427 vs 2.392 / 2.396 / 2.397 ms per step, profiles/r04f_ab_update_slot.txt: the
         # prologue launches are HBM streams, two of them side by side each run at half speed.)
-        self.ride_ahead = os.environ.get("UNIVL_RIDE_AHEAD", "launch")      # "layer": the round-3 assignment (A/B)
         self.T = B * S
         self.key_mask = key_mask            # int64 [B,S] device tensor (static buffer)
         self.p = float(p_drop)
@@ -729,26 +726,14 @@ class EncoderStack:
             slot = [0]
 
             def gemm(desc, _l=l, _slot=slot):
-                """A forward product of layer l.  With self.adam_ride it carries a quarter of a layer's optimizer chunks ONE LAUNCH
-                ahead of their use (round 4; round 3: one whole layer ahead): the k-th product of layer l (QKV, attention output,
-                FFN1, FFN2) carries quarter k + 1 of layer l's own chunk range, the last product quarter 0 of layer l + 1.  A layer's
-                four matrices lie in the flat buffer in the order their products run, and every prefix of that order fits the
-                quarters delivered before it is read (UniVL._start_riding_update checks this against the chunk table and falls back
-                to whole-layer launches otherwise).  What no product can carry shrinks from the whole first layer of a stack to its
-                first quarter -- the QKV weights: the launches in front of the forward lose ~30 us per stack at 4 pairs."""
-                k = _slot[0]
-                _slot[0] += 1
-                if self.adam_ride and self.ride_ahead == "launch":
-                    if k < 3:
-                        plan.add_gemm_rider(desc, ("layer", self.prefix, _l), k + 1, 4, sm)
-                        if _l == 0 and k == 0:
-                            plan.prologue_slots.add((("layer", self.prefix, 0), 0, 4))
-                    elif _l + 1 < self.L:
-                        plan.add_gemm_rider(desc, ("layer", self.prefix, _l + 1), 0, 4, sm)
-                    else:
-                        plan.add("univl_gemm", desc, sm)
-                elif self.adam_ride and _l + 1 < self.L:
-                    plan.add_gemm_rider(desc, ("layer", self.prefix, _l + 1), k, 4, sm)
+                """a forward product of layer l; with self.adam_ride it can carry a quarter of layer l + 1's optimizer chunks.
+                (Round 4, measured and removed: riders ONE LAUNCH ahead instead of one layer ahead -- product k of layer l carrying
+                quarter k + 1 of its own layer, so that only the first quarter of a stack's first layer is left to the launches in
+                front of the forward: bit-identical, 2.405 / 2.436 / 2.406 vs 2.422 / 2.374 / 2.408 ms per step at 4 pairs,
+                profiles/r04h_ab_ride_ahead.txt -- the bytes cost the same wherever they ride.)"""
+                if self.adam_ride and _l + 1 < self.L:
+                    plan.add_gemm_rider(desc, ("layer", self.prefix, _l + 1), _slot[0], 4, sm)
+                    _slot[0] += 1
                 else:
                     plan.add("univl_gemm", desc, sm)
 

@@ -149,7 +149,7 @@ class GraphedTrainStep:
         opt, model = self.opt, self.model
         fl = model.flat
         assert getattr(fl, "shard_reducer", None) is None, "UNIVL_ADAM_RIDE does not combine with the sharded optimizer"
-        model._rider_update = dict(desc=opt._last_desc, groups=opt.chunk_groups(), max_blocks=self.adam_blocks, tables=opt._tb)
+        model._rider_update = dict(desc=opt._last_desc, groups=opt.chunk_groups(), max_blocks=self.adam_blocks)
         opt._deferred = False                 # from here on the update counts as applied (launch_deferred's bookkeeping)
         fl.shadow_valid = True
         model._in_pipelined_call = True

@@ -737,78 +737,15 @@ class UniVL(UniVLPreTrainedModel):
         L, d = _lib.lib(), ru["desc"]
         h = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         ranges, first = {}, True
-        pro = {}                     # key -> [(slot, nslots)] launched in front of the forward although the key rides
-        for key, slot, nslots in st.fwd.prologue_slots:
-            pro.setdefault(key, []).append((slot, nslots))
-        safe = self._riding_quarters_are_safe(ru) if pro else True
-        used = set()
         for key, c0, n in ru["groups"]:
-            if safe and key in st.fwd.rider_keys and key not in ranges:
+            if key in st.fwd.rider_keys and key not in ranges:
                 ranges[key] = (c0, n)
-                for slot, nslots in pro.get(key, ()):
-                    lo, hi = c0 + n * slot // nslots, c0 + n * (slot + 1) // nslots
-                    _lib.check(L.univl_bert_adam_range(C.byref(d), lo, hi - lo, 1 if first else 0, 0, h), "bert_adam_range")
-                    first = False
-                    used.add((key, slot))
                 continue
-            # what the plan cannot carry -- or, for a chunk table the launch-ahead assignment is not safe for, everything: the riders
-            # then find no range and run as plain products
             _lib.check(L.univl_bert_adam_range(C.byref(d), c0, n, 1 if first else 0, 0, h), "bert_adam_range")
             first = False
         if first:                     # nothing went out as a prologue launch: the per-tensor scalars still have to be prepared
             _lib.check(L.univl_bert_adam_range(C.byref(d), 0, 0, 1, 0, h), "bert_adam_range")
-        st.fwd.riders = dict(desc=d, ranges=ranges, max_blocks=int(ru.get("max_blocks", 0)), used=used)
-
-    def _riding_quarters_are_safe(self, ru):
-        """The one-launch-ahead rider assignment (engine.EncoderStack.build_forward) delivers quarter q of a layer's chunk range before
-        the layer's q-th product runs; that is only correct if the first q + 1 quarters cover the first q + 1 matrices of the layer
-        (QKV | attention output | FFN1 | FFN2, in flat-buffer order).  Checked here against the optimizer's chunk table, once per
-        table: True for the reference's layer shapes; anything else (other shapes, a sharded table) takes the whole-layer form."""
-        tb = ru.get("tables")
-        if tb is None:
-            return False
-        cached = getattr(tb, "_quarters_safe", None)
-        if cached is not None:
-            return cached
-        fl, ok = self.flat, True
-        import re
-        seg_of_chunk = tb.chunk_seg_host
-        for key, c0, n in ru["groups"]:
-            if not (isinstance(key, tuple) and key[0] == "layer" and key[1] in ("bert", "visual", "cross")):
-                continue
-            ends, last = [], None                      # chunk index (relative) where each weight matrix of the layer ends
-            order = []
-            for c in range(c0, c0 + n):
-                name = fl.order[seg_of_chunk[c]]
-                if name != last:
-                    order.append(name)
-                    last = name
-                if re.search(r"attention\.self\.value\.weight$", name):
-                    idx = 0
-                elif re.search(r"attention\.output\.dense\.weight$", name):
-                    idx = 1
-                elif re.search(r"intermediate\.dense\.weight$", name):
-                    idx = 2
-                elif re.search(r"\.output\.dense\.weight$", name):
-                    idx = 3
-                else:
-                    idx = 0 if re.search(r"attention\.self\.(query|key)\.weight$", name) else None
-                if idx is None:
-                    ok = False
-                    break
-                while len(ends) <= idx:
-                    ends.append(0)
-                ends[idx] = c - c0 + 1
-            if not ok or len(ends) != 4 or ends != sorted(ends):
-                ok = False
-                break
-            for q in range(4):                         # matrix q must lie inside quarters 0 .. q
-                if ends[q] > n * (q + 1) // 4:
-                    ok = False
-            if not ok:
-                break
-        tb._quarters_safe = ok
-        return ok
+        st.fwd.riders = dict(desc=d, ranges=ranges, max_blocks=int(ru.get("max_blocks", 0)), used=set())
 
     def get_sequence_visual_output(self, input_ids, token_type_ids, attention_mask, video, video_mask, shaped=False):
         """modeling.py:299-313.  `shaped=True` means the caller already flattened the pair dim AND normalised the video
