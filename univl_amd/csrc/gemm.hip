@@ -210,7 +210,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     using TileB = Tile<T, TB, BN, BK, NT>;
     constexpr int WM = BM / WGM, WN = BN / WGN;      // per-wave sub-tile
     constexpr int MI = WM / 16, NI = WN / 16;
-    constexpr int D = 2;
+    constexpr int D = NC == 6 ? 1 : 2;      // NC == 6: the single 192-deep K step of a weight gradient at 192 tokens -- one stage
     static_assert(BM <= NT, "the bias-gradient pass uses one thread per tile row");
 
     // ONE dynamic LDS object, declared once at namespace scope (a second __shared__ object makes hipcc drain vmcnt(0) before every ds_read)
@@ -650,8 +650,8 @@ int launch_group(const GroupArgs& g, int max_blocks, hipStream_t stream) {
     constexpr int BK = NC * Mma<T>::CH, NT = 64 * WGM * WGN;
     using TileA = Tile<T, TA, BM, BK, NT>;
     using TileB = Tile<T, TB, BN, BK, NT>;
-    // NC == 6 is the one-K-step variant: only stage 0 of B is ever touched (A keeps the two-stage offset layout)
-    const size_t smem = NC == 6 ? 2 * TileA::BYTES + TileB::BYTES : 2 * (TileA::BYTES + TileB::BYTES);
+    // NC == 6 is the one-K-step variant: one stage of each operand
+    const size_t smem = NC == 6 ? TileA::BYTES + TileB::BYTES : 2 * (TileA::BYTES + TileB::BYTES);
     static bool attr_done[UNIVL_MAX_DEVICES] = {};   // per instantiation, per device
     if (smem > 48 * 1024) univl_allow_lds(gemm_group_kernel<T, TA, TB, BM, BN, NC, WGM, WGN>, smem, attr_done);
     const int total = g.first[UNIVL_GEMM_GROUP_MAX] + g.cs_first[UNIVL_GEMM_GROUP_MAX];
@@ -688,23 +688,29 @@ __host__ __device__ __forceinline__ void pair_tile(int t, int total, int nx, int
     }
 }
 
-// Two forms of the launch, both bodies on 8 waves:
-//   square (RECT = false): 64 x 64 tiles for both products, 128-deep K steps for the dgrad body, NCW x 32-deep ones (128, or the single
-//     192-deep step at 192 tokens) for the weight-gradient body; 72 KB of LDS, two workgroups per compute unit.  A few hundred tokens: the
-//     dgrad product is a latency chain and wants as many workgroups as there are compute units.
-//   rectangular (RECT = true, from 384 tokens on): 64 x 128 tiles for the dgrad product (tokens x in-features), 128 x 64 tiles for the
-//     weight gradient (out-features x in-features), 64-deep K steps, 48 KB of LDS and <= 80 VGPRs: THREE workgroups per compute unit.
-//     At 768 tokens both products are bound by what a compute unit can pull through LDS-DMA (~45 GB/s: the phase trace,
-//     profiles/r04c_trace_gemm_768_variants.txt), i.e. by the bytes the tiles stage: an FFN pair stages 226 MB as 1152 square tiles
-//     (2.25 rounds of 512 slots, 33 us) but 170 MB as 576 rectangular ones -- one round of 768 slots.
-template <int NCW, bool RECT>
-__global__ __launch_bounds__(512, RECT ? 6 : 2) void gemm_pair_kernel(PairArgs a) {
+// Forms of the launch (both bodies on 8 waves; DR / WF select the dgrad / weight-gradient body):
+//   dgrad   DR = false: 64 x 64 tiles, 128-deep K steps (a few hundred tokens: the product is a latency chain and wants as many
+//                       workgroups as there are compute units)
+//           DR = true : 64 x 128 tiles, 64-deep K steps (from 384 tokens on, dgrad slices up to 1536 deep)
+//   wgrad   WF = 0: 64 x 64 tiles, 128-deep K steps      WF = 1: 64 x 64, the single 192-deep step (round 3's form at 192 tokens)
+//           WF = 2: 128 x 64 tiles, 64-deep K steps       WF = 3: 128 x 64, the single 192-deep step
+//   (DR, WF) = (false, 0): round 2's form, now only below 384 tokens where neither operand is 8-aligned enough for the others;
+//   (true, 2): THREE workgroups per compute unit (48 KB of LDS, <= 80 VGPRs).  At 768 tokens both products are bound by what a
+//     compute unit can pull through LDS-DMA (~45 GB/s: the phase trace, profiles/r04c_trace_gemm_768_variants.txt), i.e. by the
+//     bytes the tiles stage: an FFN pair stages 226 MB as 1152 square tiles (2.25 rounds of 512 slots, 33 us) but 170 MB as 576
+//     rectangular ones -- one round of 768 slots, 25 us;
+//   (false, 3) / (false, 2): below 384 tokens the dgrad stays square, the weight gradient takes the 128 x 64 tile -- half as many
+//     workgroups behind the dgrad tiles (FFN: 288 instead of 576) staging 3/4 of the bytes: in the phase trace at 192 tokens
+//     (profiles/r04g_trace_gemm_phases.txt) the square weight-gradient tiles of the FFN1 / QKV pairs end 3 - 4 us after the dgrad
+//     chain they ride with (17.6 / 15.9 us per launch against 14.8 for the dgrad-bound FFN2 pair).
+template <bool DR, int WF>
+__global__ __launch_bounds__(512, (DR && WF == 2) ? 6 : 4) void gemm_pair_kernel(PairArgs a) {      // 4 waves per SIMD = two workgroups per compute unit
     const int w0 = blockIdx.x;
     int bx, by, bz;
     if (w0 < a.nd_pad) {
         if (w0 >= a.nd) return;                                  // padding workgroup (whole block: no barrier is skipped)
         pair_tile(w0, a.nd, a.dnx, a.dny, a.dnz, a.d.flags, a.d.gm, bx, by, bz);
-        if constexpr (RECT) gemm_tile<__bf16, false, true, 64, 128, 2, 2, 4>(a.d, bx, by, bz, a.dnz);
+        if constexpr (DR) gemm_tile<__bf16, false, true, 64, 128, 2, 2, 4>(a.d, bx, by, bz, a.dnz);
         else gemm_tile<__bf16, false, true, 64, 64, 4, 2, 4>(a.d, bx, by, bz, a.dnz);
     } else if (w0 < a.nd_pad + a.cs.n_pad) {
         const int t = w0 - a.nd_pad;
@@ -712,23 +718,23 @@ __global__ __launch_bounds__(512, RECT ? 6 : 2) void gemm_pair_kernel(PairArgs a
         colsum_tile<512>(a.cs, t, smem_raw);
     } else {
         pair_tile(w0 - a.nd_pad - a.cs.n_pad, a.nw, a.wnx, a.wny, a.wnz, a.w.flags, a.w.gm, bx, by, bz);
-        if constexpr (RECT) gemm_tile<__bf16, true, true, 128, 64, 2, 4, 2>(a.w, bx, by, bz, a.wnz);
-        else gemm_tile<__bf16, true, true, 64, 64, NCW, 2, 4>(a.w, bx, by, bz, a.wnz);
+        if constexpr (WF == 0) gemm_tile<__bf16, true, true, 64, 64, 4, 2, 4>(a.w, bx, by, bz, a.wnz);
+        else if constexpr (WF == 1) gemm_tile<__bf16, true, true, 64, 64, 6, 2, 4>(a.w, bx, by, bz, a.wnz);
+        else if constexpr (WF == 2) gemm_tile<__bf16, true, true, 128, 64, 2, 4, 2>(a.w, bx, by, bz, a.wnz);
+        else gemm_tile<__bf16, true, true, 128, 64, 6, 4, 2>(a.w, bx, by, bz, a.wnz);
     }
 }
 
-template <int NCW, bool RECT>
+template <bool DR, int WF>
 int launch_pair(const PairArgs& a, hipStream_t stream) {
-    using TA_d = Tile<__bf16, false, 64, 4 * 32, 512>;
-    using TA_w = Tile<__bf16, true, 64, NCW * 32, 512>;
-    const size_t smem_d = 2 * (size_t)(TA_d::BYTES + TA_d::BYTES);                 // A and B tiles are both 64 rows x BK
-    const size_t smem_w = NCW == 6 ? 3 * (size_t)TA_w::BYTES : 4 * (size_t)TA_w::BYTES;   // one-step form: stage 0 of B only
-    const size_t smem_sq = smem_d > smem_w ? smem_d : smem_w;
-    const size_t smem_rect = 2 * (size_t)(64 + 128) * 64 * sizeof(__bf16);         // two stages of a 64-row and a 128-row tile, BK = 64
-    const size_t smem = RECT ? smem_rect : smem_sq;
+    constexpr size_t smem_d = DR ? 2 * (size_t)(64 + 128) * 64 * sizeof(__bf16) : 2 * (size_t)(64 + 64) * 128 * sizeof(__bf16);
+    constexpr size_t smem_w = WF == 0 ? 2 * (size_t)(64 + 64) * 128 * sizeof(__bf16)
+                              : WF == 1 ? (size_t)(64 + 64) * 192 * sizeof(__bf16)
+                              : WF == 2 ? 2 * (size_t)(128 + 64) * 64 * sizeof(__bf16) : (size_t)(128 + 64) * 192 * sizeof(__bf16);
+    constexpr size_t smem = smem_d > smem_w ? smem_d : smem_w;
     static bool attr_done[UNIVL_MAX_DEVICES] = {};
-    univl_allow_lds(gemm_pair_kernel<NCW, RECT>, smem, attr_done);
-    hipLaunchKernelGGL((gemm_pair_kernel<NCW, RECT>), dim3(a.nd_pad + a.cs.n_pad + a.nw), dim3(512), smem, stream, a);
+    univl_allow_lds(gemm_pair_kernel<DR, WF>, smem, attr_done);
+    hipLaunchKernelGGL((gemm_pair_kernel<DR, WF>), dim3(a.nd_pad + a.cs.n_pad + a.nw), dim3(512), smem, stream, a);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
@@ -759,8 +765,8 @@ int launch(const GemmArgs& a, int ksplit, hipStream_t stream) {
     constexpr int BK = NC * Mma<T>::CH, NT = 64 * WGM * WGN;
     using TileA = Tile<T, TA, BM, BK, NT>;
     using TileB = Tile<T, TB, BN, BK, NT>;
-    // NC == 6 is the one-K-step variant: only stage 0 of B is ever touched (A keeps the two-stage offset layout)
-    const size_t smem = NC == 6 ? 2 * TileA::BYTES + TileB::BYTES : 2 * (TileA::BYTES + TileB::BYTES);
+    // NC == 6 is the one-K-step variant: one stage of each operand
+    const size_t smem = NC == 6 ? TileA::BYTES + TileB::BYTES : 2 * (TileA::BYTES + TileB::BYTES);
     static bool attr_done[UNIVL_MAX_DEVICES] = {};   // per instantiation, per device
     if (smem > 48 * 1024) univl_allow_lds(gemm_kernel<T, TA, TB, BM, BN, NC, WGM, WGN>, smem, attr_done);
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, ksplit);
@@ -990,20 +996,28 @@ extern "C" int univl_gemm_pair(const UnivlGemm* dgrad, const UnivlGemm* wgrad, i
     UNIVL_CHECK_ARG(dgrad->dtype == UNIVL_BF16 && wgrad->dtype == UNIVL_BF16 && !dgrad->trans_a && dgrad->trans_b && wgrad->trans_a &&
                         wgrad->trans_b && cd.tile == 64 && cw.tile == 64 && cd.nc == 4 && (cw.nc == 4 || cw.nc == 6) && !dgrad->sumsq,
                     UNIVL_EUNSUPPORTED, "univl_gemm_pair: needs a bf16 (K-major, T-major) product and a bf16 (T-major, T-major) product on the 64 tile");
-    // rectangular form from 384 tokens on (gemm_pair_kernel) -- unless the dgrad slice is deeper than 1536: its workgroups then walk
-    // more than 24 of the 64-deep K steps alone (a 3072-deep unsplit dgrad: 48 steps, 42 us at 768 tokens against 22 us for the square
-    // form's 24 steps of 128; profiles/r04d_bench_lines.txt: +7 % per step on the caption / FT-Align configurations before this rule).
-    // The split of either contraction is re-derived for 64-deep K steps.
+    // the dgrad body: rectangular from 384 tokens on (gemm_pair_kernel) -- unless the dgrad slice is deeper than 1536: its workgroups
+    // then walk more than 24 of the 64-deep K steps alone (a 3072-deep unsplit dgrad: 48 steps, 42 us at 768 tokens against 22 us for
+    // the square form's 24 steps of 128; profiles/r04d_bench_lines.txt: +7 % per step on the caption / FT-Align configurations before
+    // this rule).  The weight-gradient body: 128 x 64 tiles wherever its out-feature count allows (multiples of 128 rows keep the
+    // fused gradient-norm slots exact), 64-deep K steps or the single 192-deep one.  An explicit tile in either descriptor keeps
+    // round 2's square form (the A/B switch of engine.EncoderStack, and the form the bit-identity test compares against).
     const long dslice = ((long)dgrad->K + ksd - 1) / ksd;
-    const bool rect = dgrad->M >= 384 && dslice <= 1536 && dgrad->tile == 0 && wgrad->tile == 0;
-    if (rect) {
+    const bool plain = dgrad->tile == 0 && wgrad->tile == 0;
+    const bool drect = plain && dgrad->M >= 384 && dslice <= 1536;
+    const bool wrect = plain && wgrad->M % 128 == 0 && (!wgrad->sumsq || wgrad->sumsq_rows % 128 == 0);
+    const bool wone = cw.nc == 6;                     // K == 192, unsplit: the single-step body
+    if (drect) {
         rc = prepare(dgrad, a.d, ksd, cd, 64, 2);
         if (rc != UNIVL_OK) return rc;
+        UNIVL_CHECK_ARG(cd.nc == 2, UNIVL_EUNSUPPORTED, "univl_gemm_pair: rectangular dgrad body needs 64-deep K steps");
+    }
+    if (wrect && !wone) {
         rc = prepare(wgrad, a.w, ksw, cw, 64, 2);
         if (rc != UNIVL_OK) return rc;
-        UNIVL_CHECK_ARG(cd.nc == 2 && cw.nc == 2, UNIVL_EUNSUPPORTED, "univl_gemm_pair: rectangular form needs 64-deep K steps");
+        UNIVL_CHECK_ARG(cw.nc == 2, UNIVL_EUNSUPPORTED, "univl_gemm_pair: rectangular weight-gradient body needs 64-deep K steps");
     }
-    const int dbn = rect ? 128 : 64, wbm = rect ? 128 : 64;
+    const int dbn = drect ? 128 : 64, wbm = wrect ? 128 : 64;
     a.dnx = (dgrad->N + dbn - 1) / dbn; a.dny = (dgrad->M + 63) / 64; a.dnz = ksd;
     a.wnx = (wgrad->N + 63) / 64; a.wny = (wgrad->M + wbm - 1) / wbm; a.wnz = ksw;
     a.nd = a.dnx * a.dny * a.dnz;
@@ -1025,8 +1039,9 @@ extern "C" int univl_gemm_pair(const UnivlGemm* dgrad, const UnivlGemm* wgrad, i
         a.w.dbias = nullptr;
     }
     if (dry_run) return UNIVL_OK;
-    if (rect) return launch_pair<2, true>(a, stream);
-    return cw.nc == 6 ? launch_pair<6, false>(a, stream) : launch_pair<4, false>(a, stream);
+    if (drect) return wrect ? launch_pair<true, 2>(a, stream) : launch_pair<true, 0>(a, stream);
+    if (wrect) return wone ? launch_pair<false, 3>(a, stream) : launch_pair<false, 2>(a, stream);
+    return wone ? launch_pair<false, 1>(a, stream) : launch_pair<false, 0>(a, stream);
 }
 
 static const size_t RIDER_SMEM = 4 * (size_t)Tile<__bf16, false, 64, 128, 512>::BYTES;          // two stages of A and B
