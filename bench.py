@@ -497,20 +497,23 @@ def main():
         # HBM bytes per launch / per step from the PMC passes (FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes of
         # scripts/pmc_step.py, both calibrated on cast_kernel's exactly known traffic) -- only while the file was produced by THESE
         # kernel sources (stamp written by scripts/pmc_step_parse.py) and for this batch; otherwise null, never a stale constant
-        traffic = traffic_step = None
-        pmc = os.path.join(ROOT, "profiles", "r03_gemm_pmc.json")
-        if os.path.exists(pmc) and args.batch == 4 and args.kind == "joint":
-            try:
-                import hashlib
-                hs = hashlib.sha256()
-                for name in ("gemm.hip", "common.h"):
-                    hs.update(open(os.path.join(ROOT, "univl_amd", "csrc", name), "rb").read())
-                pj = json.load(open(pmc))
-                if pj.get("kernel_source_sha16") == hs.hexdigest()[:16]:
-                    traffic_step = pj["gemm"]["hbm_read_bytes_per_step"] + pj["gemm"]["hbm_write_bytes_per_step"]
-                    traffic = traffic_step / fam["launches"]
-            except Exception:   # noqa: BLE001
-                traffic = traffic_step = None
+        traffic = traffic_step = traffic_file = None
+        if args.batch == 4 and args.kind == "joint":
+            import glob
+            import hashlib
+            hs = hashlib.sha256()
+            for name in ("gemm.hip", "common.h"):
+                hs.update(open(os.path.join(ROOT, "univl_amd", "csrc", name), "rb").read())
+            for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_pmc.json")), reverse=True):
+                try:
+                    pj = json.load(open(pmc))
+                    if pj.get("kernel_source_sha16") == hs.hexdigest()[:16]:
+                        traffic_step = pj["gemm"]["hbm_read_bytes_per_step"] + pj["gemm"]["hbm_write_bytes_per_step"]
+                        traffic = traffic_step / fam["launches"]
+                        traffic_file = os.path.relpath(pmc, ROOT)
+                        break
+                except Exception:   # noqa: BLE001
+                    continue
         step_bytes = int((8 + bpp) * n_params + 1.0e8)
         roofline = dict(
             kernel="gemm_kernel / gemm_pair_kernel / gemm_group_kernel family (univl_amd/csrc/gemm.hip): every dense contraction of one step",
@@ -518,7 +521,7 @@ def main():
             achieved=round(fam["algorithmic_bytes_per_step"] / fam_s / 1e9, 1) if hbm_frac >= mfma_frac
             else round(fam["flops_per_step"] / fam_s / 1e12, 1),
             peak=8000.0 if hbm_frac >= mfma_frac else 2500.0, unit="GB/s" if hbm_frac >= mfma_frac else "TFLOP/s",
-            frac=round(max(hbm_frac, mfma_frac), 4), traffic=traffic, traffic_per_step=traffic_step,
+            frac=round(max(hbm_frac, mfma_frac), 4), traffic=traffic, traffic_per_step=traffic_step, traffic_source=traffic_file,
             hbm=dict(achieved_gbs=round(fam["algorithmic_bytes_per_step"] / fam_s / 1e9, 1), frac=round(hbm_frac, 4)),
             mfma=dict(achieved_tflops=round(fam["flops_per_step"] / fam_s / 1e12, 2), frac=round(mfma_frac, 4)),
             launches_per_step=fam["launches"], gemms_per_step=fam["gemms"], family_ms_per_step=fam["family_ms_per_step"],

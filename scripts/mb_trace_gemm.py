@@ -135,6 +135,13 @@ def main():
         run("fwd O    N768 K768 ks%d ->f32" % ks(H), lambda i, st: (touch(x), st(), ops.gemm(x, Wo[i % len(Wo)], M, H, H, out32=y32, bias=biasH, ksplit=ks(H))), rot=24)
         run("fwd FFN1 N3072 K768 gelu", lambda i, st: (touch(x), st(), ops.gemm(x, W1[i % len(W1)], M, I, H, out16=fo, bias=biasI, aux=u, gelu="fwd")), rot=24)
         run("fwd FFN2 N768 K3072 ks%d ->f32" % ks(I), lambda i, st: (touch(f), st(), ops.gemm(f, W2[i % len(W2)], M, H, I, out32=y32, bias=biasH, ksplit=ks(I))), rot=24)
+        # the same forward products with a non-temporal hint on the weight operand's LDS-DMA (measurement build: UNIVL_GEMM_NT_B is read per call)
+        os.environ["UNIVL_GEMM_NT_B"] = "1"
+        run("fwd QKV  N2304 K768 ->bf16  [nt B]", lambda i, st: (touch(x), st(), ops.gemm(x, Wq[i % len(Wq)], M, 3 * H, H, out16=qkv, bias=bias3)), rot=min(R, 24))
+        run("fwd O    N768 K768 ks%d [nt B]" % ks(H), lambda i, st: (touch(x), st(), ops.gemm(x, Wo[i % len(Wo)], M, H, H, out32=y32, bias=biasH, ksplit=ks(H))), rot=24)
+        run("fwd FFN1 N3072 K768 gelu [nt B]", lambda i, st: (touch(x), st(), ops.gemm(x, W1[i % len(W1)], M, I, H, out16=fo, bias=biasI, aux=u, gelu="fwd")), rot=24)
+        run("fwd FFN2 N768 K3072 ks%d [nt B]" % ks(I), lambda i, st: (touch(f), st(), ops.gemm(f, W2[i % len(W2)], M, H, I, out32=y32, bias=biasH, ksplit=ks(I))), rot=24)
+        os.environ["UNIVL_GEMM_NT_B"] = "0"
         # backward: dgrad alone, and the pair launches of the step
         dxd = torch.randn(M, H, device=DEV).to(bf)
         du = torch.empty(M, I, device=DEV, dtype=bf)

@@ -115,13 +115,14 @@ template <typename T, bool TR, int ROWS, int BK, int NT = 256> struct Tile {
 #pragma unroll
         for (int c = 0; c < PER_THREAD; ++c) P[c] += step;
     }
-    // asynchronous fill of one LDS stage
+    // asynchronous fill of one LDS stage.  AUX = 2: non-temporal hint (measurement build only: UNIVL_GEMM_NT_B, scripts/mb_trace_gemm.py)
+    template <int AUX = 0>
     __device__ static __forceinline__ void issue(const T* const (&P)[PER_THREAD], unsigned char* stage, int tid) {
         unsigned char* wbase = stage + (tid & ~63) * 16;          // wave-uniform
 #pragma unroll
         for (int c = 0; c < PER_THREAD; ++c)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)P[c],
-                                             (__attribute__((address_space(3))) void*)(wbase + c * (NT * 16)), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(wbase + c * (NT * 16)), 16, 0, AUX);
     }
     // last, partial K tile (krem < BK contraction indices left; P + skip points at the tile start): through
     // registers, clamped addresses, zero fill of everything at or beyond krem
@@ -314,11 +315,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         TileA::load_tail(ta, pa, stepA * nfull, p.lda, krem, tid);
         TileB::load_tail(tb, pb, stepB * nfull, p.ldb, krem, tid);
     }
+#ifdef UNIVL_TRACE
+    const bool nt_b = (p.flags & UNIVL_GEMM_PROBE_NT_B) != 0;
+    auto issue_b = [&](unsigned char* st) { if (nt_b) TileB::template issue<2>(pb, st, tid); else TileB::template issue<0>(pb, st, tid); };
+#else
+    auto issue_b = [&](unsigned char* st) { TileB::issue(pb, st, tid); };
+#endif
     if (nfull > 0) {
         // double-buffered LDS-DMA pipeline: tile t+1 streams into the other stage while tile t is multiplied; the
         // __syncthreads() at the end of a step carries the vmcnt(0) that makes tile t+1 visible and releases stage t.
         TileA::issue(pa, sA, tid);
-        TileB::issue(pb, sB, tid);
+        issue_b(sB);
         TileA::advance(pa, stepA);
         TileB::advance(pb, stepB);
         __syncthreads();
@@ -327,7 +334,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
             const int cur = t & 1;
             if (t + 1 < nfull) {
                 TileA::issue(pa, sA + (cur ^ 1) * TileA::BYTES, tid);
-                TileB::issue(pb, sB + (cur ^ 1) * TileB::BYTES, tid);
+                issue_b(sB + (cur ^ 1) * TileB::BYTES);
                 TileA::advance(pa, stepA);
                 TileB::advance(pb, stepB);
             }
@@ -889,7 +896,7 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int 
     UNIVL_CHECK_ARG(aligned16(d->A) && aligned16(d->B) && d->lda % epc == 0 && d->ldb % epc == 0, UNIVL_EALIGN,
                     "univl_gemm: operands must be 16-byte aligned with leading dims a multiple of %d (lda=%ld ldb=%ld)",
                     epc, d->lda, d->ldb);
-    const int flags = d->flags & ~(UNIVL_GEMM_ATOMIC | UNIVL_GEMM_XCD_MAP | UNIVL_GEMM_PROBE_NOSTORE);     // internal bits are the library's
+    const int flags = d->flags & ~(UNIVL_GEMM_ATOMIC | UNIVL_GEMM_XCD_MAP | UNIVL_GEMM_PROBE_NOSTORE | UNIVL_GEMM_PROBE_NT_B);     // internal bits are the library's
     UNIVL_CHECK_ARG(!((flags & (UNIVL_GEMM_GELU_FWD | UNIVL_GEMM_GELU_BWD)) && !d->aux), UNIVL_EINVAL,
                     "univl_gemm: GELU epilogue needs aux");
     // tile choice: 128x128 once the grid fills the chip (>= 256 tiles, measured: +6 % at bs 128 over 384, same at bs 16), else
@@ -917,6 +924,7 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int 
 #ifdef UNIVL_TRACE
     static const bool probe = getenv("UNIVL_GEMM_PROBE") && atoi(getenv("UNIVL_GEMM_PROBE")) != 0;      // measurement build only
     if (probe) a.flags |= UNIVL_GEMM_PROBE_NOSTORE;
+    if (const char* e = getenv("UNIVL_GEMM_NT_B")) { if (atoi(e) != 0) a.flags |= UNIVL_GEMM_PROBE_NT_B; }   // read per call: A/B inside one process
 #endif
     a.ksplit_len = klen;
     a.sumsq = d->sumsq; a.sumsq_rows = d->sumsq_rows; a.sumsq_stride = d->sumsq_stride;

@@ -627,6 +627,9 @@ class EncoderStack:
         # UNIVL_PROBE_SKIP=<prefix> (measurement only, scripts/probe_branches.py): this stack emits NO layer kernels, forward or
         # backward -- what the step costs without one of its two encoder branches (results are meaningless)
         self.probe_skip = os.environ.get("UNIVL_PROBE_SKIP", "") == prefix
+        # UNIVL_PROBE_NO_LN=fwd|bwd|both (measurement only): the encoder layers' LayerNorm launches are left out of the plan -- the step
+        # time then bounds from above what ANY fusion of those nodes into their neighbours could save (results are meaningless)
+        self.probe_no_ln = os.environ.get("UNIVL_PROBE_NO_LN", "")
         # (Round 4, measured and removed: the video stack's first layer updated by a launch on the video stack's own stream instead of in
         # front of the whole forward -- 2.391 / 2.391 / 2.427 vs 2.392 / 2.396 / 2.397 ms per step, profiles/r04f_ab_update_slot.txt: the
         # prologue launches are HBM streams, two of them side by side each run at half speed.)
@@ -745,18 +748,19 @@ class EncoderStack:
                 key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev), sm)
             gemm(_gemm_desc(dt, ws["ctx"], H, fl.wop(nm["o_w"]), H, T, H, H, out32=ws["y1"], ldc=H,
                             bias=fl.w32(nm["o_b"]), ksplit=self.ksplit_for(H)))
-            plan.add("univl_layernorm_fwd", ops.layernorm_desc(
+            ln_fwd = (lambda d: None) if self.probe_no_ln in ("fwd", "both") else (lambda d: plan.add("univl_layernorm_fwd", d, sm))
+            ln_fwd(ops.layernorm_desc(
                 dt, T, H, x=ws["y1"], residual=x32, gamma=fl.w32(nm["ln1_g"]), beta=fl.w32(nm["ln1_b"]), y=ws["y1"],
                 stats=ws["st1"], out32=ws["a32"], out16=ws["a16"] if self.bf else None, p_pre=p, off_pre=ws["off"][1],
-                seed_dev=self.seed_dev), sm)
+                seed_dev=self.seed_dev))
             gemm(_gemm_desc(dt, ws["a16"], H, fl.wop(nm["w1"]), H, T, I, H, out16=ws["f"], ldc=I,
                             bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd"))
             gemm(_gemm_desc(dt, ws["f"], I, fl.wop(nm["w2"]), I, T, H, I, out32=ws["y2"], ldc=H,
                             bias=fl.w32(nm["b2"]), ksplit=self.ksplit_for(I)))
-            plan.add("univl_layernorm_fwd", ops.layernorm_desc(
+            ln_fwd(ops.layernorm_desc(
                 dt, T, H, x=ws["y2"], residual=ws["a32"], gamma=fl.w32(nm["ln2_g"]), beta=fl.w32(nm["ln2_b"]), y=ws["y2"],
                 stats=ws["st2"], out32=ws["o32"], out16=ws["o16"] if self.bf else None, p_pre=p, off_pre=ws["off"][2],
-                seed_dev=self.seed_dev), sm)
+                seed_dev=self.seed_dev))
             x32, x16 = ws["o32"], ws["o16"]
 
     # ----------------------------------------------------------------------------------------- backward
@@ -805,11 +809,12 @@ class EncoderStack:
             if sw is not None and l + 2 < self.L:
                 plan.join(sw + (l % 2), sm)             # layer l+2's weight gradients are done: this scratch set is free again
             dz, da = self.gbuf, self.garena[l, 0]
+            ln_bwd = (lambda d: None) if self.probe_no_ln in ("bwd", "both") else (lambda d: plan.add("univl_layernorm_bwd", d, sm))
             # output LayerNorm / dropout backward (BertOutput, module_bert.py:246-250)
-            plan.add("univl_layernorm_bwd", ops.layernorm_desc(
+            ln_bwd(ops.layernorm_desc(
                 dt, T, H, gamma=fl.w32(nm["ln2_g"]), y=ws["y2"], stats=ws["st2"], dout=gin, dx32=dz, dxd16=s_dxd,
                 dgamma=fl.g(nm["ln2_g"]), dbeta=fl.g(nm["ln2_b"]), dbias=fl.g(nm["b2"]), p_pre=p, off_pre=ws["off"][2],
-                seed_dev=self.seed_dev), sm)
+                seed_dev=self.seed_dev))
             wgrads, colsums = [], []         # colsums: the bias gradients a big-tile group does not carry (issued after the group)
 
             def emit(dgrad, wgrad):
@@ -844,10 +849,10 @@ class EncoderStack:
                             residual=dz, ldr=H, ksplit=self.ksplit_for(I)), w_ffn1)
             # attention-output LayerNorm / dropout backward (BertSelfOutput, module_bert.py:207-211)
             dy = self.gbuf
-            plan.add("univl_layernorm_bwd", ops.layernorm_desc(
+            ln_bwd(ops.layernorm_desc(
                 dt, T, H, gamma=fl.w32(nm["ln1_g"]), y=ws["y1"], stats=ws["st1"], dout=da, dx32=dy, dxd16=s_dxd2,
                 dgamma=fl.g(nm["ln1_g"]), dbeta=fl.g(nm["ln1_b"]), dbias=fl.g(nm["o_b"]), p_pre=p, off_pre=ws["off"][1],
-                seed_dev=self.seed_dev), sm)
+                seed_dev=self.seed_dev))
             w_o = _gemm_desc(dt, s_dxd2, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
                              out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"]), nt_out=self.nt_wgrad, **wg_tile, **gs.sumsq_args(nm["o_w"], H, H))
             emit(_gemm_desc(dt, s_dxd2, H, fl.wop(nm["o_w"]), H, T, H, H, trans_b=1, out16=self.dctx, ldc=H), w_o)
