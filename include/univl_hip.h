@@ -385,13 +385,6 @@ int univl_bert_adam_range(const UnivlAdam* d, int32_t chunk_begin, int32_t chunk
  * the chunk range as its own launch -- same result.  max_blocks > 0 caps the workgroups given to the update. */
 int univl_gemm_rider(const UnivlGemm* gemm, const UnivlAdam* adam, int32_t chunk_begin, int32_t chunk_count, int32_t max_blocks,
                      hipStream_t stream);
-/* Round 4: the same for the two light launches of an encoder layer -- the attention core and the LayerNorm forward (bf16; anything else:
- * the two launches one after the other).  Their own workgroups touch a few MB and leave most compute units and memory pipelines
- * idle, which is what the update's 30 B per parameter need; on the forward GEMMs the update competed with the LDS-DMA stream. */
-int univl_attention_fwd_rider(const UnivlAttention* desc, const UnivlAdam* adam, int32_t chunk_begin, int32_t chunk_count,
-                              int32_t max_blocks, hipStream_t stream);
-int univl_layernorm_fwd_rider(const UnivlLayerNorm* desc, const UnivlAdam* adam, int32_t chunk_begin, int32_t chunk_count,
-                              int32_t max_blocks, hipStream_t stream);
 /* Large-LDS opt-in of the rider kernels on the stream's device; call once outside any stream capture before the first captured rider. */
 int univl_gemm_rider_prime(hipStream_t stream);
 /* *ctr += 1 (device word; used for per-replay dropout seeds) */

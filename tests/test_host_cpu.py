@@ -234,9 +234,7 @@ def test_adam_rider_plan_builds_on_cpu(monkeypatch):
     ride = build_step(m, "joint", 2, 16, 16, True)
     names0 = [op[3] for op in base.fwd.ops]
     names1 = [op[3] for op in ride.fwd.ops]
-    assert [n[:-6] if n.endswith("_rider") else n for n in names1] == names0
-    # round 4: the carriers are the layer's light launches -- attention core, attention-output product, the two LayerNorms
-    assert sorted({n for n in names1 if n.endswith("_rider")}) == ["univl_attention_fwd_rider", "univl_gemm_rider", "univl_layernorm_fwd_rider"]
+    assert [n.replace("univl_gemm_rider", "univl_gemm") for n in names1] == names0
     riders = [op[2] for op in ride.fwd.ops if op[0] == "rider"]
     L_t, L_v = cfg.text_num_hidden_layers, cfg.visual_num_hidden_layers
     assert len(riders) == 4 * ((L_t - 1) + (L_v - 1))

@@ -16,7 +16,6 @@
 // The backward recomputes P from the saved row log-sum-exp (module: nothing but lse is kept from the forward).
 #include "common.h"
 #include "univl_hip.h"
-#include "adam_body.h"
 
 namespace {
 
@@ -115,24 +114,22 @@ __device__ __forceinline__ void store4(T* p, const f32x4_t& v, float s) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];       // the ONE dynamic LDS object of this file's kernels
-
 template <typename T, int MAXKT>
-__device__ __forceinline__ void attn_fwd_body(const UnivlAttention& p, const int Sk_pad, const float scale, const int bh, const int qblock) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(UnivlAttention p, int Sk_pad, float scale) {
     using C = AttnCfg<T>;
     using M = Mma<T>;
-    unsigned char* smem_raw = attn_smem;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* sK = reinterpret_cast<T*>(smem_raw);
     T* sV = sK + Sk_pad * C::P;
     float* sM = reinterpret_cast<float*>(sV + Sk_pad * C::P);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
-    const int b = bh / p.H, h = bh % p.H;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
     const T* Kg = reinterpret_cast<const T*>(p.k) + (long)b * (p.bsk ? p.bsk : (long)p.Sk * p.ldk) + h * HD;
     const T* Vg = reinterpret_cast<const T*>(p.v) + (long)b * (p.bsv ? p.bsv : (long)p.Sk * p.ldv) + h * HD;
     // per-wave operands straight from global memory are requested BEFORE the K/V staging round trip (clamped rows:
     // lanes / waves beyond Sq read a valid row and never store), so the kernel pays one global latency, not two
-    const int q0 = qblock * 64 + wave * 16;
+    const int q0 = blockIdx.y * 64 + wave * 16;
     const int q = q0 + i;
     const bool qv = q < p.Sq;
     const int qc = min(q, p.Sq - 1);
@@ -218,32 +215,13 @@ __device__ __forceinline__ void attn_fwd_body(const UnivlAttention& p, const int
     }
 }
 
-template <typename T, int MAXKT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(UnivlAttention p, int Sk_pad, float scale) {
-    attn_fwd_body<T, MAXKT>(p, Sk_pad, scale, blockIdx.x, blockIdx.y);
-}
-
-// Carrier form (round 4; univl_attention_fwd_rider): a one-dimensional grid -- the attention workgroups first ((row, head) fastest, then
-// the query block), behind them workgroups that apply BertAdam chunks [c0, c1) of a prepared update.  The attention core of a layer
-// moves 18 KB per workgroup on 48 .. 192 workgroups: most compute units and nearly all of the memory pipeline are idle during it.
-template <typename T, int MAXKT, bool NT>
-__global__ __launch_bounds__(256) void attn_fwd_adam_kernel(UnivlAttention p, int Sk_pad, float scale, int n_bh, int n_own, UnivlAdam a, int c0, int c1) {
-    const int w = blockIdx.x;
-    if (w < n_own) {
-        attn_fwd_body<T, MAXKT>(p, Sk_pad, scale, w % n_bh, w / n_bh);
-        return;
-    }
-    const int nb = (int)gridDim.x - n_own;
-    for (int c = c0 + (w - n_own); c < c1; c += nb) adam_chunk<NT, 256>(a, c);
-}
-
 // ------------------------------------------------------------------------------------------------ backward
 // role A (blockIdx.y < nqb): dQ for a block of 64 queries.   role B: dK, dV for a block of 64 keys.
 template <typename T, int TRIPS>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_pad, int Sq_pad, int nqb, float scale) {
     using C = AttnCfg<T>;
     using M = Mma<T>;
-    unsigned char* smem_raw = attn_smem;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
     const uint64_t seed = seed_fetch(p);
@@ -473,33 +451,6 @@ int dispatch_fwd(const UnivlAttention* d, hipStream_t stream) {
     return launch_fwd<T, 24>(d, Sk_pad, stream);
 }
 
-template <int MAXKT>
-int launch_fwd_rider(const UnivlAttention* d, int Sk_pad, const UnivlAdam* adam, int c0, int n, int nb, bool prime_only, hipStream_t stream) {
-    const size_t smem = (size_t)2 * Sk_pad * AttnCfg<__bf16>::P * sizeof(__bf16) + Sk_pad * sizeof(float);
-    static bool done_nt[UNIVL_MAX_DEVICES] = {}, done_t[UNIVL_MAX_DEVICES] = {};
-    univl_allow_lds(attn_fwd_adam_kernel<__bf16, MAXKT, true>, 160 * 1024, done_nt);
-    univl_allow_lds(attn_fwd_adam_kernel<__bf16, MAXKT, false>, 160 * 1024, done_t);
-    if (prime_only) return UNIVL_OK;
-    const int n_bh = d->B * d->H, n_own = n_bh * ((d->Sq + 63) / 64);
-    if (univl_adam_nt())
-        hipLaunchKernelGGL((attn_fwd_adam_kernel<__bf16, MAXKT, true>), dim3(n_own + nb), dim3(256), smem, stream, *d, Sk_pad, 0.125f, n_bh, n_own,
-                           *adam, c0, c0 + n);
-    else
-        hipLaunchKernelGGL((attn_fwd_adam_kernel<__bf16, MAXKT, false>), dim3(n_own + nb), dim3(256), smem, stream, *d, Sk_pad, 0.125f, n_bh, n_own,
-                           *adam, c0, c0 + n);
-    UNIVL_LAUNCH_CHECK();
-    return UNIVL_OK;
-}
-
-int dispatch_fwd_rider(const UnivlAttention* d, int Sk, const UnivlAdam* adam, int c0, int n, int nb, bool prime_only, hipStream_t stream) {
-    const int Sk_pad = (Sk + 31) / 32 * 32;
-    const int nkt = Sk_pad / 16;
-    if (nkt <= 4) return launch_fwd_rider<4>(d, Sk_pad, adam, c0, n, nb, prime_only, stream);
-    if (nkt <= 8) return launch_fwd_rider<8>(d, Sk_pad, adam, c0, n, nb, prime_only, stream);
-    if (nkt <= 16) return launch_fwd_rider<16>(d, Sk_pad, adam, c0, n, nb, prime_only, stream);
-    return launch_fwd_rider<24>(d, Sk_pad, adam, c0, n, nb, prime_only, stream);
-}
-
 template <typename T>
 int dispatch_bwd(const UnivlAttention* d, hipStream_t stream) {
     const int CH = Mma<T>::CH;
@@ -532,32 +483,6 @@ extern "C" int univl_attention_fwd(const UnivlAttention* d, hipStream_t stream) 
     int rc = check(d, "univl_attention_fwd", false);
     if (rc) return rc;
     return d->dtype == UNIVL_DT_BF16 ? dispatch_fwd<__bf16>(d, stream) : dispatch_fwd<float>(d, stream);
-}
-
-extern "C" int univl_attention_fwd_rider(const UnivlAttention* d, const UnivlAdam* adam, int32_t chunk_begin, int32_t chunk_count,
-                                        int32_t max_blocks, hipStream_t stream) {
-    UNIVL_CHECK_ARG(d != nullptr && adam != nullptr, UNIVL_EINVAL, "univl_attention_fwd_rider: null descriptor");
-    UNIVL_CHECK_ARG(adam->p && adam->g && adam->m && adam->v && adam->segs && adam->chunk_seg && adam->chunk_off && adam->chunk_len &&
-                        adam->seg_scalars && adam->nchunk > 0 && chunk_begin >= 0 && chunk_count >= 0 &&
-                        chunk_begin + chunk_count <= adam->nchunk,
-                    UNIVL_EINVAL, "univl_attention_fwd_rider: chunks [%d, +%d) of %d", chunk_begin, chunk_count, adam->nchunk);
-    if (d->dtype != UNIVL_DT_BF16 || chunk_count == 0) {      // the two launches one after the other (same result)
-        const int r1 = univl_attention_fwd(d, stream);
-        if (r1 != UNIVL_OK || chunk_count == 0) return r1;
-        return univl_bert_adam_range(adam, chunk_begin, chunk_count, 0, max_blocks, stream);
-    }
-    UNIVL_ON_STREAM_DEVICE(stream);
-    int rc = check(d, "univl_attention_fwd_rider", false);
-    if (rc) return rc;
-    const int nb = (max_blocks > 0 && max_blocks < chunk_count) ? max_blocks : chunk_count;
-    return dispatch_fwd_rider(d, d->Sk, adam, chunk_begin, chunk_count, nb, false, stream);
-}
-
-// large-LDS opt-in of the carrier kernels for keys up to `max_sk`, outside any stream capture (univl_gemm_rider_prime calls it)
-int univl_attention_rider_prime(int max_sk, hipStream_t stream) {
-    UNIVL_ON_STREAM_DEVICE(stream);
-    for (int sk = 32; sk <= max_sk; sk *= 2) dispatch_fwd_rider(nullptr, sk, nullptr, 0, 0, 0, true, stream);
-    return UNIVL_OK;
 }
 
 extern "C" int univl_attention_bwd(const UnivlAttention* d, hipStream_t stream) {

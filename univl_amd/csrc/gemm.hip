@@ -1096,12 +1096,10 @@ extern "C" int univl_gemm_rider(const UnivlGemm* gemm, const UnivlAdam* adam, in
 
 // The rider kernels' large-LDS opt-in, outside any stream capture: their first launch happens INSIDE the capture of the pipelined
 // training step (the eager iteration before it has no pending update to carry).
-int univl_attention_rider_prime(int max_sk, hipStream_t stream);      // attention.hip
-
 extern "C" int univl_gemm_rider_prime(hipStream_t stream) {
     UNIVL_ON_STREAM_DEVICE(stream);
     rider_allow_lds();
-    return univl_attention_rider_prime(384, stream);
+    return UNIVL_OK;
 }
 
 extern "C" int univl_gemm_group(const UnivlGemm* d, int n, hipStream_t stream) {

@@ -6,15 +6,14 @@
 #include <stdlib.h>
 #include "common.h"
 #include "univl_hip.h"
-#include "adam_body.h"
 
 namespace {
 
 template <int N, typename TO, bool F64>
-__device__ __forceinline__ void ln_fwd_body(const UnivlLayerNorm& p, const int block) {
+__global__ __launch_bounds__(256) void ln_fwd_kernel(UnivlLayerNorm p) {
     constexpr int NV = N / 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = block * 4 + wave;
+    const int row = blockIdx.x * 4 + wave;
     if (row >= p.rows) return;
     float v[NV][4];
     // Every global operand of the row (seed, x, residual, position row, gamma, beta) is requested up front, from
@@ -106,24 +105,6 @@ __device__ __forceinline__ void ln_fwd_body(const UnivlLayerNorm& p, const int b
             }
         }
     }
-}
-
-template <int N, typename TO, bool F64>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(UnivlLayerNorm p) { ln_fwd_body<N, TO, F64>(p, blockIdx.x); }
-
-// Carrier form (round 4; univl_layernorm_fwd_rider): the LayerNorm's own workgroups take the first ids, the rest of the grid applies
-// BertAdam chunks [c0, c1) of a prepared update (adam_body.h, the arithmetic of optim.hip's adam_apply_kernel).  A LayerNorm launch
-// touches 2 MB on 48 .. 192 workgroups and ends in ~2 us of kernel time: the compute units and their memory pipelines are idle, which
-// is exactly what the update's 30 B per parameter need -- riding on the forward GEMMs it competed with their LDS-DMA stream for the
-// SAME per-CU memory pipeline.
-template <int N, typename TO, bool NT>
-__global__ __launch_bounds__(256) void ln_fwd_adam_kernel(UnivlLayerNorm p, int n_own, UnivlAdam a, int c0, int c1) {
-    if ((int)blockIdx.x < n_own) {
-        ln_fwd_body<N, TO, false>(p, blockIdx.x);
-        return;
-    }
-    const int nb = (int)gridDim.x - n_own;
-    for (int c = c0 + ((int)blockIdx.x - n_own); c < c1; c += nb) adam_chunk<NT, 256>(a, c);
 }
 
 // Backward.  Each wave walks RPW rows, keeps per-column partial sums of dgamma / dbeta / dbias in registers, the
@@ -314,38 +295,6 @@ extern "C" int univl_layernorm_fwd(const UnivlLayerNorm* d, hipStream_t stream) 
         else          { if (bf) LN_FWD(1024, __bf16, false); else LN_FWD(1024, float, false); }
     }
 #undef LN_FWD
-    UNIVL_LAUNCH_CHECK();
-    return UNIVL_OK;
-}
-
-extern "C" int univl_layernorm_fwd_rider(const UnivlLayerNorm* d, const UnivlAdam* adam, int32_t chunk_begin, int32_t chunk_count,
-                                         int32_t max_blocks, hipStream_t stream) {
-    UNIVL_CHECK_ARG(d != nullptr && adam != nullptr, UNIVL_EINVAL, "univl_layernorm_fwd_rider: null descriptor");
-    UNIVL_CHECK_ARG(adam->p && adam->g && adam->m && adam->v && adam->segs && adam->chunk_seg && adam->chunk_off && adam->chunk_len &&
-                        adam->seg_scalars && adam->nchunk > 0 && chunk_begin >= 0 && chunk_count >= 0 &&
-                        chunk_begin + chunk_count <= adam->nchunk,
-                    UNIVL_EINVAL, "univl_layernorm_fwd_rider: chunks [%d, +%d) of %d", chunk_begin, chunk_count, adam->nchunk);
-    const bool fits = d->dtype == UNIVL_DT_BF16 && d->N == 768 && !d->x_f64 && chunk_count > 0;
-    if (!fits) {                               // the two launches one after the other (same result)
-        const int r1 = univl_layernorm_fwd(d, stream);
-        if (r1 != UNIVL_OK || chunk_count == 0) return r1;
-        return univl_bert_adam_range(adam, chunk_begin, chunk_count, 0, max_blocks, stream);
-    }
-    UNIVL_ON_STREAM_DEVICE(stream);
-    int rc = check_common(d, "univl_layernorm_fwd_rider");
-    if (rc) return rc;
-    UNIVL_CHECK_ARG(d->x && d->beta && (d->out32 || d->out16), UNIVL_EINVAL, "univl_layernorm_fwd_rider: null x/beta/out");
-    UNIVL_CHECK_ARG(aligned16(d->x) && aligned16(d->out32) && aligned16(d->out16) && aligned16(d->y) &&
-                        aligned16(d->residual) && aligned16(d->pos) && aligned16(d->gamma) && aligned16(d->beta),
-                    UNIVL_EALIGN, "univl_layernorm_fwd_rider: pointers must be 16-byte aligned");
-    const int n_own = (d->rows + 3) / 4;
-    const int nb = (max_blocks > 0 && max_blocks < chunk_count) ? max_blocks : chunk_count;
-    if (univl_adam_nt())
-        hipLaunchKernelGGL((ln_fwd_adam_kernel<768, __bf16, true>), dim3(n_own + nb), dim3(256), 0, stream, *d, n_own, *adam, chunk_begin,
-                           chunk_begin + chunk_count);
-    else
-        hipLaunchKernelGGL((ln_fwd_adam_kernel<768, __bf16, false>), dim3(n_own + nb), dim3(256), 0, stream, *d, n_own, *adam, chunk_begin,
-                           chunk_begin + chunk_count);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }

@@ -303,15 +303,10 @@ class Plan:
     def add_gemm_rider(self, desc, key, slot, nslots, stream=0):
         """A forward product that, while self.riders names a chunk range for `key`, also carries
         the slot-th of nslots parts of that range of a prepared BertAdam update (univl_gemm_rider); otherwise a plain univl_gemm."""
-        self.add_rider("univl_gemm", desc, key, slot, nslots, stream)
-
-    def add_rider(self, fn_name, desc, key, slot, nslots, stream=0):
-        """The carrier form of any launch that has one (<fn_name>_rider: univl_gemm, univl_attention_fwd, univl_layernorm_fwd)."""
-        L = _lib.lib()
         self.keep.append(desc)
         self.descs[len(self.ops)] = [desc]
         self.rider_keys.add(key)
-        self.ops.append(("rider", getattr(L, fn_name + "_rider"), (desc, key, int(slot), int(nslots), getattr(L, fn_name)), fn_name + "_rider", stream))
+        self.ops.append(("rider", _lib.lib().univl_gemm_rider, (desc, key, int(slot), int(nslots)), "univl_gemm_rider", stream))
 
     def add(self, fn_name, desc, stream=0):
         fn = getattr(_lib.lib(), fn_name)
@@ -424,13 +419,13 @@ class Plan:
                 h = handles.get(sidx)
                 if h is None:
                     h = handles[sidx] = C.c_void_p(self._stream(sidx, cur).cuda_stream)
-                desc, key, slot, nslots, plain = b
+                desc, key, slot, nslots = b
                 rd = self.riders
                 rng = rd["ranges"].get(key) if rd else None
                 if rng is not None and (key, slot) in rd["used"]:
                     rng = None               # a stack that runs twice in one forward (pretrain: clean and masked pass) carries once
                 if rng is None:
-                    rc = plain(C.byref(desc), h)
+                    rc = _lib.lib().univl_gemm(C.byref(desc), h)
                 else:
                     rd["used"].add((key, slot))
                     lo, hi = rng[0] + rng[1] * slot // nslots, rng[0] + rng[1] * (slot + 1) // nslots
@@ -536,7 +531,7 @@ class Plan:
             elif kind == "group" and name.startswith(prefix):
                 out.append((lambda h, fn=fn, arg=arg: fn(arg[0], arg[1], arg[2], h), self.descs[i]))
             elif kind == "rider" and name.startswith(prefix):
-                out.append((lambda h, d=arg[0], plain=arg[4]: plain(C.byref(d), h), self.descs[i]))
+                out.append((lambda h, d=arg[0]: _lib.lib().univl_gemm(C.byref(d), h), self.descs[i]))
             elif kind == "pair" and name.startswith(prefix):
                 out.append((lambda h, fn=fn, arg=arg: fn(C.byref(arg[0]), C.byref(arg[1]), 0, h), self.descs[i]))
         return out
@@ -631,7 +626,6 @@ class EncoderStack:
                           and flat.compute_dtype == torch.bfloat16 and prefix in ("bert", "visual", "cross"))
         # UNIVL_PROBE_SKIP=<prefix> (measurement only, scripts/probe_branches.py): this stack emits NO layer kernels, forward or
         # backward -- what the step costs without one of its two encoder branches (results are meaningless)
-        self.ride_on = os.environ.get("UNIVL_RIDE_ON", "light")      # "gemm": round 3's carriers (the four forward products), A/B
         self.probe_skip = os.environ.get("UNIVL_PROBE_SKIP", "") == prefix
         # UNIVL_PROBE_NO_LN=fwd|bwd|both (measurement only): the encoder layers' LayerNorm launches are left out of the plan -- the step
         # time then bounds from above what ANY fusion of those nodes into their neighbours could save (results are meaningless)
@@ -734,48 +728,31 @@ class EncoderStack:
             plan.wait_point(("layer", self.prefix, l), sm)
             slot = [0]
 
-            carry = self.adam_ride and l + 1 < self.L
-            nxt = ("layer", self.prefix, l + 1)
-
             def gemm(desc, _l=l, _slot=slot):
-                """a forward product of layer l; with self.adam_ride and UNIVL_RIDE_ON=gemm (round 3's assignment) it carries a quarter
-                of layer l + 1's optimizer chunks.
+                """a forward product of layer l; with self.adam_ride it can carry a quarter of layer l + 1's optimizer chunks.
                 (Round 4, measured and removed: riders ONE LAUNCH ahead instead of one layer ahead -- product k of layer l carrying
                 quarter k + 1 of its own layer, so that only the first quarter of a stack's first layer is left to the launches in
                 front of the forward: bit-identical, 2.405 / 2.436 / 2.406 vs 2.422 / 2.374 / 2.408 ms per step at 4 pairs,
                 profiles/r04h_ab_ride_ahead.txt -- the bytes cost the same wherever they ride.)"""
-                if carry and self.ride_on == "gemm":
-                    plan.add_gemm_rider(desc, nxt, _slot[0], 4, sm)
+                if self.adam_ride and _l + 1 < self.L:
+                    plan.add_gemm_rider(desc, ("layer", self.prefix, _l + 1), _slot[0], 4, sm)
                     _slot[0] += 1
                 else:
                     plan.add("univl_gemm", desc, sm)
 
-            def light(fn_name, desc, quarter):
-                """Round 4 (UNIVL_RIDE_ON=light, default): the quarters of layer l + 1's update ride on the layer's LIGHT launches -- the
-                attention core, the attention-output product (the smallest GEMM: 72 .. 144 workgroups) and the two LayerNorms -- whose
-                own workgroups leave the compute units' memory pipelines idle; the three large products run alone."""
-                if carry and self.ride_on == "light":
-                    plan.add_rider(fn_name, desc, nxt, quarter, 4, sm)
-                else:
-                    plan.add(fn_name, desc, sm)
-
             wqkv, bqkv = fl.wop_fused(nm["qkv_w"]), fl.w32_fused(nm["qkv_b"])
             gemm(_gemm_desc(dt, x16, H, wqkv, H, T, 3 * H, H, out16=ws["qkv"], ldc=3 * H, bias=bqkv))
             qkv = ws["qkv"]
-            light("univl_attention_fwd", ops.attention_desc(
+            plan.add("univl_attention_fwd", ops.attention_desc(
                 dt, B, self.NH, S, S, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx"], H, ws["lse"],
-                key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev), 0)
-            d_o = _gemm_desc(dt, ws["ctx"], H, fl.wop(nm["o_w"]), H, T, H, H, out32=ws["y1"], ldc=H,
-                             bias=fl.w32(nm["o_b"]), ksplit=self.ksplit_for(H))
-            if self.ride_on == "light":
-                light("univl_gemm", d_o, 1)
-            else:
-                gemm(d_o)
-            ln_fwd = (lambda d, q: None) if self.probe_no_ln in ("fwd", "both") else (lambda d, q: light("univl_layernorm_fwd", d, q))
+                key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev), sm)
+            gemm(_gemm_desc(dt, ws["ctx"], H, fl.wop(nm["o_w"]), H, T, H, H, out32=ws["y1"], ldc=H,
+                            bias=fl.w32(nm["o_b"]), ksplit=self.ksplit_for(H)))
+            ln_fwd = (lambda d: None) if self.probe_no_ln in ("fwd", "both") else (lambda d: plan.add("univl_layernorm_fwd", d, sm))
             ln_fwd(ops.layernorm_desc(
                 dt, T, H, x=ws["y1"], residual=x32, gamma=fl.w32(nm["ln1_g"]), beta=fl.w32(nm["ln1_b"]), y=ws["y1"],
                 stats=ws["st1"], out32=ws["a32"], out16=ws["a16"] if self.bf else None, p_pre=p, off_pre=ws["off"][1],
-                seed_dev=self.seed_dev), 2)
+                seed_dev=self.seed_dev))
             gemm(_gemm_desc(dt, ws["a16"], H, fl.wop(nm["w1"]), H, T, I, H, out16=ws["f"], ldc=I,
                             bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd"))
             gemm(_gemm_desc(dt, ws["f"], I, fl.wop(nm["w2"]), I, T, H, I, out32=ws["y2"], ldc=H,
@@ -783,7 +760,7 @@ class EncoderStack:
             ln_fwd(ops.layernorm_desc(
                 dt, T, H, x=ws["y2"], residual=ws["a32"], gamma=fl.w32(nm["ln2_g"]), beta=fl.w32(nm["ln2_b"]), y=ws["y2"],
                 stats=ws["st2"], out32=ws["o32"], out16=ws["o16"] if self.bf else None, p_pre=p, off_pre=ws["off"][2],
-                seed_dev=self.seed_dev), 3)
+                seed_dev=self.seed_dev))
             x32, x16 = ws["o32"], ws["o16"]
 
     # ----------------------------------------------------------------------------------------- backward
