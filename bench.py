@@ -62,6 +62,9 @@ def get_args():
                          "segmented hipGraphs) with real world-size-1 collectives")
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="N > 1: reduce-scatter + sharded clip / BertAdam + all-gather of the bf16 shadow instead of all-reduce")
+    ap.add_argument("--grad-exchange", default=None, choices=["fp32", "bf16"],
+                    help="N > 1: dtype the gradient buckets cross the wire in (default: UNIVL_GRAD_EXCHANGE or fp32, the reference's DDP "
+                         "semantics; bf16 halves the bytes -- every exchanged element rounded to 8 mantissa bits, gated in tests/test_ddp_gpu.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / PCIe-inclusive side measurements")
     ap.add_argument("--no-others", action="store_true",
@@ -311,6 +314,8 @@ def main():
     tc = task_config(args, world)
     model = UniVL.from_pretrained("bert-base-uncased", "visual-base", "cross-base", "decoder-base", task_config=tc)
     model.to(dev).train()
+    if args.grad_exchange:
+        os.environ["UNIVL_GRAD_EXCHANGE"] = args.grad_exchange
     if world > 1 or args.force_dp:
         model.enable_data_parallel(force=args.force_dp, shard_optimizer=args.shard_optimizer)
     elif args.loopback:
@@ -550,7 +555,8 @@ def main():
             red = model._reducer
             exchange = dict(points=len(pts), dense_mb=round(sum(e - s for c in pts for s, e in c) * 4 / 2 ** 20, 1),
                             sparse_word_embedding=getattr(stp[0], "sparse_exchange", None),
-                            backend="loopback" if red.loopback else "rccl",
+                            backend="loopback" if red.loopback else "rccl", wire_dtype="bf16" if red.bf16 else "fp32",
+                            graphs_per_iteration=(2 if (gstep is not None and gstep._g_rest is not None) else 1) if gstep is not None and gstep.mode == "whole" else None,
                             captured_in_step_graph=bool(red.capturable and gstep is not None and gstep.mode == "whole"))
             if red.capturable:
                 # Where the step's time goes once gradients cross xGMI: a few EAGER iterations (events cannot be timed inside a
