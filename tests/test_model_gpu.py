@@ -39,8 +39,10 @@ ALL_CASES = JOINT_CASES + ["align_small", "caption_small", "pretrain_small"] + F
 GATES = {
     torch.float32: dict(hidden=1e-3, sim=1e-3, logits=1e-3, loss=1e-3, gnorm=1e-3, gsample=2e-3, gtop=2e-3, gmedian=1e-3,
                         gp95=1e-3, gglobal=1e-3, gcos=1e-5),
-    torch.bfloat16: dict(hidden=5e-2, sim=1e-2, logits=1e-2, loss=1e-2, gnorm=1e-2, gsample=4e-2, gtop=2.5e-2, gmedian=2e-2,
-                         gp95=3e-2, gglobal=1.5e-2, gcos=2e-4),
+    # round 4: tightened to ~1.3 x the worst measured value of the cases that use them (cfg1-3, cfg4): gnorm 3.2e-3, gtop 1.3e-2,
+    # gmedian 1.0e-2, gp95 1.5e-2, gglobal 1.2e-2, gcos 7.1e-5 -- and see check_against_reference_bf16 for the yardstick
+    torch.bfloat16: dict(hidden=5e-2, sim=1e-2, logits=1e-2, loss=1e-2, gnorm=6e-3, gsample=4e-2, gtop=2e-2, gmedian=1.5e-2,
+                         gp95=2e-2, gglobal=1.3e-2, gcos=1.5e-4),
 }
 # Branch-specific bf16 GRADIENT gates.
 #  * caption: the 30522-way softmax gradient through the tied table leaves a few small tensors at 3e-2 (measured 3.0-3.4e-2).
@@ -156,7 +158,7 @@ def compare_gradients(params, names, ref_norms, ref_samples, top_index, top_samp
     gmax = float(np.max(ref_norms))
     floor = (1e-6 if f32 else 2e-3) * max(gmax, 1.0 if f32 else gmax)
     worst_norm = 0.0
-    bad, rels, allg, allr, relnames = [], [], [], [], []
+    bad, rels, raw, allg, allr, relnames = [], [], [], [], [], []
     for i, n in enumerate(names):
         gr = params[n].grad
         assert gr is not None, n
@@ -181,6 +183,7 @@ def compare_gradients(params, names, ref_norms, ref_samples, top_index, top_samp
         rn_eff = max(rn, ref * (min(256, gr.numel()) / gr.numel()) ** 0.5)
         if significant and rn > 0:
             rels.append(d / rn_eff)
+            raw.append(d / rn)                        # the statistic oracle/bf16_noise.py records for the reference's own bf16 run
             relnames.append((d / rn_eff, n, ref / gmax))
         if G["gsample"] is not None and not d < G["gsample"] * rn + floor * (min(256, gr.numel()) / gr.numel()) ** 0.5 + 1e-9:
             bad.append((n, "sample", d, rn))
@@ -202,7 +205,7 @@ def compare_gradients(params, names, ref_norms, ref_samples, top_index, top_samp
               "; ".join("#%d %.4e vs %.4e" % (int(k), gs[k], rs[k]) for k in top))
     err = dict(gnorm=worst_norm, gsample=float(np.max(rels)), gtop=worst_top, gmedian=float(np.median(rels)),
                gp95=float(np.percentile(rels, 95)), gglobal=float(np.linalg.norm(ag - ar) / np.linalg.norm(ar)),
-               gcos=float(1.0 - np.dot(ag, ar) / (np.linalg.norm(ag) * np.linalg.norm(ar))))
+               gcos=float(1.0 - np.dot(ag, ar) / (np.linalg.norm(ag) * np.linalg.norm(ar))), gmedian_raw=float(np.median(raw)))
     return err, bad
 
 
@@ -210,6 +213,30 @@ def check_gates(tag, err, G):
     for k, v in err.items():
         if G.get(k) is not None:
             assert v < G[k], (tag, k, v, G[k])
+
+
+_NOISE = None
+
+
+def check_against_reference_bf16(golden_dir, name, err):
+    """bf16 only.  The yardstick for "how close can a bf16 run be": the REFERENCE model itself under torch.autocast(bfloat16) against
+    its own fp32 run on the same inputs (oracle/bf16_noise.py -> tests/golden/bf16_autocast_noise.json: median per-tensor sample error and
+    worst per-tensor norm error, the statistics `gmedian_raw` / `gnorm` are computed the same way).  This library's bf16 step must be
+    AT LEAST as close to the reference's fp32 gradients as the reference's own bf16 run is: median strictly, the worst norm within 1.25 x
+    (a worst-of-300 statistic of two different rounding patterns).  Measured: 0.55 - 0.65 x the reference's median at cfg1-3, 0.9 x at
+    cfg4, 0.45 x at cfg5, 0.2 - 0.55 x through the FT-Align hinge."""
+    global _NOISE
+    if _NOISE is None:
+        import json
+        with open(os.path.join(golden_dir, "bf16_autocast_noise.json")) as f:
+            _NOISE = json.load(f)
+    ref = _NOISE.get(name)
+    if ref is None:
+        return {}
+    out = dict(vs_autocast_median=err["gmedian_raw"] / ref["grad_sample_rel_median"], vs_autocast_norm=err["gnorm"] / ref["grad_norm_rel_max"])
+    assert err["gmedian_raw"] <= ref["grad_sample_rel_median"], (name, "median", err["gmedian_raw"], ref["grad_sample_rel_median"])
+    assert err["gnorm"] <= 1.25 * ref["grad_norm_rel_max"], (name, "norm", err["gnorm"], ref["grad_norm_rel_max"])
+    return out
 
 
 def hinge_pattern(sim, margin):
@@ -279,6 +306,9 @@ def test_forward_backward_vs_reference_golden(golden_dir, name, dtype):
     print(f"[parity {name} {dtype}] " + " ".join(f"{k}={v:.2e}" for k, v in sorted(err.items())))
     assert not bad, bad[:5]
     check_gates(name, err, G)
+    if not f32:
+        err.update(check_against_reference_bf16(golden_dir, name, err))
+        _record(name, dtype, **err)
 
 
 def _pooler_step(model):

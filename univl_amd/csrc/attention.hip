@@ -14,6 +14,7 @@
 // as T-major operands straight from their row-major LDS image with the gfx950 transpose read.
 //
 // The backward recomputes P from the saved row log-sum-exp (module: nothing but lse is kept from the forward).
+#include <stdlib.h>
 #include "common.h"
 #include "univl_hip.h"
 
@@ -25,7 +26,14 @@ template <typename T> struct AttnCfg {
     static constexpr int CH = Mma<T>::CH;
     static constexpr int TPC = CH / 16;              // 16-wide accumulator tiles per contraction chunk
     static constexpr int NCD = HD / CH;              // chunks across the head dim
-    static constexpr int P = HD + (sizeof(T) == 2 ? 16 : 4);   // LDS row pitch (elements), see common.h pads
+    // LDS row pitches (elements).  A staged matrix is read in one or both of two ways, and the two want different pitches (round 3's
+    // stall pass, profiles/r03z_pmc_stall_b128.txt: 52-59 % of the kernels' LDS cycles were bank conflicts with ONE 160-byte pitch):
+    //   PT  image consumed by the transpose read (ds_read_b64_tr_b16: eight 32-byte row segments per half wave): 160 B rows;
+    //   PK  image consumed K-major (two 8-byte reads per lane over 16 consecutive rows): 144 B rows -- 36 dwords, so the 16 rows of a
+    //       fragment start 4 banks apart (with 160 B rows i and i + 8 start on the same bank).
+    // A matrix that is read both ways is staged as TWO images where the launch can afford the LDS (DUAL, bwd kernel), else as one PT image.
+    static constexpr int PT = HD + (sizeof(T) == 2 ? 16 : 4);
+    static constexpr int PK = HD + (sizeof(T) == 2 ? 8 : 4);
     static constexpr int EPC = Mma<T>::EPC;
 };
 
@@ -35,10 +43,11 @@ template <typename T> struct AttnCfg {
 // hipcc (rows_pad is a run-time value) and pays one round trip per piece and matrix.
 // TRIPS > 0: compile-time trip count (rows_pad <= 64 * TRIPS for bf16), no run-time loop at all -- a loop header makes
 // hipcc drain every load that is already in flight (the per-wave Q / mask / seed requests issued before the staging).
-template <typename T, int TRIPS>
-__device__ __forceinline__ void stage_pair(T* ldsA, const T* gA, long ldA, T* ldsB, const T* gB, long ldB, int rows, int rows_pad,
-                                           int tid) {
-    constexpr int EPC = AttnCfg<T>::EPC, P = AttnCfg<T>::P;
+template <typename T, int TRIPS, int PA, int PA2, int PB, int PB2>
+__device__ __forceinline__ void stage_pair(T* ldsA, T* ldsA2, const T* gA, long ldA, T* ldsB, T* ldsB2, const T* gB, long ldB, int rows,
+                                           int rows_pad, int tid) {
+    // PA / PB: pitch of the (first) image of matrix A / B; PA2 / PB2 > 0: a second image of the same rows with that pitch
+    constexpr int EPC = AttnCfg<T>::EPC;
     constexpr int CPR = HD / EPC;   // 16-byte pieces per row
     constexpr int UNR = 2;
     const int total = rows_pad * CPR;
@@ -63,8 +72,10 @@ __device__ __forceinline__ void stage_pair(T* ldsA, const T* gA, long ldA, T* ld
         for (int u = 0; u < UNR; ++u) {
             if (rr[u] >= rows) { va[u] = make_uint4(0u, 0u, 0u, 0u); vb[u] = make_uint4(0u, 0u, 0u, 0u); }
             if (ok[u]) {
-                *reinterpret_cast<uint4*>(ldsA + rr[u] * P + ee[u]) = va[u];
-                *reinterpret_cast<uint4*>(ldsB + rr[u] * P + ee[u]) = vb[u];
+                *reinterpret_cast<uint4*>(ldsA + rr[u] * PA + ee[u]) = va[u];
+                *reinterpret_cast<uint4*>(ldsB + rr[u] * PB + ee[u]) = vb[u];
+                if constexpr (PA2 > 0) *reinterpret_cast<uint4*>(ldsA2 + rr[u] * PA2 + ee[u]) = va[u];
+                if constexpr (PB2 > 0) *reinterpret_cast<uint4*>(ldsB2 + rr[u] * PB2 + ee[u]) = vb[u];
             }
         }
     }
@@ -119,9 +130,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(UnivlAttention p, int Sk_
     using C = AttnCfg<T>;
     using M = Mma<T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* sK = reinterpret_cast<T*>(smem_raw);
-    T* sV = sK + Sk_pad * C::P;
-    float* sM = reinterpret_cast<float*>(sV + Sk_pad * C::P);
+    T* sK = reinterpret_cast<T*>(smem_raw);                     // K-major reads only: PK image
+    T* sV = sK + Sk_pad * C::PK;                                // transpose reads only: PT image
+    float* sM = reinterpret_cast<float*>(sV + Sk_pad * C::PT);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(UnivlAttention p, int Sk_
     const uint64_t seed = seed_fetch(p);
     const MaskRegs mk = mask_fetch(p.key_mask, p.q, b, p.Sk, tid);
     constexpr int TRIPS = (MAXKT * 16 * (HD / C::EPC) <= 1024) ? (MAXKT * 16 * (HD / C::EPC) + 511) / 512 : 0;
-    stage_pair<T, TRIPS>(sK, Kg, p.ldk, sV, Vg, p.ldv, p.Sk, Sk_pad, tid);
+    stage_pair<T, TRIPS, C::PK, 0, C::PT, 0>(sK, nullptr, Kg, p.ldk, sV, nullptr, Vg, p.ldv, p.Sk, Sk_pad, tid);
     mask_store(sM, mk, p.key_mask != nullptr, p.Sk, Sk_pad, tid);
     __syncthreads();
     if (q0 >= p.Sq) return;
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(UnivlAttention p, int Sk_
         if (kt < nkt) {
 #pragma unroll
             for (int c = 0; c < C::NCD; ++c)
-                s[kt] = M::mma(M::lds_kmajor(sK + (kt * 16 + i) * C::P + c * C::CH, g), fq[c], s[kt]);
+                s[kt] = M::mma(M::lds_kmajor(sK + (kt * 16 + i) * C::PK + c * C::CH, g), fq[c], s[kt]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * 16 + 4 * g + r;
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(UnivlAttention p, int Sk_
             const typename M::frag fp = M::from_acc(s[kc * C::TPC], s[kc * C::TPC + C::TPC - 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-                o[dt] = M::mma(M::lds_tmajor(sV + (kc * C::CH) * C::P + dt * 16, C::P, lane), fp, o[dt]);
+                o[dt] = M::mma(M::lds_tmajor(sV + (kc * C::CH) * C::PT + dt * 16, C::PT, lane), fp, o[dt]);
         }
     }
     if (qv) {
@@ -217,10 +228,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(UnivlAttention p, int Sk_
 
 // ------------------------------------------------------------------------------------------------ backward
 // role A (blockIdx.y < nqb): dQ for a block of 64 queries.   role B: dK, dV for a block of 64 keys.
-template <typename T, int TRIPS>
+// DUAL: the matrices that are read both ways (K in role A, Q and dO in role B) are staged as a PK image and a PT image.
+template <typename T, int TRIPS, bool DUAL>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_pad, int Sq_pad, int nqb, float scale) {
     using C = AttnCfg<T>;
     using M = Mma<T>;
+    constexpr int PB = DUAL ? C::PK : C::PT;         // pitch of the image the K-major reads of a two-way matrix use
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
@@ -235,9 +248,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_
 
     if ((int)blockIdx.y < nqb) {
         // ---------------------------------------------------------------- role A: dQ
-        T* sK = reinterpret_cast<T*>(smem_raw);
-        T* sV = sK + Sk_pad * C::P;
-        float* sM = reinterpret_cast<float*>(sV + Sk_pad * C::P);
+        T* sKt = reinterpret_cast<T*>(smem_raw);                  // transpose reads (dQ)
+        T* sV = sKt + Sk_pad * C::PT;                             // K-major reads only
+        T* sKk = DUAL ? sV + Sk_pad * C::PK : sKt;                // K-major reads (scores)
+        float* sM = reinterpret_cast<float*>(sV + Sk_pad * C::PK + (DUAL ? Sk_pad * C::PK : 0));
         const int q0 = blockIdx.y * 64 + wave * 16;
         const int q = q0 + i;
         const bool qv = q < p.Sq;
@@ -250,7 +264,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_
             fo[c] = M::gmem_kmajor(Ob + (long)qc * p.ldo + c * C::CH, g);
         }
         const float lse = p.lse[(long)bh * p.Sq + qc];
-        stage_pair<T, TRIPS>(sK, Kb, p.ldk, sV, Vb, p.ldv, p.Sk, Sk_pad, tid);
+        stage_pair<T, TRIPS, C::PT, DUAL ? C::PK : 0, C::PK, 0>(sKt, sKk, Kb, p.ldk, sV, nullptr, Vb, p.ldv, p.Sk, Sk_pad, tid);
         mask_store(sM, mk, p.key_mask != nullptr, p.Sk, Sk_pad, tid);
         __syncthreads();
         if (q0 >= p.Sq) return;
@@ -274,8 +288,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_
                 f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < C::NCD; ++c) {
-                    st = M::mma(M::lds_kmajor(sK + (kt * 16 + i) * C::P + c * C::CH, g), fq[c], st);
-                    dp = M::mma(M::lds_kmajor(sV + (kt * 16 + i) * C::P + c * C::CH, g), fdo[c], dp);
+                    st = M::mma(M::lds_kmajor(sKk + (kt * 16 + i) * PB + c * C::CH, g), fq[c], st);
+                    dp = M::mma(M::lds_kmajor(sV + (kt * 16 + i) * C::PK + c * C::CH, g), fdo[c], dp);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_
             const typename M::frag fds = M::from_acc(ds[0], ds[C::TPC - 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-                dq[dt] = M::mma(M::lds_tmajor(sK + (kc * C::CH) * C::P + dt * 16, C::P, lane), fds, dq[dt]);
+                dq[dt] = M::mma(M::lds_tmajor(sKt + (kc * C::CH) * C::PT + dt * 16, C::PT, lane), fds, dq[dt]);
         }
         if (qv) {
             T* dQg = reinterpret_cast<T*>(p.dq) + ((long)b * p.Sq + q) * p.lddq + h * HD;
@@ -299,9 +313,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_
         }
     } else {
         // ---------------------------------------------------------------- role B: dK, dV
-        T* sQ = reinterpret_cast<T*>(smem_raw);
-        T* sDO = sQ + Sq_pad * C::P;
-        float* sM = reinterpret_cast<float*>(sDO + Sq_pad * C::P);   // [Sk_pad]
+        T* sQt = reinterpret_cast<T*>(smem_raw);                  // transpose reads (dK, dV)
+        T* sDOt = sQt + Sq_pad * C::PT;
+        T* sQk = DUAL ? sDOt + Sq_pad * C::PT : sQt;              // K-major reads (scores, dP)
+        T* sDOk = DUAL ? sQk + Sq_pad * C::PK : sDOt;
+        float* sM = reinterpret_cast<float*>(sDOt + Sq_pad * C::PT + (DUAL ? 2 * Sq_pad * C::PK : 0));   // [Sk_pad]
         float* sL = sM + Sk_pad;                                      // [Sq_pad] lse
         float* sD = sL + Sq_pad;                                      // [Sq_pad] rowsum(dO*O)
         const int k0 = ((int)blockIdx.y - nqb) * 64 + wave * 16;
@@ -344,7 +360,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_
         typename M::frag vo0[NV], vd0[NV];
         float l0 = 0.f;
         if (TRIPS > 0) d_fetch(tid >> 2, vo0, vd0, l0);
-        stage_pair<T, TRIPS>(sQ, Qb, p.ldq, sDO, dOb, p.lddo, p.Sq, Sq_pad, tid);
+        stage_pair<T, TRIPS, C::PT, DUAL ? C::PK : 0, C::PT, DUAL ? C::PK : 0>(sQt, sQk, Qb, p.ldq, sDOt, sDOk, dOb, p.lddo, p.Sq, Sq_pad, tid);
         mask_store(sM, mk, p.key_mask != nullptr, p.Sk, Sk_pad, tid);
         if (TRIPS > 0) {
             d_store(tid >> 2, vo0, vd0, l0);
@@ -371,8 +387,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_
                 f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < C::NCD; ++c) {
-                    st = M::mma(M::lds_kmajor(sQ + (qt * 16 + i) * C::P + c * C::CH, g), fk[c], st);
-                    dp = M::mma(M::lds_kmajor(sDO + (qt * 16 + i) * C::P + c * C::CH, g), fv[c], dp);
+                    st = M::mma(M::lds_kmajor(sQk + (qt * 16 + i) * PB + c * C::CH, g), fk[c], st);
+                    dp = M::mma(M::lds_kmajor(sDOk + (qt * 16 + i) * PB + c * C::CH, g), fv[c], dp);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -392,8 +408,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(UnivlAttention p, int Sk_
             const typename M::frag fds = M::from_acc(ds[0], ds[C::TPC - 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                dv[dt] = M::mma(M::lds_tmajor(sDO + (qc * C::CH) * C::P + dt * 16, C::P, lane), fpd, dv[dt]);
-                dk[dt] = M::mma(M::lds_tmajor(sQ + (qc * C::CH) * C::P + dt * 16, C::P, lane), fds, dk[dt]);
+                dv[dt] = M::mma(M::lds_tmajor(sDOt + (qc * C::CH) * C::PT + dt * 16, C::PT, lane), fpd, dv[dt]);
+                dk[dt] = M::mma(M::lds_tmajor(sQt + (qc * C::CH) * C::PT + dt * 16, C::PT, lane), fds, dk[dt]);
             }
         }
         if (kv) {
@@ -431,7 +447,7 @@ int check(const UnivlAttention* d, const char* who, bool bwd) {
 
 template <typename T, int MAXKT>
 int launch_fwd(const UnivlAttention* d, int Sk_pad, hipStream_t stream) {
-    const size_t smem = (size_t)2 * Sk_pad * AttnCfg<T>::P * sizeof(T) + Sk_pad * sizeof(float);
+    const size_t smem = (size_t)Sk_pad * (AttnCfg<T>::PK + AttnCfg<T>::PT) * sizeof(T) + Sk_pad * sizeof(float);
     static bool attr_done[UNIVL_MAX_DEVICES] = {};
     univl_allow_lds(attn_fwd_kernel<T, MAXKT>, 160 * 1024, attr_done);
     dim3 grid(d->B * d->H, (d->Sq + 63) / 64);
@@ -451,29 +467,43 @@ int dispatch_fwd(const UnivlAttention* d, hipStream_t stream) {
     return launch_fwd<T, 24>(d, Sk_pad, stream);
 }
 
-template <typename T>
-int dispatch_bwd(const UnivlAttention* d, hipStream_t stream) {
-    const int CH = Mma<T>::CH;
-    const int Sk_pad = (d->Sk + CH - 1) / CH * CH, Sq_pad = (d->Sq + CH - 1) / CH * CH;
+template <typename T, int TR, bool DUAL>
+int launch_bwd(const UnivlAttention* d, int Sk_pad, int Sq_pad, size_t smem, hipStream_t stream) {
     const int nqb = (d->Sq + 63) / 64, nkb = (d->Sk + 63) / 64;
-    const size_t smemA = (size_t)2 * Sk_pad * AttnCfg<T>::P * sizeof(T) + Sk_pad * sizeof(float);
-    const size_t smemB = (size_t)2 * Sq_pad * AttnCfg<T>::P * sizeof(T) + (Sk_pad + 2 * Sq_pad) * sizeof(float);
-    const size_t smem = smemA > smemB ? smemA : smemB;
-    constexpr int PIECES64 = 64 * (HD / AttnCfg<T>::EPC);          // 16-byte pieces of a 64-row tile
-    const bool small = Sk_pad <= 64 && Sq_pad <= 64;
-    constexpr int TR = (PIECES64 + 511) / 512;
+    static bool attr_done[UNIVL_MAX_DEVICES] = {};
+    univl_allow_lds(attn_bwd_kernel<T, TR, DUAL>, 160 * 1024, attr_done);
     dim3 grid(d->B * d->H, nqb + nkb);
-    if (small) {
-        static bool attr_small[UNIVL_MAX_DEVICES] = {};
-        univl_allow_lds(attn_bwd_kernel<T, TR>, 160 * 1024, attr_small);
-        hipLaunchKernelGGL((attn_bwd_kernel<T, TR>), grid, dim3(256), smem, stream, *d, Sk_pad, Sq_pad, nqb, 0.125f);
-    } else {
-        static bool attr_done[UNIVL_MAX_DEVICES] = {};
-        univl_allow_lds(attn_bwd_kernel<T, 0>, 160 * 1024, attr_done);
-        hipLaunchKernelGGL((attn_bwd_kernel<T, 0>), grid, dim3(256), smem, stream, *d, Sk_pad, Sq_pad, nqb, 0.125f);
-    }
+    hipLaunchKernelGGL((attn_bwd_kernel<T, TR, DUAL>), grid, dim3(256), smem, stream, *d, Sk_pad, Sq_pad, nqb, 0.125f);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
+}
+
+// Sequences up to this many (padded) positions get the two-image staging in the backward (bf16 only): 64 rows x (144 + 160) B x 2
+// matrices = 38 KB per workgroup, four workgroups per compute unit.  Longer sequences keep one image per matrix: at S = 224 the two
+// images of Q and dO are 136 KB -- one 4-wave workgroup per compute unit.
+constexpr int ATTN_DUAL_MAX = 64;
+
+template <typename T>
+int dispatch_bwd(const UnivlAttention* d, hipStream_t stream) {
+    using C = AttnCfg<T>;
+    const int CH = Mma<T>::CH;
+    const int Sk_pad = (d->Sk + CH - 1) / CH * CH, Sq_pad = (d->Sq + CH - 1) / CH * CH;
+    int dual_max = ATTN_DUAL_MAX;
+#ifdef UNIVL_TRACE
+    if (const char* e = getenv("UNIVL_ATTN_DUAL_MAX")) dual_max = atoi(e);      // measurement build only (scripts/mb_attention.py)
+#endif
+    const bool dual = sizeof(T) == 2 && Sk_pad <= dual_max && Sq_pad <= dual_max;
+    const size_t smemA = (size_t)Sk_pad * (C::PT + C::PK + (dual ? C::PK : 0)) * sizeof(T) + Sk_pad * sizeof(float);
+    const size_t smemB = (size_t)Sq_pad * (2 * C::PT + (dual ? 2 * C::PK : 0)) * sizeof(T) + (Sk_pad + 2 * Sq_pad) * sizeof(float);
+    const size_t smem = smemA > smemB ? smemA : smemB;
+    UNIVL_CHECK_ARG(smem <= 160 * 1024, UNIVL_EUNSUPPORTED, "univl_attention_bwd: %zu bytes of LDS", smem);
+    constexpr int PIECES64 = 64 * (HD / C::EPC);                   // 16-byte pieces of a 64-row tile
+    const bool small = Sk_pad <= 64 && Sq_pad <= 64;
+    constexpr int TR = (PIECES64 + 511) / 512;
+    if constexpr (sizeof(T) == 2) {
+        if (dual) return small ? launch_bwd<T, TR, true>(d, Sk_pad, Sq_pad, smem, stream) : launch_bwd<T, 0, true>(d, Sk_pad, Sq_pad, smem, stream);
+    }
+    return small ? launch_bwd<T, TR, false>(d, Sk_pad, Sq_pad, smem, stream) : launch_bwd<T, 0, false>(d, Sk_pad, Sq_pad, smem, stream);
 }
 
 }  // namespace

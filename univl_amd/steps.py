@@ -96,6 +96,9 @@ class EncoderPass:
         e, ct, bf, fl = cx.e, cx.ct, cx.bf, cx.fl
         D = cx.tc.video_dim
         self.D, self.Tt, self.Tv = D, B * W, B * F
+        # (Round 4, measured and removed: the video stack BEHIND the text stack on one stream where every product fills the chip by
+        # itself -- 13.40 / 13.40 vs 11.99 / 12.11 ms at 128 pairs, 12.03 vs 9.25 at 64, 6.60 vs 5.30 at 32, profiles/r04m_ab_serial_branches.txt:
+        # two streams also overlap one branch's tails and non-GEMM kernels with the other's products.)
         self.ST, self.SV = s_text, s_vis
         i64 = torch.int64
         self.ids, self.type_ids, self.amask = e(B, W, dtype=i64), e(B, W, dtype=i64), e(B, W, dtype=i64)
