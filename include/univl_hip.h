@@ -385,6 +385,19 @@ int univl_bert_adam_range(const UnivlAdam* d, int32_t chunk_begin, int32_t chunk
  * the chunk range as its own launch -- same result.  max_blocks > 0 caps the workgroups given to the update. */
 int univl_gemm_rider(const UnivlGemm* gemm, const UnivlAdam* adam, int32_t chunk_begin, int32_t chunk_count, int32_t max_blocks,
                      hipStream_t stream);
+/* K8 / K10 of the survey (module_bert.py:207-211, 246-250: dense -> dropout -> + input -> LayerNorm; the copies in module_visual.py /
+ * module_cross.py): a forward product whose fp32 output is the input x of a LayerNorm, with that LayerNorm finished INSIDE the product's
+ * launch -- each 64-row block of the output is normalised by the last workgroups to contribute to it (agent-scope release / acquire around
+ * a per-block arrival counter), instead of by a second launch behind a kernel boundary.  Same arithmetic per row as univl_layernorm_fwd
+ * (the same device function); the product's sums meet in hardware order exactly as in any split-K product, so the entry point refuses
+ * deterministic mode.  Optionally also carries BertAdam chunks like univl_gemm_rider (adam may be NULL with chunk_count 0).
+ *   gemm: bf16, both operands K-major, fp32 output C32 == ln->x with ldc = N = 768, no C16 / GELU / ACCUM / sumsq, at most 4096 rows;
+ *   ln:   rows == gemm->M, N == 768, fp32 x, dtype bf16 (residual / dropout / y / stats / out32 / out16 as for univl_layernorm_fwd);
+ *   counters: 2 * ceil(M / 64) int32 device words owned by this call site, ZERO before its first launch (the launch leaves them zero).
+ * Returns UNIVL_EUNSUPPORTED for anything else (callers then enqueue univl_gemm / univl_gemm_rider + univl_layernorm_fwd);
+ * dry_run != 0 validates without launching. */
+int univl_gemm_ln(const UnivlGemm* gemm, const UnivlLayerNorm* ln, int32_t* counters, const UnivlAdam* adam, int32_t chunk_begin,
+                  int32_t chunk_count, int32_t max_blocks, int32_t dry_run, hipStream_t stream);
 /* Large-LDS opt-in of the rider kernels on the stream's device; call once outside any stream capture before the first captured rider. */
 int univl_gemm_rider_prime(hipStream_t stream);
 /* *ctr += 1 (device word; used for per-replay dropout seeds) */

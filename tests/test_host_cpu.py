@@ -235,9 +235,18 @@ def test_adam_rider_plan_builds_on_cpu(monkeypatch):
     names0 = [op[3] for op in base.fwd.ops]
     names1 = [op[3] for op in ride.fwd.ops]
     assert [n.replace("univl_gemm_rider", "univl_gemm") for n in names1] == names0
-    riders = [op[2] for op in ride.fwd.ops if op[0] == "rider"]
+    # (desc, key, slot, nslots) of every launch that can carry chunks: plain rider launches and the (product + LayerNorm) launches
+    riders = [op[2] for op in ride.fwd.ops if op[0] == "rider"] + [(op[2][0],) + op[2][3:] for op in ride.fwd.ops if op[0] == "gemm_ln" and op[2][3] is not None]
     L_t, L_v = cfg.text_num_hidden_layers, cfg.visual_num_hidden_layers
     assert len(riders) == 4 * ((L_t - 1) + (L_v - 1))
+    # K8 / K10: the attention-output and FFN2 products of every layer carry their LayerNorm (round 4); no separate launch is left for those
+    folds = [op for op in ride.fwd.ops if op[0] == "gemm_ln"]
+    assert len(folds) == 2 * (L_t + L_v) and len([op for op in base.fwd.ops if op[0] == "gemm_ln"]) == len(folds)
+    assert sum(1 for n in names1 if n == "univl_layernorm_fwd") == 2          # NormalizeVideo + the video embedding LayerNorm
+    monkeypatch.setenv("UNIVL_LN_FOLD", "0")
+    unfolded = build_step(m, "joint", 2, 16, 16, True)
+    monkeypatch.delenv("UNIVL_LN_FOLD")
+    assert sum(1 for op in unfolded.fwd.ops if op[3] == "univl_layernorm_fwd") == 2 + len(folds) and not [op for op in unfolded.fwd.ops if op[0] == "gemm_ln"]
     carried = {("layer", "bert", l) for l in range(1, L_t)} | {("layer", "visual", l) for l in range(1, L_v)}
     assert ride.fwd.rider_keys == carried
     for key in carried:

@@ -428,6 +428,62 @@ def test_layernorm_dropout_mask_consistency():
     assert torch.equal(dxd == 0, y == 0) or ((dxd == 0) & (y != 0)).float().mean().item() < 1e-3
 
 
+# ----------------------------------------------------------------------- product + LayerNorm in one launch (K8 / K10)
+@pytest.mark.parametrize("M,K,ksplit,p_drop", [(192, 768, 2, 0.0), (192, 3072, 8, 0.1), (768, 768, 1, 0.1), (768, 3072, 3, 0.0),
+                                                (100, 768, 2, 0.1), (1024, 768, 1, 0.0), (64, 3072, 8, 0.1)])
+def test_gemm_ln_fold_matches_the_two_launches(M, K, ksplit, p_drop):
+    """univl_gemm_ln (gemm.hip: ln_fold): the LayerNorm behind an attention-output / FFN2 product finished by the product's own launch.
+    Same arithmetic per row as univl_layernorm_fwd on the same fp32 sums: bit-identical to the two launches when the product is not
+    split (plain stores), within fp32 summation-order noise when its slices meet in atomics; 40 back-to-back launches per case as a
+    race screen (a workgroup normalising a row block before every contribution landed would show up as a wrong row), and the arrival
+    counters must be zero again after every launch."""
+    import ctypes as C
+    import univl_amd
+    was = univl_amd.deterministic()
+    univl_amd.set_deterministic(False)
+    try:
+        N = 768
+        bf = torch.bfloat16
+        a = gen(M, K, seed=1).to(DEV, bf)
+        w = gen(N, K, seed=2, scale=K ** -0.5).to(DEV, bf)
+        bias = gen(N, seed=3).to(DEV)
+        res = gen(M, N, seed=4).to(DEV)
+        gm, bt = (1.0 + 0.1 * gen(N, seed=5)).to(DEV), gen(N, seed=6).to(DEV)
+
+        def bufs():
+            return dict(x=torch.zeros(M, N, device=DEV), stats=torch.zeros(M, 2, device=DEV), out32=torch.zeros(M, N, device=DEV),
+                        out16=torch.zeros(M, N, device=DEV, dtype=bf))
+
+        def descs(b):
+            g = ops.gemm_desc(a, w, M, N, K, out32=b["x"], bias=bias, ksplit=ksplit)
+            ln = ops.layernorm_desc(ops.dtype_code(bf), M, N, x=b["x"], residual=res, gamma=gm, beta=bt, y=b["x"], stats=b["stats"],
+                                    out32=b["out32"], out16=b["out16"], p_pre=p_drop, seed=7, off_pre=3 << 40)
+            return g, ln
+
+        ref = bufs()
+        g, ln = descs(ref)
+        _lib.check(_lib.lib().univl_gemm(C.byref(g), None), "gemm")
+        _lib.check(_lib.lib().univl_layernorm_fwd(C.byref(ln), None), "layernorm_fwd")
+        ctr = torch.zeros(2 * ((M + 63) // 64), dtype=torch.int32, device=DEV)
+        got = bufs()
+        g2, ln2 = descs(got)
+        assert ops.gemm_ln(g2, ln2, ctr, dry_run=True)
+        for it in range(40):
+            got["x"].zero_()
+            assert ops.gemm_ln(g2, ln2, ctr)
+            assert int(ctr.abs().sum()) == 0, it
+            for k in ("x", "stats", "out32", "out16"):
+                if ksplit == 1:
+                    assert torch.equal(got[k], ref[k]), (it, k)
+                else:
+                    assert rel_err(got[k].float(), ref[k].float()) < (1e-2 if k == "out16" else 2e-5), (it, k)
+        # deterministic mode: refused (callers enqueue the two launches)
+        univl_amd.set_deterministic(True)
+        assert not ops.gemm_ln(g2, ln2, ctr, dry_run=True)
+    finally:
+        univl_amd.set_deterministic(was)
+
+
 # --------------------------------------------------------------------------------------------- attention
 ATTN_CASES = [(2, 48, 48, False), (3, 20, 20, False), (2, 12, 12, False), (2, 96, 96, False), (2, 40, 56, False),
               (1, 128, 224, False), (2, 24, 24, True), (1, 128, 128, True), (1, 224, 224, False)]

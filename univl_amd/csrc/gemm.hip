@@ -23,6 +23,7 @@
 #include "common.h"
 #include "univl_hip.h"
 #include "adam_body.h"
+#include "ln_body.h"
 
 // -DUNIVL_TRACE (a second, measurement-only build: univl_amd/build.py trace=True -> lib/libunivl_hip_trace.so, never the product library): thread 0
 // of every workgroup of a GEMM-family kernel writes the device wall clock (100 MHz) at kernel entry, when its first staged tile has
@@ -767,6 +768,68 @@ __global__ __launch_bounds__(512, 2) void gemm_adam_kernel(GemmArgs g, int nd, i
     }
 }
 
+// K8 / K10 (module_bert.py:207-211, 246-250: dense -> dropout -> + input -> LayerNorm): the LayerNorm that consumes a product's fp32
+// output, finished INSIDE the product's launch.  The output rows of a 64-row block are complete when all nx * nz tiles of the block
+// (column tiles x split-K slices, meeting in fp32 atomics) have added to them; every tile workgroup announces itself
+// on the block's counter once its atomics are performed, and the LAST LN_SHARE arrivals normalise 8 rows each (one row per wave, the
+// body of ln_fwd_kernel) once the counter is full -- the earlier ones of them spin on it, which cannot deadlock: they only wait for
+// workgroups that are already running.  What it buys: one kernel boundary (~3 us here) and one launch's fixed cost per LayerNorm on
+// a chain of ~190 dependent launches per step; what it costs: a counter round trip on the product's tail.
+// counters: two ints per row block (arrivals, finished sharers), zero before the first launch; the last sharer re-zeroes them.
+constexpr int LN_SHARE = 8;
+
+struct LnFold {
+    UnivlLayerNorm ln;
+    int* counters;
+};
+
+__device__ __forceinline__ void ln_fold(const LnFold& f, const int by, const int n, const int M) {
+    // No agent-scope FENCE anywhere: __threadfence() is an L2 write-back plus an L2 invalidate of the whole XCD, per wave, in a launch
+    // whose other workgroups stream optimizer state and weight tiles through that L2 (measured: +70 us per launch).  The contributions
+    // are fp32 atomics (performed at the device's coherence point; the host sets UNIVL_GEMM_ATOMIC for every fold launch), so "this
+    // thread's contributions are done" is s_waitcnt vmcnt(0), and the rows are read back with agent-scope loads (ln_fwd_row<XC>).
+    int* cnt = f.counters + 2 * by;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // every thread's atomics are performed; the LDS stages are free from here on
+    int* slot = reinterpret_cast<int*>(smem_raw);
+    if (threadIdx.x == 0) slot[0] = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int arrival = slot[0];
+    if (arrival < n - LN_SHARE) return;
+    if (arrival != n - 1) {
+        if (threadIdx.x == 0) {
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+    }
+    asm volatile("" ::: "memory");
+    const int row = by * 64 + (arrival - (n - LN_SHARE)) * 8 + (int)(threadIdx.x >> 6);
+    if (row < M) ln_fwd_row<768, __bf16, false, true>(f.ln, row, (int)(threadIdx.x & 63));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (__hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == LN_SHARE - 1) {
+            // every sharer is past its spin: ready for the next launch / graph replay
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(512, 2) void gemm_ln_kernel(GemmArgs g, int nd, int nd_pad, int nx, int ny, int nz, UnivlAdam a, int c0, int c1, LnFold f) {
+    const int w0 = blockIdx.x;
+    if (w0 < nd_pad) {
+        if (w0 >= nd) return;                                  // padding workgroup
+        int bx, by, bz;
+        pair_tile(w0, nd, nx, ny, nz, g.flags, g.gm, bx, by, bz);
+        gemm_tile<__bf16, false, false, 64, 64, 4, 2, 4>(g, bx, by, bz, nz);
+        ln_fold(f, by, nx * nz, g.M);
+    } else {
+        const int nb = (int)gridDim.x - nd_pad;
+        for (int c = c0 + (w0 - nd_pad); c < c1; c += nb) adam_chunk<NT, 512>(a, c);
+    }
+}
+
 template <typename T, bool TA, bool TB, int BM, int BN, int NC, int WGM = 2, int WGN = 2>
 int launch(const GemmArgs& a, int ksplit, hipStream_t stream) {
     constexpr int BK = NC * Mma<T>::CH, NT = 64 * WGM * WGN;
@@ -1094,11 +1157,61 @@ extern "C" int univl_gemm_rider(const UnivlGemm* gemm, const UnivlAdam* adam, in
     return UNIVL_OK;
 }
 
+// The same launch with the LayerNorm that consumes the product's fp32 output folded in (gemm_ln_kernel); adam may be null (no chunks).
+// The product must be one the rider kernel carries (bf16, K-major operands, the 64 x 64 tile) with fp32 output = ln->x over ln->rows
+// = M rows of N = 768; the LayerNorm a bf16-output, fp32-input, non-positional one.  Returns UNIVL_EUNSUPPORTED otherwise (callers
+// then enqueue the two launches), and in deterministic mode (the fold's row sums meet in hardware order like any split-K product's).
+extern "C" int univl_gemm_ln(const UnivlGemm* gemm, const UnivlLayerNorm* ln, int32_t* counters, const UnivlAdam* adam,
+                             int32_t chunk_begin, int32_t chunk_count, int32_t max_blocks, int32_t dry_run, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    UNIVL_CHECK_ARG(gemm != nullptr && ln != nullptr && counters != nullptr, UNIVL_EINVAL, "univl_gemm_ln: null argument");
+    UNIVL_CHECK_ARG(chunk_count == 0 || (adam != nullptr && adam->p && adam->g && adam->m && adam->v && adam->segs && adam->chunk_seg &&
+                                         adam->chunk_off && adam->chunk_len && adam->seg_scalars && chunk_begin >= 0 && chunk_count > 0 &&
+                                         chunk_begin + chunk_count <= adam->nchunk),
+                    UNIVL_EINVAL, "univl_gemm_ln: chunks [%d, +%d)", chunk_begin, chunk_count);
+    GemmArgs a;
+    int ks;
+    Choice c;
+    const int rc = prepare(gemm, a, ks, c);
+    if (rc != UNIVL_OK) return rc;
+    const int nx = (gemm->N + 63) / 64, ny = (gemm->M + 63) / 64;
+    UNIVL_CHECK_ARG(!univl_deterministic() && gemm->dtype == UNIVL_BF16 && !gemm->trans_a && !gemm->trans_b && c.tile == 64 && c.nc == 4 &&
+                        !gemm->sumsq && !gemm->dbias && gemm->C32 && !gemm->C16 && gemm->N == 768 && gemm->ldc == 768 &&
+                        !(gemm->flags & (UNIVL_GEMM_GELU_FWD | UNIVL_GEMM_GELU_BWD | UNIVL_GEMM_ACCUM)) && nx * ks >= LN_SHARE &&
+                        ny <= 64 && ln->dtype == UNIVL_BF16 && ln->N == 768 && ln->rows == gemm->M && !ln->x_f64 &&
+                        ln->x == (const void*)gemm->C32 && ln->gamma && ln->beta && (ln->out16 || ln->out32),
+                    UNIVL_EUNSUPPORTED, "univl_gemm_ln: not a (product, LayerNorm) pair this launch carries");
+    if (dry_run) return UNIVL_OK;
+    a.flags |= UNIVL_GEMM_ATOMIC;            // every contribution an fp32 atomic into the pre-zeroed output, also when the product is not split
+    const int nd = nx * ny * ks, nd_pad = (nd + 7) / 8 * 8;
+    const int nb = chunk_count <= 0 ? 0 : ((max_blocks > 0 && max_blocks < chunk_count) ? max_blocks : chunk_count);
+    UnivlAdam none = {};
+    const UnivlAdam& ad = chunk_count > 0 ? *adam : none;
+    LnFold f;
+    f.ln = *ln;
+    f.counters = counters;
+    static bool done_nt[UNIVL_MAX_DEVICES] = {}, done_t[UNIVL_MAX_DEVICES] = {};
+    univl_allow_lds(gemm_ln_kernel<true>, RIDER_SMEM, done_nt);
+    univl_allow_lds(gemm_ln_kernel<false>, RIDER_SMEM, done_t);
+    if (univl_adam_nt()) {
+        hipLaunchKernelGGL(gemm_ln_kernel<true>, dim3(nd_pad + nb), dim3(512), RIDER_SMEM, stream, a, nd, nd_pad, nx, ny, ks, ad,
+                           chunk_begin, chunk_begin + (chunk_count > 0 ? chunk_count : 0), f);
+    } else {
+        hipLaunchKernelGGL(gemm_ln_kernel<false>, dim3(nd_pad + nb), dim3(512), RIDER_SMEM, stream, a, nd, nd_pad, nx, ny, ks, ad,
+                           chunk_begin, chunk_begin + (chunk_count > 0 ? chunk_count : 0), f);
+    }
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
 // The rider kernels' large-LDS opt-in, outside any stream capture: their first launch happens INSIDE the capture of the pipelined
 // training step (the eager iteration before it has no pending update to carry).
 extern "C" int univl_gemm_rider_prime(hipStream_t stream) {
     UNIVL_ON_STREAM_DEVICE(stream);
     rider_allow_lds();
+    static bool done_nt[UNIVL_MAX_DEVICES] = {}, done_t[UNIVL_MAX_DEVICES] = {};
+    univl_allow_lds(gemm_ln_kernel<true>, RIDER_SMEM, done_nt);
+    univl_allow_lds(gemm_ln_kernel<false>, RIDER_SMEM, done_t);
     return UNIVL_OK;
 }
 

@@ -6,105 +6,16 @@
 #include <stdlib.h>
 #include "common.h"
 #include "univl_hip.h"
+#include "ln_body.h"
 
 namespace {
 
 template <int N, typename TO, bool F64>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(UnivlLayerNorm p) {
-    constexpr int NV = N / 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= p.rows) return;
-    float v[NV][4];
-    // Every global operand of the row (seed, x, residual, position row, gamma, beta) is requested up front, from
-    // SELECTED (always valid) pointers instead of inside "if (ptr)" blocks: a branch per operand kind costs one full
-    // memory round trip each (hipcc drains the loads in flight at every join), five in a row for the post-GEMM LayerNorm.
-    const uint64_t* sp = p.seed_dev ? p.seed_dev : reinterpret_cast<const uint64_t*>(p.gamma);
-    const uint64_t sdv = *sp;
-    const uint64_t seed = p.seed + (p.seed_dev ? sdv : 0ull);
-    const float inv_keep_pre = p.p_pre > 0.f ? 1.0f / (1.0f - p.p_pre) : 1.0f;
-    const float inv_keep_post = p.p_post > 0.f ? 1.0f / (1.0f - p.p_post) : 1.0f;
-    const float* rp = p.residual ? p.residual + (long)row * N : p.gamma;
-    const float* pp = p.pos ? p.pos + (long)(row % (p.pos ? p.pos_period : 1)) * N : p.gamma;
-    float4 rr[NV], pr[NV], gav[NV], bev[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const long o = (long)row * N + 4 * lane + 256 * j;
-        if (F64) {
-            const double* x = reinterpret_cast<const double*>(p.x) + o;
-            const double2 a = *reinterpret_cast<const double2*>(x);
-            const double2 b = *reinterpret_cast<const double2*>(x + 2);
-            v[j][0] = (float)a.x; v[j][1] = (float)a.y; v[j][2] = (float)b.x; v[j][3] = (float)b.y;
-        } else {
-            const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.x) + o);
-            v[j][0] = a.x; v[j][1] = a.y; v[j][2] = a.z; v[j][3] = a.w;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int col = 4 * lane + 256 * j;
-        rr[j] = *reinterpret_cast<const float4*>(rp + col);
-        pr[j] = *reinterpret_cast<const float4*>(pp + col);
-        gav[j] = *reinterpret_cast<const float4*>(p.gamma + col);
-        bev[j] = *reinterpret_cast<const float4*>(p.beta + col);
-    }
-    if (p.p_pre > 0.f) {
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const long o = (long)row * N + 4 * lane + 256 * j;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[j][e] *= dropout_scale(seed, p.off_pre, (uint64_t)(o + e), p.p_pre, inv_keep_pre);
-        }
-    }
-    const bool useR = p.residual != nullptr, useP = p.pos != nullptr;      // selects, not multiplies: dummy words may be anything
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        v[j][0] += (useR ? rr[j].x : 0.f) + (useP ? pr[j].x : 0.f); v[j][1] += (useR ? rr[j].y : 0.f) + (useP ? pr[j].y : 0.f);
-        v[j][2] += (useR ? rr[j].z : 0.f) + (useP ? pr[j].z : 0.f); v[j][3] += (useR ? rr[j].w : 0.f) + (useP ? pr[j].w : 0.f);
-    }
-    if (p.y) {
-#pragma unroll
-        for (int j = 0; j < NV; ++j)
-            *reinterpret_cast<float4*>(p.y + (long)row * N + 4 * lane + 256 * j) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-    const float mean = wave_sum(s) * (1.0f / N);
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < NV; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float c = v[j][e] - mean; q += c * c; }
-    const float var = wave_sum(q) * (1.0f / N);
-    const float rstd = 1.0f / sqrtf(var + p.eps);
-    if (p.stats && lane == 0) { p.stats[2 * (long)row] = mean; p.stats[2 * (long)row + 1] = rstd; }
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int col = 4 * lane + 256 * j;
-        const long o = (long)row * N + col;
-        const float4 ga = gav[j], be = bev[j];
-        float r[4];
-        r[0] = (v[j][0] - mean) * rstd * ga.x + be.x;
-        r[1] = (v[j][1] - mean) * rstd * ga.y + be.y;
-        r[2] = (v[j][2] - mean) * rstd * ga.z + be.z;
-        r[3] = (v[j][3] - mean) * rstd * ga.w + be.w;
-        if (p.p_post > 0.f) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] *= dropout_scale(seed, p.off_post, (uint64_t)(o + e), p.p_post, inv_keep_post);
-        }
-        if (p.out32) *reinterpret_cast<float4*>(p.out32 + o) = make_float4(r[0], r[1], r[2], r[3]);
-        if (p.out16) {
-            TO* d = reinterpret_cast<TO*>(p.out16) + o;
-            if (sizeof(TO) == 2) {
-                bf16x4_t w;
-                w[0] = (__bf16)r[0]; w[1] = (__bf16)r[1]; w[2] = (__bf16)r[2]; w[3] = (__bf16)r[3];
-                *reinterpret_cast<bf16x4_t*>(d) = w;
-            } else {
-                *reinterpret_cast<float4*>(d) = make_float4(r[0], r[1], r[2], r[3]);
-            }
-        }
-    }
+    ln_fwd_row<N, TO, F64>(p, row, lane);
 }
 
 // Backward.  Each wave walks RPW rows, keeps per-column partial sums of dgamma / dbeta / dbias in registers, the

@@ -308,6 +308,16 @@ class Plan:
         self.rider_keys.add(key)
         self.ops.append(("rider", _lib.lib().univl_gemm_rider, (desc, key, int(slot), int(nslots)), "univl_gemm_rider", stream))
 
+    def add_gemm_ln(self, desc, ln_desc, counters, key=None, slot=0, nslots=1, stream=0):
+        """A forward product AND the LayerNorm that consumes its fp32 output in one launch (univl_gemm_ln: the last workgroups to
+        contribute to a 64-row block normalise it); with `key` it also carries optimizer chunks like add_gemm_rider.  `counters`: the
+        call site's int32 arrival counters (zeroed at allocation, left zero by every launch)."""
+        self.keep += [desc, ln_desc, counters]
+        self.descs[len(self.ops)] = [desc]
+        if key is not None:
+            self.rider_keys.add(key)
+        self.ops.append(("gemm_ln", _lib.lib().univl_gemm_ln, (desc, ln_desc, counters, key, int(slot), int(nslots)), "univl_gemm_ln", stream))
+
     def add(self, fn_name, desc, stream=0):
         fn = getattr(_lib.lib(), fn_name)
         self.keep.append(desc)
@@ -432,6 +442,29 @@ class Plan:
                     rc = a(C.byref(desc), C.byref(rd["desc"]), lo, hi - lo, int(rd.get("max_blocks", 0)), h)
                 if rc != 0:
                     _lib.check(rc, name)
+            elif kind == "gemm_ln":
+                h = handles.get(sidx)
+                if h is None:
+                    h = handles[sidx] = C.c_void_p(self._stream(sidx, cur).cuda_stream)
+                desc, lnd, ctr, key, slot, nslots = b
+                rd = self.riders
+                rng = rd["ranges"].get(key) if (rd and key is not None) else None
+                if rng is not None and (key, slot) in rd["used"]:
+                    rng = None
+                L_ = _lib.lib()
+                if rng is None:
+                    rc = a(C.byref(desc), C.byref(lnd), C.c_void_p(ctr.data_ptr()), None, 0, 0, 0, 0, h)
+                    if rc == _lib.EUNSUPPORTED:          # deterministic mode (or a shape the fold does not carry): the two launches
+                        rc = L_.univl_gemm(C.byref(desc), h) or L_.univl_layernorm_fwd(C.byref(lnd), h)
+                else:
+                    rd["used"].add((key, slot))
+                    lo, hi = rng[0] + rng[1] * slot // nslots, rng[0] + rng[1] * (slot + 1) // nslots
+                    rc = a(C.byref(desc), C.byref(lnd), C.c_void_p(ctr.data_ptr()), C.byref(rd["desc"]), lo, hi - lo, int(rd.get("max_blocks", 0)), 0, h)
+                    if rc == _lib.EUNSUPPORTED:
+                        rc = (L_.univl_gemm_rider(C.byref(desc), C.byref(rd["desc"]), lo, hi - lo, int(rd.get("max_blocks", 0)), h)
+                              or L_.univl_layernorm_fwd(C.byref(lnd), h))
+                if rc != 0:
+                    _lib.check(rc, name)
             elif kind == "pair":
                 h = handles.get(sidx)
                 if h is None:
@@ -534,6 +567,9 @@ class Plan:
                 out.append((lambda h, d=arg[0]: _lib.lib().univl_gemm(C.byref(d), h), self.descs[i]))
             elif kind == "pair" and name.startswith(prefix):
                 out.append((lambda h, fn=fn, arg=arg: fn(C.byref(arg[0]), C.byref(arg[1]), 0, h), self.descs[i]))
+            elif kind == "gemm_ln" and name.startswith(prefix):
+                out.append((lambda h, fn=fn, arg=arg: fn(C.byref(arg[0]), C.byref(arg[1]), C.c_void_p(arg[2].data_ptr()), None, 0, 0, 0, 0, h),
+                            self.descs[i]))
         return out
 
     @property
@@ -634,6 +670,14 @@ class EncoderStack:
         # front of the whole forward -- 2.391 / 2.391 / 2.427 vs 2.392 / 2.396 / 2.397 ms per step, profiles/r04f_ab_update_slot.txt: the
         # prologue launches are HBM streams, two of them side by side each run at half speed.)
         self.T = B * S
+        # K8 / K10: the post-product LayerNorms of the forward finished inside the product's launch (Plan.add_gemm_ln, gemm.hip: ln_fold)
+        # up to 512 tokens -- where a layer is a chain of latency-bound launches and one kernel boundary per LayerNorm is worth more than
+        # the fold's tail (three dependent round trips to the coherence point: atomics done, arrival counter, row loads).  Measured per
+        # step, fold vs two launches (profiles/r04p_ab_ln_fold.txt, r04q_ab_ln_fold_sizes.txt): 192 tokens 2.271 vs 2.333 ms (-2.6 %),
+        # 384: 2.780 vs 2.829 (-1.7 %), 576: 3.144 vs 3.148, 768: 3.469 vs 3.415 (+1.6 %); FT-Align 3.193 vs 3.318 (-3.8 %).
+        # UNIVL_LN_FOLD=0: two launches (A/B).  Deterministic mode falls back to the two launches (the C side refuses).
+        self.ln_fold = (flat.compute_dtype == torch.bfloat16 and B * S <= 512 and os.environ.get("UNIVL_LN_FOLD", "1") != "0"
+                        and prefix in ("bert", "visual", "cross"))
         self.key_mask = key_mask            # int64 [B,S] device tensor (static buffer)
         self.p = float(p_drop)
         self.seed_dev = seed_dev
@@ -646,6 +690,7 @@ class EncoderStack:
         # fp32 GEMM outputs that may be produced by split-K atomics live in two arenas zeroed ONCE per pass
         self.yarena = e(n_layers, 2, T, H)
         self.garena = e(n_layers, 2, T, H)
+        self.ln_ctr = torch.zeros(n_layers, 2, 2 * ((T + 63) // 64), dtype=torch.int32, device=dev) if self.ln_fold else None   # arrival counters of the folds (every launch leaves them zero)
         for l in range(n_layers):
             ws = dict(qkv=e(T, 3 * H, dtype=ct), lse=e(B, self.NH, S), ctx=e(T, H, dtype=ct),
                       y1=self.yarena[l, 0], st1=e(T, 2), a32=e(T, H), u=e(T, I, dtype=ct), f=e(T, I, dtype=ct),
@@ -746,21 +791,34 @@ class EncoderStack:
             plan.add("univl_attention_fwd", ops.attention_desc(
                 dt, B, self.NH, S, S, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx"], H, ws["lse"],
                 key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev), sm)
-            gemm(_gemm_desc(dt, ws["ctx"], H, fl.wop(nm["o_w"]), H, T, H, H, out32=ws["y1"], ldc=H,
-                            bias=fl.w32(nm["o_b"]), ksplit=self.ksplit_for(H)))
             ln_fwd = (lambda d: None) if self.probe_no_ln in ("fwd", "both") else (lambda d: plan.add("univl_layernorm_fwd", d, sm))
-            ln_fwd(ops.layernorm_desc(
-                dt, T, H, x=ws["y1"], residual=x32, gamma=fl.w32(nm["ln1_g"]), beta=fl.w32(nm["ln1_b"]), y=ws["y1"],
-                stats=ws["st1"], out32=ws["a32"], out16=ws["a16"] if self.bf else None, p_pre=p, off_pre=ws["off"][1],
-                seed_dev=self.seed_dev))
+
+            def gemm_ln(desc, lnd, site, _l=l, _slot=slot):
+                """a forward product and the LayerNorm behind it: one launch where the library carries the pair (ln_fold), else two"""
+                ctr = self.ln_ctr[_l, site] if self.ln_fold else None
+                if (ctr is not None and not self.probe_no_ln and
+                        _lib.lib().univl_gemm_ln(C.byref(desc), C.byref(lnd), C.c_void_p(ctr.data_ptr()), None, 0, 0, 0, 1, None) == 0):
+                    key = ("layer", self.prefix, _l + 1) if (self.adam_ride and _l + 1 < self.L) else None
+                    plan.add_gemm_ln(desc, lnd, ctr, key, _slot[0], 4, sm)
+                    _slot[0] += 1 if key is not None else 0
+                else:
+                    gemm(desc)
+                    ln_fwd(lnd)
+
+            gemm_ln(_gemm_desc(dt, ws["ctx"], H, fl.wop(nm["o_w"]), H, T, H, H, out32=ws["y1"], ldc=H,
+                               bias=fl.w32(nm["o_b"]), ksplit=self.ksplit_for(H)),
+                    ops.layernorm_desc(
+                        dt, T, H, x=ws["y1"], residual=x32, gamma=fl.w32(nm["ln1_g"]), beta=fl.w32(nm["ln1_b"]), y=ws["y1"],
+                        stats=ws["st1"], out32=ws["a32"], out16=ws["a16"] if self.bf else None, p_pre=p, off_pre=ws["off"][1],
+                        seed_dev=self.seed_dev), 0)
             gemm(_gemm_desc(dt, ws["a16"], H, fl.wop(nm["w1"]), H, T, I, H, out16=ws["f"], ldc=I,
                             bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd"))
-            gemm(_gemm_desc(dt, ws["f"], I, fl.wop(nm["w2"]), I, T, H, I, out32=ws["y2"], ldc=H,
-                            bias=fl.w32(nm["b2"]), ksplit=self.ksplit_for(I)))
-            ln_fwd(ops.layernorm_desc(
-                dt, T, H, x=ws["y2"], residual=ws["a32"], gamma=fl.w32(nm["ln2_g"]), beta=fl.w32(nm["ln2_b"]), y=ws["y2"],
-                stats=ws["st2"], out32=ws["o32"], out16=ws["o16"] if self.bf else None, p_pre=p, off_pre=ws["off"][2],
-                seed_dev=self.seed_dev))
+            gemm_ln(_gemm_desc(dt, ws["f"], I, fl.wop(nm["w2"]), I, T, H, I, out32=ws["y2"], ldc=H,
+                               bias=fl.w32(nm["b2"]), ksplit=self.ksplit_for(I)),
+                    ops.layernorm_desc(
+                        dt, T, H, x=ws["y2"], residual=ws["a32"], gamma=fl.w32(nm["ln2_g"]), beta=fl.w32(nm["ln2_b"]), y=ws["y2"],
+                        stats=ws["st2"], out32=ws["o32"], out16=ws["o16"] if self.bf else None, p_pre=p, off_pre=ws["off"][2],
+                        seed_dev=self.seed_dev), 1)
             x32, x16 = ws["o32"], ws["o16"]
 
     # ----------------------------------------------------------------------------------------- backward

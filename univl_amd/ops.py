@@ -103,6 +103,16 @@ def gemm_pair(dgrad, wgrad, dry_run=False):
     return True
 
 
+def gemm_ln(gemm, ln, counters, dry_run=False):
+    """A forward product and the LayerNorm that consumes its fp32 output in ONE launch (univl_gemm_ln).  Returns False when the C side
+    does not carry the pair (deterministic mode, other tiles / layouts); counters: int32 [2 * ceil(M / 64)], zero."""
+    rc = _lib.lib().univl_gemm_ln(_BYREF(gemm), _BYREF(ln), C.c_void_p(counters.data_ptr()), None, 0, 0, 0, int(bool(dry_run)), _stream())
+    if rc == _lib.EUNSUPPORTED:
+        return False
+    _lib.check(rc, "gemm_ln")
+    return True
+
+
 def layernorm_desc(dtype, rows, N, *, x=None, x_f64=False, residual=None, pos=None, pos_period=0, gamma=None,
                    beta=None, eps=1e-12, y=None, stats=None, out32=None, out16=None, p_pre=0.0, p_post=0.0, seed=0,
                    off_pre=0, off_post=0, seed_dev=None, dout=None, dx32=None, dxd32=None, dxd16=None, dgamma=None,
