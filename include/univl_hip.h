@@ -398,6 +398,13 @@ int univl_gemm_rider(const UnivlGemm* gemm, const UnivlAdam* adam, int32_t chunk
  * dry_run != 0 validates without launching. */
 int univl_gemm_ln(const UnivlGemm* gemm, const UnivlLayerNorm* ln, int32_t* counters, const UnivlAdam* adam, int32_t chunk_begin,
                   int32_t chunk_count, int32_t max_blocks, int32_t dry_run, hipStream_t stream);
+/* The backward twin: univl_gemm_pair whose dgrad product's fp32 output is the upstream gradient of a LayerNorm backward (ln->dout ==
+ * dgrad->C32, e.g. the FFN1 dgrad in front of BertSelfOutput's LayerNorm, module_bert.py:207-211 differentiated), with that LayerNorm
+ * backward (dx32 / dxd16 rows, dgamma / dbeta / dbias column sums) finished inside the launch by the dgrad's last workgroups per 64-row
+ * block.  Square dgrad body only (below 384 rows), N = 768, C32 pre-zeroed (the dgrad's contributions become fp32 atomics), no position
+ * rows (ln->dpos NULL); counters as for univl_gemm_ln; UNIVL_EUNSUPPORTED otherwise and in deterministic mode. */
+int univl_gemm_pair_ln(const UnivlGemm* dgrad, const UnivlGemm* wgrad, const UnivlLayerNorm* ln, int32_t* counters, int32_t dry_run,
+                       hipStream_t stream);
 /* Large-LDS opt-in of the rider kernels on the stream's device; call once outside any stream capture before the first captured rider. */
 int univl_gemm_rider_prime(hipStream_t stream);
 /* *ctr += 1 (device word; used for per-replay dropout seeds) */

@@ -196,11 +196,13 @@ def test_riding_weight_gradients_only_repackage_the_backward_plan(kw, kind, fres
                 (wgrads if (d.trans_a and d.trans_b and flat_off(d.C32) and flat_off(d.C32)[0] == "g32") else chain).append(("gemm",) + rec(d))
             elif kind_ == "group":
                 wgrads += [("gemm",) + rec(d) for d in plan.descs[i]]
-            elif kind_ == "pair":
+            elif kind_ in ("pair", "pair_ln"):
                 dg, wg = plan.descs[i]
                 chain.append(("gemm",) + rec(dg))
                 wgrads.append(("gemm",) + rec(wg))
                 pairs.append((dg, wg))
+                if kind_ == "pair_ln":           # the LayerNorm backward fed by this dgrad, finished inside the launch (round 4)
+                    chain.append(("univl_layernorm_bwd",))
             elif kind_ in ("call", "py", "eager"):
                 chain.append((name,))
         return chain, sorted(wgrads, key=repr), pairs
@@ -253,6 +255,13 @@ def test_adam_rider_plan_builds_on_cpu(monkeypatch):
         assert sorted(r[2] for r in riders if r[1] == key) == [0, 1, 2, 3]
     assert not base.fwd.rider_keys and len(ride.fwd.launches("univl_gemm")) == len(base.fwd.launches("univl_gemm"))
     assert [op[3] for op in ride.backward_plan(True).ops] == [op[3] for op in base.backward_plan(True).ops]
+    # ... and the backward twin: every LayerNorm backward of a stack but its topmost one rides in the pair launch of the dgrad that feeds it
+    bw = [op[3] for op in ride.backward_plan(True).ops]
+    assert bw.count("univl_gemm_pair_ln") == (2 * L_t - 1) + (2 * L_v - 1)
+    monkeypatch.setenv("UNIVL_LN_FOLD_BWD", "0")
+    bw0 = [op[3] for op in build_step(m, "joint", 2, 16, 16, True).backward_plan(True).ops]
+    monkeypatch.delenv("UNIVL_LN_FOLD_BWD")
+    assert bw0.count("univl_gemm_pair_ln") == 0 and bw0.count("univl_layernorm_bwd") == bw.count("univl_layernorm_bwd") + bw.count("univl_gemm_pair_ln")
 
 
 def test_stage_inputs_host_logic_on_cpu():

@@ -484,6 +484,61 @@ def test_gemm_ln_fold_matches_the_two_launches(M, K, ksplit, p_drop):
         univl_amd.set_deterministic(was)
 
 
+@pytest.mark.parametrize("T,K_out,ks,p_drop", [(192, 3072, 8, 0.1), (192, 2304, 6, 0.0), (100, 3072, 8, 0.1), (320, 768, 2, 0.1), (64, 2304, 6, 0.0)])
+def test_gemm_pair_ln_fold_matches_the_two_launches(T, K_out, ks, p_drop):
+    """univl_gemm_pair_ln (gemm.hip: ln_fold_bwd): the LayerNorm BACKWARD fed by a pair launch's dgrad product, finished by the dgrad's
+    last workgroups per 64-row block -- dx32 / dxd16 rows and the dgamma / dbeta / dbias column sums against univl_gemm_pair +
+    univl_layernorm_bwd on the same inputs (fp32 summation-order noise only: the dgrad slices meet in atomics, the column sums are
+    grouped by 8 rows instead of 4), the weight gradient bit for bit; 40 launches per case as a race screen, counters back at zero."""
+    import univl_amd
+    was = univl_amd.deterministic()
+    univl_amd.set_deterministic(False)
+    try:
+        H = 768
+        bf = torch.bfloat16
+        dY = gen(T, K_out, seed=1).to(DEV, bf)
+        W = gen(K_out, H, seed=2, scale=0.05).to(DEV, bf)
+        X = gen(T, H, seed=3).to(DEV, bf)
+        res = gen(T, H, seed=5).to(DEV)
+        gm = (1.0 + 0.1 * gen(H, seed=6)).to(DEV)
+        y = gen(T, H, seed=7).to(DEV)
+        stats = torch.stack([y.mean(1), 1.0 / (y.var(1, unbiased=False) + 1e-12).sqrt()], 1).contiguous()
+
+        def bufs():
+            return dict(da=torch.zeros(T, H, device=DEV), dx32=torch.zeros(T, H, device=DEV), dxd16=torch.zeros(T, H, device=DEV, dtype=bf),
+                        dgamma=torch.zeros(H, device=DEV), dbeta=torch.zeros(H, device=DEV), dbias=torch.zeros(H, device=DEV),
+                        dW=torch.zeros(K_out, H, device=DEV), db=torch.zeros(K_out, device=DEV))
+
+        def descs(b):
+            dg = ops.gemm_desc(dY, W, T, H, K_out, trans_b=True, out32=b["da"], residual=res, ksplit=ks)
+            wg = ops.gemm_desc(dY, X, K_out, H, T, trans_a=True, trans_b=True, out32=b["dW"], dbias=b["db"])
+            ln = ops.layernorm_desc(ops.dtype_code(bf), T, H, gamma=gm, y=y, stats=stats, dout=b["da"], dx32=b["dx32"], dxd16=b["dxd16"],
+                                    dgamma=b["dgamma"], dbeta=b["dbeta"], dbias=b["dbias"], p_pre=p_drop, seed=9, off_pre=2 << 40)
+            return dg, wg, ln
+
+        ref = bufs()
+        dg, wg, ln = descs(ref)
+        assert ops.gemm_pair(dg, wg)
+        _lib.check(_lib.lib().univl_layernorm_bwd(ops._BYREF(ln), ops._stream()), "layernorm_bwd")
+        torch.cuda.synchronize()
+        ctr = torch.zeros(2 * ((T + 63) // 64), dtype=torch.int32, device=DEV)
+        got = bufs()
+        dg2, wg2, ln2 = descs(got)
+        assert ops.gemm_pair_ln(dg2, wg2, ln2, ctr, dry_run=True)
+        for it in range(40):
+            for k in ("da", "dgamma", "dbeta", "dbias", "dW", "db"):
+                got[k].zero_()
+            assert ops.gemm_pair_ln(dg2, wg2, ln2, ctr)
+            assert int(ctr.abs().sum()) == 0, it
+            assert torch.equal(got["dW"], ref["dW"]), it
+            for k, t in (("da", 2e-5), ("dx32", 1e-4), ("dxd16", 1e-2), ("dgamma", 1e-4), ("dbeta", 1e-4), ("dbias", 1e-4), ("db", 1e-5)):
+                assert rel_err(got[k].float(), ref[k].float()) < t, (it, k, rel_err(got[k].float(), ref[k].float()))
+        univl_amd.set_deterministic(True)
+        assert not ops.gemm_pair_ln(dg2, wg2, ln2, ctr, dry_run=True)
+    finally:
+        univl_amd.set_deterministic(was)
+
+
 # --------------------------------------------------------------------------------------------- attention
 ATTN_CASES = [(2, 48, 48, False), (3, 20, 20, False), (2, 12, 12, False), (2, 96, 96, False), (2, 40, 56, False),
               (1, 128, 224, False), (2, 24, 24, True), (1, 128, 128, True), (1, 224, 224, False)]

@@ -677,12 +677,66 @@ int launch_group(const GroupArgs& g, int max_blocks, hipStream_t stream) {
 // the 8 XCDs; padded to a multiple of 8 so that the weight-gradient ids keep their own id % 8 = XCD relation), the weight-gradient
 // tiles follow.  No extra stream, no extra graph branch (every cross-branch edge of a hipGraph costs ~30 us here).
 // Both tile bodies are the 64 x 64 tile on 8 waves; NCW = K-step depth of the weight-gradient body (6: the 192-deep single step).
+// Arrival counters of the LayerNorm folds (ln_fold / ln_fold_bwd below): the last LN_SHARE workgroups to contribute to a 64-row block of a
+// product's output finish the LayerNorm work on that block.
+constexpr int LN_SHARE = 8;
+
+struct LnFold {
+    UnivlLayerNorm ln;
+    int* counters;
+};
+
 struct PairArgs {
     GemmArgs d, w;
     int nd, nd_pad, nw;
     int dnx, dny, dnz, wnx, wny, wnz;
     ColsumArgs cs;
 };
+
+// The arrival protocol shared by both folds: returns the slab (0 .. LN_SHARE - 1) of the 64-row block `by` this workgroup finishes, or
+// -1 (not one of the last LN_SHARE arrivals).  No agent-scope FENCE anywhere: __threadfence() is an L2 write-back plus an L2
+// invalidate of the whole XCD, per wave, in a launch whose other workgroups stream optimizer state and weight tiles through that L2
+// (measured: +70 us per launch, profiles/r04o_ab_ln_fold_with_agent_fences.txt).  The contributions are fp32 atomics (performed at
+// the device's coherence point; the host sets UNIVL_GEMM_ATOMIC for every fold launch), so "this thread's contributions are done" is
+// s_waitcnt vmcnt(0), and the rows are read back with agent-scope loads (ln_body.h: XC).
+__device__ __forceinline__ int fold_arrive(int* cnt, const int n) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // every thread's atomics are performed; the LDS stages are free from here on
+    int* slot = reinterpret_cast<int*>(smem_raw);
+    if (threadIdx.x == 0) slot[0] = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int arrival = slot[0];
+    if (arrival < n - LN_SHARE) return -1;
+    if (arrival != n - 1) {                            // the earlier ones of the last arrivals wait for the rest (all of them running)
+        if (threadIdx.x == 0) {
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+    }
+    asm volatile("" ::: "memory");
+    return arrival - (n - LN_SHARE);
+}
+
+__device__ __forceinline__ void fold_leave(int* cnt) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (__hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == LN_SHARE - 1) {
+            // every sharer is past its spin: ready for the next launch / graph replay
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// Backward twin (the dgrad half of a pair launch whose fp32 output is the upstream gradient `dout` of a LayerNorm backward,
+// module_bert.py:207-211 / 246-250 differentiated): the last arrivals of a row block run the LayerNorm backward of 8 rows each.
+__device__ __forceinline__ void ln_fold_bwd(const LnFold& f, const int by, const int n) {
+    int* cnt = f.counters + 2 * by;
+    const int slab = fold_arrive(cnt, n);
+    if (slab < 0) return;
+    ln_bwd_rows<768, __bf16, 8, true>(f.ln, by * 64 + slab * 8, reinterpret_cast<float*>(smem_raw));
+    fold_leave(cnt);
+}
 
 __host__ __device__ __forceinline__ void pair_tile(int t, int total, int nx, int ny, int nz, int flags, int gm, int& bx, int& by, int& bz) {
     if ((flags & UNIVL_GEMM_XCD_MAP) && total >= 16 && ny > 1) {
@@ -711,8 +765,8 @@ __host__ __device__ __forceinline__ void pair_tile(int t, int total, int nx, int
 //     workgroups behind the dgrad tiles (FFN: 288 instead of 576) staging 3/4 of the bytes: in the phase trace at 192 tokens
 //     (profiles/r04g_trace_gemm_phases.txt) the square weight-gradient tiles of the FFN1 / QKV pairs end 3 - 4 us after the dgrad
 //     chain they ride with (17.6 / 15.9 us per launch against 14.8 for the dgrad-bound FFN2 pair).
-template <bool DR, int WF>
-__global__ __launch_bounds__(512, (DR && WF == 2) ? 6 : 4) void gemm_pair_kernel(PairArgs a) {      // 4 waves per SIMD = two workgroups per compute unit
+template <bool DR, int WF, bool FOLD = false>
+__global__ __launch_bounds__(512, (DR && WF == 2) ? 6 : 4) void gemm_pair_kernel(PairArgs a, LnFold f) {      // 4 waves per SIMD = two workgroups per compute unit
     const int w0 = blockIdx.x;
     int bx, by, bz;
     if (w0 < a.nd_pad) {
@@ -720,6 +774,7 @@ __global__ __launch_bounds__(512, (DR && WF == 2) ? 6 : 4) void gemm_pair_kernel
         pair_tile(w0, a.nd, a.dnx, a.dny, a.dnz, a.d.flags, a.d.gm, bx, by, bz);
         if constexpr (DR) gemm_tile<__bf16, false, true, 64, 128, 2, 2, 4>(a.d, bx, by, bz, a.dnz);
         else gemm_tile<__bf16, false, true, 64, 64, 4, 2, 4>(a.d, bx, by, bz, a.dnz);
+        if constexpr (FOLD) ln_fold_bwd(f, by, a.dnx * a.dnz);
     } else if (w0 < a.nd_pad + a.cs.n_pad) {
         const int t = w0 - a.nd_pad;
         if (t >= a.cs.n_tiles) return;
@@ -733,16 +788,18 @@ __global__ __launch_bounds__(512, (DR && WF == 2) ? 6 : 4) void gemm_pair_kernel
     }
 }
 
-template <bool DR, int WF>
-int launch_pair(const PairArgs& a, hipStream_t stream) {
+template <bool DR, int WF, bool FOLD = false>
+int launch_pair(const PairArgs& a, hipStream_t stream, const LnFold* f = nullptr) {
     constexpr size_t smem_d = DR ? 2 * (size_t)(64 + 128) * 64 * sizeof(__bf16) : 2 * (size_t)(64 + 64) * 128 * sizeof(__bf16);
     constexpr size_t smem_w = WF == 0 ? 2 * (size_t)(64 + 64) * 128 * sizeof(__bf16)
                               : WF == 1 ? (size_t)(64 + 64) * 192 * sizeof(__bf16)
                               : WF == 2 ? 2 * (size_t)(128 + 64) * 64 * sizeof(__bf16) : (size_t)(128 + 64) * 192 * sizeof(__bf16);
-    constexpr size_t smem = smem_d > smem_w ? smem_d : smem_w;
+    constexpr size_t smem = smem_d > smem_w ? smem_d : smem_w;        // >= 8 x 768 floats: the fold's column-sum pass fits in it
+    static_assert(!FOLD || smem >= 8 * 768 * sizeof(float), "LayerNorm-backward fold needs 24 KB of LDS");
     static bool attr_done[UNIVL_MAX_DEVICES] = {};
-    univl_allow_lds(gemm_pair_kernel<DR, WF>, smem, attr_done);
-    hipLaunchKernelGGL((gemm_pair_kernel<DR, WF>), dim3(a.nd_pad + a.cs.n_pad + a.nw), dim3(512), smem, stream, a);
+    univl_allow_lds(gemm_pair_kernel<DR, WF, FOLD>, smem, attr_done);
+    LnFold none = {};
+    hipLaunchKernelGGL((gemm_pair_kernel<DR, WF, FOLD>), dim3(a.nd_pad + a.cs.n_pad + a.nw), dim3(512), smem, stream, a, f ? *f : none);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
@@ -776,43 +833,13 @@ __global__ __launch_bounds__(512, 2) void gemm_adam_kernel(GemmArgs g, int nd, i
 // workgroups that are already running.  What it buys: one kernel boundary (~3 us here) and one launch's fixed cost per LayerNorm on
 // a chain of ~190 dependent launches per step; what it costs: a counter round trip on the product's tail.
 // counters: two ints per row block (arrivals, finished sharers), zero before the first launch; the last sharer re-zeroes them.
-constexpr int LN_SHARE = 8;
-
-struct LnFold {
-    UnivlLayerNorm ln;
-    int* counters;
-};
-
 __device__ __forceinline__ void ln_fold(const LnFold& f, const int by, const int n, const int M) {
-    // No agent-scope FENCE anywhere: __threadfence() is an L2 write-back plus an L2 invalidate of the whole XCD, per wave, in a launch
-    // whose other workgroups stream optimizer state and weight tiles through that L2 (measured: +70 us per launch).  The contributions
-    // are fp32 atomics (performed at the device's coherence point; the host sets UNIVL_GEMM_ATOMIC for every fold launch), so "this
-    // thread's contributions are done" is s_waitcnt vmcnt(0), and the rows are read back with agent-scope loads (ln_fwd_row<XC>).
     int* cnt = f.counters + 2 * by;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                   // every thread's atomics are performed; the LDS stages are free from here on
-    int* slot = reinterpret_cast<int*>(smem_raw);
-    if (threadIdx.x == 0) slot[0] = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int arrival = slot[0];
-    if (arrival < n - LN_SHARE) return;
-    if (arrival != n - 1) {
-        if (threadIdx.x == 0) {
-            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) __builtin_amdgcn_s_sleep(1);
-        }
-        __syncthreads();
-    }
-    asm volatile("" ::: "memory");
-    const int row = by * 64 + (arrival - (n - LN_SHARE)) * 8 + (int)(threadIdx.x >> 6);
+    const int slab = fold_arrive(cnt, n);
+    if (slab < 0) return;
+    const int row = by * 64 + slab * 8 + (int)(threadIdx.x >> 6);
     if (row < M) ln_fwd_row<768, __bf16, false, true>(f.ln, row, (int)(threadIdx.x & 63));
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (__hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == LN_SHARE - 1) {
-            // every sharer is past its spin: ready for the next launch / graph replay
-            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    fold_leave(cnt);
 }
 
 template <bool NT>
@@ -1053,8 +1080,8 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
     return dispatch_trans<float, 64, 64, 4>(a, ta, tb, ksplit, stream);
 }
 
-extern "C" int univl_gemm_pair(const UnivlGemm* dgrad, const UnivlGemm* wgrad, int32_t dry_run, hipStream_t stream) {
-    UNIVL_ON_STREAM_DEVICE(stream);
+static int pair_impl(const UnivlGemm* dgrad, const UnivlGemm* wgrad, const UnivlLayerNorm* ln, int32_t* counters, int32_t dry_run,
+                     hipStream_t stream) {
     UNIVL_CHECK_ARG(dgrad != nullptr && wgrad != nullptr, UNIVL_EINVAL, "univl_gemm_pair: null descriptor");
     PairArgs a;
     int ksd, ksw;
@@ -1109,10 +1136,42 @@ extern "C" int univl_gemm_pair(const UnivlGemm* dgrad, const UnivlGemm* wgrad, i
         a.cs.n_pad = (a.cs.n_tiles + 7) / 8 * 8;
         a.w.dbias = nullptr;
     }
+    if (ln != nullptr) {
+        // the LayerNorm backward whose upstream gradient this dgrad produces, finished by the dgrad's last workgroups per 64-row block
+        // (ln_fold_bwd): square dgrad body only (below 384 tokens), fp32 output over N = 768 columns, pre-zeroed (atomics)
+        UNIVL_CHECK_ARG(!univl_deterministic() && !drect && counters != nullptr && dgrad->C32 && !dgrad->C16 && dgrad->N == 768 &&
+                            dgrad->ldc == 768 && !(dgrad->flags & (UNIVL_GEMM_GELU_FWD | UNIVL_GEMM_GELU_BWD | UNIVL_GEMM_ACCUM)) &&
+                            a.dnx * a.dnz >= LN_SHARE && ln->dtype == UNIVL_BF16 && ln->N == 768 && ln->rows == dgrad->M &&
+                            ln->dout == (const float*)dgrad->C32 && ln->gamma && ln->y && ln->stats && !ln->dpos &&
+                            (const void*)ln->dx32 != (const void*)dgrad->C32,
+                        UNIVL_EUNSUPPORTED, "univl_gemm_pair_ln: not a (dgrad, LayerNorm backward) pair this launch carries");
+        a.d.flags |= UNIVL_GEMM_ATOMIC;
+    }
     if (dry_run) return UNIVL_OK;
+    if (ln != nullptr) {
+        LnFold f;
+        f.ln = *ln;
+        f.counters = counters;
+        if (wrect) return wone ? launch_pair<false, 3, true>(a, stream, &f) : launch_pair<false, 2, true>(a, stream, &f);
+        return wone ? launch_pair<false, 1, true>(a, stream, &f) : launch_pair<false, 0, true>(a, stream, &f);
+    }
     if (drect) return wrect ? launch_pair<true, 2>(a, stream) : launch_pair<true, 0>(a, stream);
     if (wrect) return wone ? launch_pair<false, 3>(a, stream) : launch_pair<false, 2>(a, stream);
     return wone ? launch_pair<false, 1>(a, stream) : launch_pair<false, 0>(a, stream);
+}
+
+extern "C" int univl_gemm_pair(const UnivlGemm* dgrad, const UnivlGemm* wgrad, int32_t dry_run, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    return pair_impl(dgrad, wgrad, nullptr, nullptr, dry_run, stream);
+}
+
+// univl_gemm_pair with the LayerNorm BACKWARD that consumes the dgrad's fp32 output (ln->dout == dgrad->C32) finished inside the launch;
+// counters as for univl_gemm_ln.  UNIVL_EUNSUPPORTED where the launch does not carry it (callers: univl_gemm_pair + univl_layernorm_bwd).
+extern "C" int univl_gemm_pair_ln(const UnivlGemm* dgrad, const UnivlGemm* wgrad, const UnivlLayerNorm* ln, int32_t* counters,
+                                  int32_t dry_run, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    UNIVL_CHECK_ARG(ln != nullptr && counters != nullptr, UNIVL_EINVAL, "univl_gemm_pair_ln: null argument");
+    return pair_impl(dgrad, wgrad, ln, counters, dry_run, stream);
 }
 
 static const size_t RIDER_SMEM = 4 * (size_t)Tile<__bf16, false, 64, 128, 512>::BYTES;          // two stages of A and B

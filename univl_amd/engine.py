@@ -355,6 +355,14 @@ class Plan:
         self.descs[len(self.ops)] = [dgrad, wgrad]
         self.ops.append(("pair", fn, arr, "univl_gemm_pair", stream))
 
+    def add_gemm_pair_ln(self, dgrad, wgrad, ln_desc, counters, stream=0):
+        """add_gemm_pair with the LayerNorm BACKWARD that consumes the dgrad's fp32 output finished inside the launch
+        (univl_gemm_pair_ln); falls back to the two launches at run time where the library refuses (deterministic mode)."""
+        arr = (_lib.Gemm * 2)(dgrad, wgrad)
+        self.keep += [arr, ln_desc, counters]
+        self.descs[len(self.ops)] = [dgrad, wgrad]
+        self.ops.append(("pair_ln", _lib.lib().univl_gemm_pair_ln, (arr, ln_desc, counters), "univl_gemm_pair_ln", stream))
+
     def add_zeros(self, tensors, stream=0):
         """Clear several buffers with one launch (univl_zero_many)."""
         ts = [t for t in tensors if t is not None and t.numel() > 0]
@@ -465,6 +473,16 @@ class Plan:
                               or L_.univl_layernorm_fwd(C.byref(lnd), h))
                 if rc != 0:
                     _lib.check(rc, name)
+            elif kind == "pair_ln":
+                h = handles.get(sidx)
+                if h is None:
+                    h = handles[sidx] = C.c_void_p(self._stream(sidx, cur).cuda_stream)
+                arr, lnd, ctr = b
+                rc = a(C.byref(arr[0]), C.byref(arr[1]), C.byref(lnd), C.c_void_p(ctr.data_ptr()), 0, h)
+                if rc == _lib.EUNSUPPORTED:
+                    rc = _lib.lib().univl_gemm_pair(C.byref(arr[0]), C.byref(arr[1]), 0, h) or _lib.lib().univl_layernorm_bwd(C.byref(lnd), h)
+                if rc != 0:
+                    _lib.check(rc, name)
             elif kind == "pair":
                 h = handles.get(sidx)
                 if h is None:
@@ -567,6 +585,9 @@ class Plan:
                 out.append((lambda h, d=arg[0]: _lib.lib().univl_gemm(C.byref(d), h), self.descs[i]))
             elif kind == "pair" and name.startswith(prefix):
                 out.append((lambda h, fn=fn, arg=arg: fn(C.byref(arg[0]), C.byref(arg[1]), 0, h), self.descs[i]))
+            elif kind == "pair_ln" and name.startswith(prefix):
+                out.append((lambda h, fn=fn, arg=arg: fn(C.byref(arg[0][0]), C.byref(arg[0][1]), C.byref(arg[1]), C.c_void_p(arg[2].data_ptr()), 0, h),
+                            self.descs[i]))
             elif kind == "gemm_ln" and name.startswith(prefix):
                 out.append((lambda h, fn=fn, arg=arg: fn(C.byref(arg[0]), C.byref(arg[1]), C.c_void_p(arg[2].data_ptr()), None, 0, 0, 0, 0, h),
                             self.descs[i]))
@@ -691,6 +712,11 @@ class EncoderStack:
         self.yarena = e(n_layers, 2, T, H)
         self.garena = e(n_layers, 2, T, H)
         self.ln_ctr = torch.zeros(n_layers, 2, 2 * ((T + 63) // 64), dtype=torch.int32, device=dev) if self.ln_fold else None   # arrival counters of the folds (every launch leaves them zero)
+        # ... and the backward twin (Plan.add_gemm_pair_ln: the LayerNorm backward behind the FFN1 / QKV dgrad, square pair form: < 384 tokens).
+        # Measured (profiles/r04r_ab_ln_fold_bwd.txt, three interleaved pairs at 4 pairs): 2.231 vs 2.260 ms per step (-1.3 %; no fold at
+        # all: 2.357), 288 tokens 2.656 vs 2.665, FT-Align 3.144 vs 3.184, pretrain 9.66 vs 9.75.  UNIVL_LN_FOLD_BWD=0: two launches (A/B).
+        self.ln_fold_bwd = self.ln_fold and T < 384 and os.environ.get("UNIVL_LN_FOLD_BWD", "1") != "0"
+        self.ln_ctr_b = torch.zeros(n_layers, 2, 2 * ((T + 63) // 64), dtype=torch.int32, device=dev) if self.ln_fold_bwd else None
         for l in range(n_layers):
             ws = dict(qkv=e(T, 3 * H, dtype=ct), lse=e(B, self.NH, S), ctx=e(T, H, dtype=ct),
                       y1=self.yarena[l, 0], st1=e(T, 2), a32=e(T, H), u=e(T, I, dtype=ct), f=e(T, I, dtype=ct),
@@ -858,6 +884,7 @@ class EncoderStack:
         big_wgrad = self.bf and (T >= int(big_min) if big_min else ((T + 127) // 128) * ((H + 127) // 128) >= 256)
         wg_tile = dict(tile=128, stages=2, waves=4) if big_wgrad else {}
         pair_square = os.environ.get("UNIVL_PAIR_FORM", "") == "square"
+        ln2_folded = False
         for l in range(self.L - 1, -1, -1):
             ws, nm = self.layers[l], self._names(l)
             xin32, xin16 = (x0_32, x0_16) if l == 0 else (self.layers[l - 1]["o32"], self.layers[l - 1]["o16"])
@@ -868,23 +895,38 @@ class EncoderStack:
                 plan.join(sw + (l % 2), sm)             # layer l+2's weight gradients are done: this scratch set is free again
             dz, da = self.gbuf, self.garena[l, 0]
             ln_bwd = (lambda d: None) if self.probe_no_ln in ("bwd", "both") else (lambda d: plan.add("univl_layernorm_bwd", d, sm))
-            # output LayerNorm / dropout backward (BertOutput, module_bert.py:246-250)
-            ln_bwd(ops.layernorm_desc(
-                dt, T, H, gamma=fl.w32(nm["ln2_g"]), y=ws["y2"], stats=ws["st2"], dout=gin, dx32=dz, dxd16=s_dxd,
-                dgamma=fl.g(nm["ln2_g"]), dbeta=fl.g(nm["ln2_b"]), dbias=fl.g(nm["b2"]), p_pre=p, off_pre=ws["off"][2],
-                seed_dev=self.seed_dev))
+
+            def ln2_desc(_l, _gin):
+                """output LayerNorm / dropout backward of layer _l (BertOutput, module_bert.py:246-250)"""
+                _ws, _nm = self.layers[_l], self._names(_l)
+                return ops.layernorm_desc(
+                    dt, T, H, gamma=fl.w32(_nm["ln2_g"]), y=_ws["y2"], stats=_ws["st2"], dout=_gin, dx32=self.gbuf, dxd16=s_dxd,
+                    dgamma=fl.g(_nm["ln2_g"]), dbeta=fl.g(_nm["ln2_b"]), dbias=fl.g(_nm["b2"]), p_pre=p, off_pre=_ws["off"][2],
+                    seed_dev=self.seed_dev)
+
+            if not ln2_folded:               # (folded: the QKV pair launch of the layer above finished it, see the end of the loop body)
+                ln_bwd(ln2_desc(l, gin))
+            ln2_folded = False
             wgrads, colsums = [], []         # colsums: the bias gradients a big-tile group does not carry (issued after the group)
 
-            def emit(dgrad, wgrad):
+            def emit(dgrad, wgrad, lnd=None, site=0, _l=l):
                 """dgrad on the chain; its weight-gradient twin either into the layer's grouped launch (default) or into the
-                SAME launch (self.ride, where the C side accepts the pair: bf16, 64 x 64 tiles)."""
+                SAME launch (self.ride, where the C side accepts the pair: bf16, 64 x 64 tiles).  lnd: the LayerNorm backward that
+                consumes the dgrad's output -- finished inside the pair launch where the library carries it (returns True), else the
+                caller enqueues it."""
                 if pair_square:
                     dgrad.tile = 64          # A/B switch UNIVL_PAIR_FORM=square: an explicit tile keeps the 64 x 64 form of the pair launch
+                if (lnd is not None and self.ride and self.ln_fold_bwd and not self.probe_no_ln and
+                        _lib.lib().univl_gemm_pair_ln(C.byref(dgrad), C.byref(wgrad), C.byref(lnd),
+                                                      C.c_void_p(self.ln_ctr_b[_l, site].data_ptr()), 1, None) == 0):
+                    plan.add_gemm_pair_ln(dgrad, wgrad, lnd, self.ln_ctr_b[_l, site], sm)
+                    return True
                 if self.ride and _lib.lib().univl_gemm_pair(C.byref(dgrad), C.byref(wgrad), 1, None) == 0:
                     plan.add_gemm_pair(dgrad, wgrad, sm)
                 else:
                     plan.add("univl_gemm", dgrad, sm)
                     wgrads.append(wgrad)
+                return False
 
             w_ffn2 = _gemm_desc(dt, s_dxd, H, ws["f"], I, H, I, T, trans_a=1, trans_b=1,
                                 out32=fl.g(nm["w2"]), ldc=I, accumulate=gs.acc(nm["w2"]), nt_out=self.nt_wgrad, **wg_tile, **gs.sumsq_args(nm["w2"], H, I))
@@ -903,14 +945,15 @@ class EncoderStack:
                                 nt_out=self.nt_wgrad, **wg_tile, **gs.sumsq_args(nm["w1"], I, H))
             if sep_dbias:
                 colsums.append(lambda _du=s_du, _g=fl.g(nm["b1"]): ops.colsum(_du, _g))
-            emit(_gemm_desc(dt, s_du, I, fl.wop(nm["w1"]), H, T, H, I, trans_b=1, out32=da, ldc=H,
-                            residual=dz, ldr=H, ksplit=self.ksplit_for(I)), w_ffn1)
-            # attention-output LayerNorm / dropout backward (BertSelfOutput, module_bert.py:207-211)
+            # attention-output LayerNorm / dropout backward (BertSelfOutput, module_bert.py:207-211), fed by the FFN1 dgrad
             dy = self.gbuf
-            ln_bwd(ops.layernorm_desc(
+            ln1 = ops.layernorm_desc(
                 dt, T, H, gamma=fl.w32(nm["ln1_g"]), y=ws["y1"], stats=ws["st1"], dout=da, dx32=dy, dxd16=s_dxd2,
                 dgamma=fl.g(nm["ln1_g"]), dbeta=fl.g(nm["ln1_b"]), dbias=fl.g(nm["o_b"]), p_pre=p, off_pre=ws["off"][1],
-                seed_dev=self.seed_dev))
+                seed_dev=self.seed_dev)
+            if not emit(_gemm_desc(dt, s_du, I, fl.wop(nm["w1"]), H, T, H, I, trans_b=1, out32=da, ldc=H,
+                                   residual=dz, ldr=H, ksplit=self.ksplit_for(I)), w_ffn1, ln1, 0):
+                ln_bwd(ln1)
             w_o = _gemm_desc(dt, s_dxd2, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
                              out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"]), nt_out=self.nt_wgrad, **wg_tile, **gs.sumsq_args(nm["o_w"], H, H))
             emit(_gemm_desc(dt, s_dxd2, H, fl.wop(nm["o_w"]), H, T, H, H, trans_b=1, out16=self.dctx, ldc=H), w_o)
@@ -926,8 +969,10 @@ class EncoderStack:
             if sep_dbias:
                 colsums.append(lambda _d=dqkv, _g=fl.g_fused(nm["qkv_b"]): ops.colsum(_d, _g.view(-1)))
             dx = self.garena[l, 1]
-            emit(_gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["qkv_w"]), H, T, H, 3 * H, trans_b=1,
-                            out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ksplit_for(3 * H)), w_qkv)
+            # ... the QKV dgrad feeds the output LayerNorm backward of the layer BELOW (next iteration)
+            ln2_folded = emit(_gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["qkv_w"]), H, T, H, 3 * H, trans_b=1,
+                                         out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ksplit_for(3 * H)), w_qkv,
+                                      ln2_desc(l - 1, dx) if l > 0 else None, 1)
             # the layer's four weight-gradient GEMMs only consume tensors the chain above produced (dxd, du, dxd2, dqkv
             # are distinct buffers): one grouped launch, after which the scratch may be reused by the next layer
             ws_stream = sm

@@ -113,6 +113,15 @@ def gemm_ln(gemm, ln, counters, dry_run=False):
     return True
 
 
+def gemm_pair_ln(dgrad, wgrad, ln, counters, dry_run=False):
+    """univl_gemm_pair with the LayerNorm backward fed by the dgrad's fp32 output finished inside the launch (univl_gemm_pair_ln)."""
+    rc = _lib.lib().univl_gemm_pair_ln(_BYREF(dgrad), _BYREF(wgrad), _BYREF(ln), C.c_void_p(counters.data_ptr()), int(bool(dry_run)), _stream())
+    if rc == _lib.EUNSUPPORTED:
+        return False
+    _lib.check(rc, "gemm_pair_ln")
+    return True
+
+
 def layernorm_desc(dtype, rows, N, *, x=None, x_f64=False, residual=None, pos=None, pos_period=0, gamma=None,
                    beta=None, eps=1e-12, y=None, stats=None, out32=None, out16=None, p_pre=0.0, p_post=0.0, seed=0,
                    off_pre=0, off_post=0, seed_dev=None, dout=None, dx32=None, dxd32=None, dxd16=None, dgamma=None,
