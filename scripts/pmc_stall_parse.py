@@ -9,7 +9,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(gemm_group_kernel|gemm_pair_kernel|gemm_kernel|attn_fwd_kernel|attn_bwd_kernel|ln_fwd_kernel|ln_bwd_kernel|adam_apply_kernel)", name)
+    m = re.search(r"(gemm_group_kernel|gemm_pair_kernel|gemm_ln_kernel|gemm_adam_kernel|gemm_kernel|attn_fwd_kernel|attn_bwd_kernel|ln_fwd_kernel|ln_bwd_kernel|adam_apply_kernel)", name)
     if not m:
         return "other"
     k = m.group(1)
