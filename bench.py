@@ -234,16 +234,25 @@ def respawn_under_launcher(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def gemm_family(model, dev, reps=10):
+def gemm_family(model, dev, reps=10, carried=False):
     """Replays ONLY the GEMM launches of one training step (forward + backward plan of the compiled step), in plan order on
-    one stream, as a hipGraph; HIP events around `reps` replays.  Algorithmic work comes from the launch descriptors."""
+    one stream, as a hipGraph; HIP events around `reps` replays.  Algorithmic work comes from the launch descriptors.
+    carried=False: every product alone (no optimizer chunks, no folded LayerNorm: the dense contractions, comparable with rounds
+    1-3); carried=True: the launches with the LayerNorm they finish in the step (round 4: univl_gemm_ln / univl_gemm_pair_ln),
+    whose rows then count as algorithmic bytes of the launch."""
     from univl_amd import _lib
     st = next(v for v in model._steps.values() if getattr(v, "kind", None) in ("joint", "align", "caption", "pretrain") and v.cx.training)
-    items = st.fwd.launches("univl_gemm") + st.backward_plan(True).launches("univl_gemm")
+    items = st.fwd.launches("univl_gemm", carried) + st.backward_plan(True).launches("univl_gemm", carried)
     flops = nbytes = wbytes = 0
-    ndesc = 0
+    ndesc = nfold = 0
     for _, descs in items:
         for d in descs:
+            if isinstance(d, _lib.LayerNorm):
+                # rows the folded LayerNorm moves: forward x, residual, y, out32 (fp32) + out16; backward dout, y, dx32 (fp32) + dxd16
+                nfold += 1
+                nbytes += d.rows * d.N * ((12 + (4 if d.out32 else 0) + (2 if d.out16 else 0)) if not d.dout
+                                          else (8 + (4 if d.dx32 else 0) + (2 if d.dxd16 else 0)))
+                continue
             esz = 2 if d.dtype == _lib.DT_BF16 else 4
             ndesc += 1
             flops += 2.0 * d.M * d.N * d.K
@@ -274,7 +283,7 @@ def gemm_family(model, dev, reps=10):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    return dict(launches=len(items), gemms=ndesc, family_ms_per_step=round(ms, 4), avg_launch_ms=round(ms / len(items), 5),
+    return dict(launches=len(items), gemms=ndesc, folded_layernorms=nfold, family_ms_per_step=round(ms, 4), avg_launch_ms=round(ms / len(items), 5),
                 algorithmic_bytes_per_step=int(nbytes), weight_bytes_per_step=int(wbytes), flops_per_step=flops)
 
 
@@ -496,6 +505,19 @@ def main():
                     avg_launch_ms=round(upd_ms, 4))
         # ---- the GEMM family of one step, replayed alone
         fam = gemm_family(model, dev)
+        # the same launches as they RUN in the step where they also finish the LayerNorm behind the product (round 4, K8 / K10): slower
+        # alone than the bare products (the fold's tail -- three dependent round trips -- replaces a kernel boundary and a launch that
+        # this replay never contained), with the LayerNorm rows counted as algorithmic bytes; None when the plan folds nothing
+        as_run = None
+        try:
+            fr = gemm_family(model, dev, carried=True)
+            if fr["folded_layernorms"]:
+                as_run = dict(folded_layernorms=fr["folded_layernorms"], family_ms_per_step=fr["family_ms_per_step"],
+                              algorithmic_bytes_per_step=fr["algorithmic_bytes_per_step"],
+                              hbm_frac=round(fr["algorithmic_bytes_per_step"] / (fr["family_ms_per_step"] * 1e-3) / 8.0e12, 4),
+                              note="the family's launches with the LayerNorms they finish in the step; `frac` above is the bare products, as in rounds 1-3")
+        except Exception as ex:   # noqa: BLE001
+            as_run = dict(error=str(ex)[:200])
         fam_s = fam["family_ms_per_step"] * 1e-3
         hbm_frac = fam["algorithmic_bytes_per_step"] / fam_s / 8.0e12
         mfma_frac = fam["flops_per_step"] / fam_s / 2.5e15
@@ -532,8 +554,10 @@ def main():
             launches_per_step=fam["launches"], gemms_per_step=fam["gemms"], family_ms_per_step=fam["family_ms_per_step"],
             avg_launch_ms=fam["avg_launch_ms"], algorithmic_bytes_per_launch=int(fam["algorithmic_bytes_per_step"] / fam["launches"]),
             algorithmic_bytes_per_step=fam["algorithmic_bytes_per_step"], flops_per_step=fam["flops_per_step"],
-            how="the step's GEMM launches replayed alone, in plan order on one stream, as a hipGraph; HIP events; includes the "
-                "dependent-launch gaps between them (the rocprofv3 kernel-trace sum under profiles/ excludes them)",
+            how="the step's GEMM launches replayed alone (each product without the optimizer chunks / LayerNorm it carries in the step), "
+                "in plan order on one stream, as a hipGraph; HIP events; includes the dependent-launch gaps between them (the "
+                "rocprofv3 kernel-trace sum under profiles/ excludes them); `as_run`: the same with the folded LayerNorms",
+            as_run=as_run,
             adam=adam,
             step=dict(flops_per_pair=gflop_row * 1e9, achieved_tflops=round(pairs_per_s * gflop_row * 1e9 / 1e12 / world, 2),
                       mfma_frac=round(pairs_per_s * gflop_row * 1e9 / world / 2.5e15, 4), hbm_bytes_per_step=step_bytes,

@@ -571,9 +571,12 @@ class Plan:
                 seg[2] = g
             seg[2].replay()
 
-    def launches(self, prefix):
+    def launches(self, prefix, carried=False):
         """[(launch(stream_handle), [descriptors])] for every planned launch whose entry point starts with `prefix`, in plan
-        order -- bench.py replays one kernel family alone to time it with HIP events."""
+        order -- bench.py replays one kernel family alone to time it with HIP events.  A product that CARRIES other work in the step
+        (optimizer chunks: add_gemm_rider; the LayerNorm behind it: add_gemm_ln / add_gemm_pair_ln) is replayed without it by
+        default -- the dense contraction alone, the quantity rounds 1-3 report -- and with its LayerNorm when carried=True (the
+        descriptor list then ends with that LayerNorm descriptor; optimizer chunks never replay: they would change the parameters)."""
         out = []
         for i, op in enumerate(self.ops):
             kind, fn, arg, name, _ = op
@@ -586,11 +589,17 @@ class Plan:
             elif kind == "pair" and name.startswith(prefix):
                 out.append((lambda h, fn=fn, arg=arg: fn(C.byref(arg[0]), C.byref(arg[1]), 0, h), self.descs[i]))
             elif kind == "pair_ln" and name.startswith(prefix):
-                out.append((lambda h, fn=fn, arg=arg: fn(C.byref(arg[0][0]), C.byref(arg[0][1]), C.byref(arg[1]), C.c_void_p(arg[2].data_ptr()), 0, h),
-                            self.descs[i]))
+                if carried:
+                    out.append((lambda h, fn=fn, arg=arg: fn(C.byref(arg[0][0]), C.byref(arg[0][1]), C.byref(arg[1]), C.c_void_p(arg[2].data_ptr()), 0, h),
+                                self.descs[i] + [arg[1]]))
+                else:
+                    out.append((lambda h, arg=arg: _lib.lib().univl_gemm_pair(C.byref(arg[0][0]), C.byref(arg[0][1]), 0, h), self.descs[i]))
             elif kind == "gemm_ln" and name.startswith(prefix):
-                out.append((lambda h, fn=fn, arg=arg: fn(C.byref(arg[0]), C.byref(arg[1]), C.c_void_p(arg[2].data_ptr()), None, 0, 0, 0, 0, h),
-                            self.descs[i]))
+                if carried:
+                    out.append((lambda h, fn=fn, arg=arg: fn(C.byref(arg[0]), C.byref(arg[1]), C.c_void_p(arg[2].data_ptr()), None, 0, 0, 0, 0, h),
+                                self.descs[i] + [arg[1]]))
+                else:
+                    out.append((lambda h, d=arg[0]: _lib.lib().univl_gemm(C.byref(d), h), self.descs[i]))
         return out
 
     @property
