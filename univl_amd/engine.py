@@ -801,8 +801,8 @@ class EncoderStack:
         p = self.p if training else 0.0
         if self.probe_skip:
             return
-        if self.any_split and zero_arena:
-            plan.add_callable(self.yarena.zero_, stream=sm)
+        if zero_arena:
+            plan.add_zeros(([self.yarena] if self.any_split else []) + ([self.ln_ctr] if self.ln_ctr is not None else []), sm)
         for l, ws in enumerate(self.layers):
             nm = self._names(l)
             plan.wait_point(("layer", self.prefix, l), sm)
@@ -877,8 +877,8 @@ class EncoderStack:
         self.bwd_out = gin
         if self.probe_skip:
             return
-        if self.any_split and zero_arena:
-            plan.add_callable(self.garena.zero_, stream=sm)
+        if zero_arena:
+            plan.add_zeros(([self.garena] if self.any_split else []) + ([self.ln_ctr_b] if self.ln_ctr_b is not None else []), sm)
         sw = self.sw
         # Weight gradients over thousands of tokens (UNIVL_WGRAD_BIG_MIN, bf16): the layer's grouped launch on the 128 x 128 tile
         # (two stages, 4 waves) with the two bias gradients it used to carry on a column-sum kernel instead.  The column-0

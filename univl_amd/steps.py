@@ -140,7 +140,10 @@ class EncoderPass:
         cx, n, fl, dt, bf = self.cx, self.N, self.cx.fl, self.cx.dt, self.cx.bf
         W32, p, B, W, F, D, Tv = fl.w32, cx.p, self.B, self.W, self.F, self.D, self.Tv
         ST, SV = self.ST, self.SV
-        fwd.add_zeros([st.yarena for st in (self.text, self.vis) if st.any_split], ST)      # split-K accumulation targets
+        # split-K accumulation targets; and the arrival counters of the LayerNorm folds (every launch leaves them zero: clearing them with
+        # the arenas, in the same launch, only makes a step self-healing after a launch that did not complete)
+        fwd.add_zeros([st.yarena for st in (self.text, self.vis) if st.any_split] +
+                      [st.ln_ctr for st in (self.text, self.vis) if st.ln_ctr is not None], ST)
         cx.stamp(fwd, "f_fork", ST)
         fwd.fork(ST, SV)           # the video encoder runs concurrently with the text encoder
         cx.stamp(fwd, "f_vis_start", SV)
@@ -170,7 +173,8 @@ class EncoderPass:
 
     def zero_list(self):
         """Accumulation buffers a backward clears before anything adds into them."""
-        return [self.dseq, self.dvis, self.dvnorm] + [st.garena for st in (self.text, self.vis) if st.any_split]
+        return ([self.dseq, self.dvis, self.dvnorm] + [st.garena for st in (self.text, self.vis) if st.any_split] +
+                [st.ln_ctr_b for st in (self.text, self.vis) if st.ln_ctr_b is not None])
 
     def build_backward(self, bwd, gs, hook=None):
         """Consumes self.dseq / self.dvis (+ whatever was accumulated into self.dvnorm)."""
