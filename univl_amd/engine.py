@@ -810,6 +810,8 @@ class EncoderStack:
 
             def gemm(desc, _l=l, _slot=slot):
                 """a forward product of layer l; with self.adam_ride it can carry a quarter of layer l + 1's optimizer chunks.
+                (Equal quarters: with the LayerNorm folds two of the four carrying launches end in a latency-bound tail, but giving them
+                a larger share -- or a smaller one -- changes nothing: 2.26 - 2.29 vs 2.23 / 2.27 ms, profiles/r04u_ab_rider_shares.txt.)
                 (Round 4, measured and removed: riders ONE LAUNCH ahead instead of one layer ahead -- product k of layer l carrying
                 quarter k + 1 of its own layer, so that only the first quarter of a stack's first layer is left to the launches in
                 front of the forward: bit-identical, 2.405 / 2.436 / 2.406 vs 2.422 / 2.374 / 2.408 ms per step at 4 pairs,
