@@ -539,6 +539,86 @@ def test_gemm_pair_ln_fold_matches_the_two_launches(T, K_out, ks, p_drop):
         univl_amd.set_deterministic(was)
 
 
+def test_layernorm_folds_under_concurrent_hbm_traffic():
+    """The folds' hand-over has no fence: contributions are fp32 atomics, "done" is s_waitcnt vmcnt(0) before the ticket, the rows come
+    back through agent-scope loads.  Stress form of the race screens above: 400 forward and 400 backward fold launches at the 4-pair
+    shapes while a second stream saturates HBM with 256 MB copies (what the riding optimizer chunks and the other encoder branch do
+    to these launches in the step); every launch is compared with the two-launch reference."""
+    import univl_amd
+    was = univl_amd.deterministic()
+    univl_amd.set_deterministic(False)
+    try:
+        bf, H, T, I = torch.bfloat16, 768, 192, 3072
+        a = gen(T, I, seed=1).to(DEV, bf)
+        w = gen(H, I, seed=2, scale=I ** -0.5).to(DEV, bf)
+        bias, res = gen(H, seed=3).to(DEV), gen(T, H, seed=4).to(DEV)
+        gm, bt = (1.0 + 0.1 * gen(H, seed=5)).to(DEV), gen(H, seed=6).to(DEV)
+        dY = gen(T, I, seed=7).to(DEV, bf)
+        W1 = gen(I, H, seed=8, scale=0.05).to(DEV, bf)
+        X = gen(T, H, seed=9).to(DEV, bf)
+        y = gen(T, H, seed=10).to(DEV)
+        stats = torch.stack([y.mean(1), 1.0 / (y.var(1, unbiased=False) + 1e-12).sqrt()], 1).contiguous()
+
+        def fwd_bufs():
+            return dict(x=torch.zeros(T, H, device=DEV), stats=torch.zeros(T, 2, device=DEV), out32=torch.zeros(T, H, device=DEV),
+                        out16=torch.zeros(T, H, device=DEV, dtype=bf))
+
+        def fwd_descs(b):
+            return (ops.gemm_desc(a, w, T, H, I, out32=b["x"], bias=bias, ksplit=8),
+                    ops.layernorm_desc(ops.dtype_code(bf), T, H, x=b["x"], residual=res, gamma=gm, beta=bt, y=b["x"], stats=b["stats"],
+                                       out32=b["out32"], out16=b["out16"], p_pre=0.1, seed=7, off_pre=3 << 40))
+
+        def bwd_bufs():
+            return dict(da=torch.zeros(T, H, device=DEV), dx32=torch.zeros(T, H, device=DEV), dxd16=torch.zeros(T, H, device=DEV, dtype=bf),
+                        dgamma=torch.zeros(H, device=DEV), dbeta=torch.zeros(H, device=DEV), dbias=torch.zeros(H, device=DEV),
+                        dW=torch.zeros(I, H, device=DEV), db=torch.zeros(I, device=DEV))
+
+        def bwd_descs(b):
+            return (ops.gemm_desc(dY, W1, T, H, I, trans_b=True, out32=b["da"], residual=res, ksplit=8),
+                    ops.gemm_desc(dY, X, I, H, T, trans_a=True, trans_b=True, out32=b["dW"], dbias=b["db"]),
+                    ops.layernorm_desc(ops.dtype_code(bf), T, H, gamma=gm, y=y, stats=stats, dout=b["da"], dx32=b["dx32"], dxd16=b["dxd16"],
+                                       dgamma=b["dgamma"], dbeta=b["dbeta"], dbias=b["dbias"], p_pre=0.1, seed=9, off_pre=2 << 40))
+
+        rf = fwd_bufs()
+        g, ln = fwd_descs(rf)
+        _lib.check(_lib.lib().univl_gemm(ops._BYREF(g), ops._stream()), "gemm")
+        _lib.check(_lib.lib().univl_layernorm_fwd(ops._BYREF(ln), ops._stream()), "layernorm_fwd")
+        rb = bwd_bufs()
+        dg, wg, lb = bwd_descs(rb)
+        assert ops.gemm_pair(dg, wg)
+        _lib.check(_lib.lib().univl_layernorm_bwd(ops._BYREF(lb), ops._stream()), "layernorm_bwd")
+        torch.cuda.synchronize()
+        gf, gb = fwd_bufs(), bwd_bufs()
+        g2, ln2 = fwd_descs(gf)
+        dg2, wg2, lb2 = bwd_descs(gb)
+        cf = torch.zeros(2 * ((T + 63) // 64), dtype=torch.int32, device=DEV)
+        cb = torch.zeros_like(cf)
+        big_a, big_b = torch.empty(64 << 20, device=DEV), torch.empty(64 << 20, device=DEV)      # 256 MB each
+        side = torch.cuda.Stream()
+        worst = dict(out32=0.0, dx32=0.0, dgamma=0.0)
+        for it in range(400):
+            if it % 8 == 0:
+                with torch.cuda.stream(side):
+                    for _ in range(6):
+                        big_b.copy_(big_a)                                                            # ~3 GB of HBM traffic per burst
+            gf["x"].zero_()
+            assert ops.gemm_ln(g2, ln2, cf)
+            for k in ("da", "dgamma", "dbeta", "dbias", "dW", "db"):
+                gb[k].zero_()
+            assert ops.gemm_pair_ln(dg2, wg2, lb2, cb)
+            if it % 4 == 3:
+                worst["out32"] = max(worst["out32"], rel_err(gf["out32"], rf["out32"]))
+                worst["dx32"] = max(worst["dx32"], rel_err(gb["dx32"], rb["dx32"]))
+                worst["dgamma"] = max(worst["dgamma"], rel_err(gb["dgamma"], rb["dgamma"]))
+                assert int(cf.abs().sum()) == 0 and int(cb.abs().sum()) == 0, it
+                assert worst["out32"] < 2e-5 and worst["dx32"] < 1e-4 and worst["dgamma"] < 1e-4, (it, worst)
+                assert torch.equal(gb["dW"], rb["dW"]), it
+        side.synchronize()
+        print("[fold stress] worst relative errors over 400 + 400 launches under load:", worst)
+    finally:
+        univl_amd.set_deterministic(was)
+
+
 # --------------------------------------------------------------------------------------------- attention
 ATTN_CASES = [(2, 48, 48, False), (3, 20, 20, False), (2, 12, 12, False), (2, 96, 96, False), (2, 40, 56, False),
               (1, 128, 224, False), (2, 24, 24, True), (1, 128, 128, True), (1, 224, 224, False)]
