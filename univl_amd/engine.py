@@ -656,33 +656,21 @@ class EncoderStack:
 
     H, NH, I = 768, 12, 3072
 
-    def __init__(self, flat, prefix, n_layers, B, S, key_mask, p_drop, seed_dev, sites, splitk=True, s_main=0, s_side=1,
-                 s_wgrad=None, s_offload=None, n_offload=0):
-        """s_offload / n_offload: the grouped weight-gradient launch of the first n_offload layers to be processed (the LAST
-        layers of the stack) is enqueued on stream s_offload -- the other encoder stack's stream, which has slack: the video
-        stack is half as deep as the text stack -- instead of the stack's own chain.  Those layers keep their four wgrad
-        operands in buffers of their own (nothing waits for a scratch set to be free again).
-
-        s_wgrad / UNIVL_WGRAD_BLOCKS (EXPERIMENTAL, off): "background" weight gradients -- a layer's grouped weight-gradient
-        launch capped at that many workgroups on two alternating side streams beside the next layer's dgrad chain, its four
-        operands in two alternating scratch sets.  Runs correctly when enqueued directly; capturing that fork / join
-        pattern into a hipGraph crashes inside hipStreamEndCapture on ROCm 7.0.2 (profiles/README.md, round 2), and the
-        step is only fast as a graph, so it stays off."""
+    def __init__(self, flat, prefix, n_layers, B, S, key_mask, p_drop, seed_dev, sites, splitk=True, s_main=0, s_side=1):
+        """(Measured and removed, numbers in DESIGN.md section 8: a layer's weight gradients on the OTHER stack's stream
+        (UNIVL_WGRAD_OFFLOAD), "background" weight gradients capped at n workgroups on two alternating side streams
+        (UNIVL_WGRAD_BLOCKS: correct when enqueued directly, crashes hipStreamEndCapture on ROCm 7.0.2), non-temporal stores of
+        fresh weight gradients (UNIVL_WGRAD_NT), bias-gradient column sums as launches of their own (UNIVL_DBIAS_COLSUM_MIN,
+        UNIVL_COLSUM_ON_CHAIN) -- since round 2 every weight gradient rides with its dgrad or sits in the layer's grouped launch.)"""
         self.flat, self.prefix, self.L, self.B, self.S = flat, prefix, n_layers, B, S
         self.sm, self.ss = s_main, s_side
-        self.wg_blocks = int(os.environ.get("UNIVL_WGRAD_BLOCKS", "0"))
-        self.nt_wgrad = os.environ.get("UNIVL_WGRAD_NT", "0") == "1"       # non-temporal stores of fresh weight gradients (A/B: no gain)
-        self.sw = s_wgrad if (s_wgrad is not None and self.wg_blocks > 0 and n_layers > 1) else None
-        self.s_off = s_offload if (s_offload is not None and n_offload > 0 and self.sw is None) else None
-        self.n_off = min(int(n_offload), n_layers) if self.s_off is not None else 0
         # Every weight-gradient GEMM rides in the launch of the dgrad GEMM that consumes the same upstream gradient
         # (Plan.add_gemm_pair) instead of the layer's grouped launch at the end of the chain: the grouped launch was the longest
         # node of the backward chain (29 of ~100 us per layer at 4 pairs) although nothing downstream waits for it, and the dgrad
         # kernels it now shares a launch with leave most compute units idle.  Measured 2.85 vs 3.11 ms per step at 4 pairs
         # (profiles/r02h_ab_wgrad_ride.txt).  bf16, 64 x 64 tiles only -- the C side refuses other pairs (univl_gemm_pair dry run)
         # and those weight gradients stay in the grouped launch.  UNIVL_WGRAD_RIDE=0: the grouped launch for all of them.
-        self.ride = (os.environ.get("UNIVL_WGRAD_RIDE", "1") == "1" and flat.compute_dtype == torch.bfloat16
-                     and self.sw is None and self.s_off is None)
+        self.ride = os.environ.get("UNIVL_WGRAD_RIDE", "1") == "1" and flat.compute_dtype == torch.bfloat16
         # The forward products of layer l can carry the BertAdam chunks of layer l + 1 (Plan.add_gemm_rider): switched on per model by
         # graphed.GraphedTrainStep(pipeline_optimizer=True) (flat.adam_ride), or for every model by UNIVL_ADAM_RIDE=1.
         # All passes of a stack through its layers in one forward (text / video: clean + masked pass; cross: up to three runs) are
@@ -738,10 +726,8 @@ class EncoderStack:
         self.gbuf = e(T, H)
         self.dctx = e(T, H, dtype=ct)
         # operands of the weight-gradient GEMMs: dxd = grad wrt the FFN2 output, dxd2 = grad wrt the attention-output
-        # projection (separate buffers: the four wgrads of a layer are one grouped launch), du, dqkv.  Two sets when the
-        # weight gradients of layer l run while layer l-1's chain already produces its own.
-        self.scr = [dict(dxd=e(T, H, dtype=ct), dxd2=e(T, H, dtype=ct), du=e(T, I, dtype=ct), dqkv=e(T, 3 * H, dtype=ct))
-                    for _ in range(2 if self.sw is not None else 1 + self.n_off)]
+        # projection (separate buffers: the four wgrads of a layer may be one grouped launch), du, dqkv
+        self.scr = dict(dxd=e(T, H, dtype=ct), dxd2=e(T, H, dtype=ct), du=e(T, I, dtype=ct), dqkv=e(T, 3 * H, dtype=ct))
         # split-K of the products with H-wide outputs (N = 768: attention output, FFN2, and the dgrads of QKV / FFN1):
         #   * below 128 output tiles (a few hundred tokens) every one of them is split into ~384-deep slices -- the grid would not fill
         #     the chip otherwise (UNIVL_SPLITK_TILES / _LEN / _MAXWG, measured in rounds 1-3);
@@ -881,7 +867,6 @@ class EncoderStack:
             return
         if zero_arena:
             plan.add_zeros(([self.garena] if self.any_split else []) + ([self.ln_ctr_b] if self.ln_ctr_b is not None else []), sm)
-        sw = self.sw
         # Weight gradients over thousands of tokens (UNIVL_WGRAD_BIG_MIN, bf16): the layer's grouped launch on the 128 x 128 tile
         # (two stages, 4 waves) with the two bias gradients it used to carry on a column-sum kernel instead.  The column-0
         # workgroups of a product with a fused bias gradient walk their staged A tile element by element every K step; with
@@ -899,11 +884,8 @@ class EncoderStack:
         for l in range(self.L - 1, -1, -1):
             ws, nm = self.layers[l], self._names(l)
             xin32, xin16 = (x0_32, x0_16) if l == 0 else (self.layers[l - 1]["o32"], self.layers[l - 1]["o16"])
-            off = self.s_off is not None and (self.L - 1 - l) < self.n_off       # this layer's wgrads go to the other stream
-            sc = self.scr[1 + (self.L - 1 - l)] if off else self.scr[l % len(self.scr) if sw is not None else 0]
+            sc = self.scr
             s_dxd, s_dxd2, s_du, s_dqkv = sc["dxd"], sc["dxd2"], sc["du"], sc["dqkv"]
-            if sw is not None and l + 2 < self.L:
-                plan.join(sw + (l % 2), sm)             # layer l+2's weight gradients are done: this scratch set is free again
             dz, da = self.gbuf, self.garena[l, 0]
             ln_bwd = (lambda d: None) if self.probe_no_ln in ("bwd", "both") else (lambda d: plan.add("univl_layernorm_bwd", d, sm))
 
@@ -918,7 +900,7 @@ class EncoderStack:
             if not ln2_folded:               # (folded: the QKV pair launch of the layer above finished it, see the end of the loop body)
                 ln_bwd(ln2_desc(l, gin))
             ln2_folded = False
-            wgrads, colsums = [], []         # colsums: the bias gradients a big-tile group does not carry (issued after the group)
+            wgrads = []                      # the weight gradients that do not ride with their dgrad: the layer's grouped launch
 
             def emit(dgrad, wgrad, lnd=None, site=0, _l=l):
                 """dgrad on the chain; its weight-gradient twin either into the layer's grouped launch (default) or into the
@@ -940,22 +922,15 @@ class EncoderStack:
                 return False
 
             w_ffn2 = _gemm_desc(dt, s_dxd, H, ws["f"], I, H, I, T, trans_a=1, trans_b=1,
-                                out32=fl.g(nm["w2"]), ldc=I, accumulate=gs.acc(nm["w2"]), nt_out=self.nt_wgrad, **wg_tile, **gs.sumsq_args(nm["w2"], H, I))
+                                out32=fl.g(nm["w2"]), ldc=I, accumulate=gs.acc(nm["w2"]), **wg_tile, **gs.sumsq_args(nm["w2"], H, I))
             emit(_gemm_desc(dt, s_dxd, H, fl.wop(nm["w2"]), I, T, I, H, trans_b=1, out16=s_du,
                             ldc=I, aux=ws["u"], ldaux=I, gelu="bwd"), w_ffn2)
-            # Bias gradients of the two projections whose upstream gradient no LayerNorm kernel sees (FFN1, QKV): column sums of
-            # du / dqkv, taken by the weight-gradient GEMM from the operand tiles it stages anyway.  UNIVL_DBIAS_COLSUM_MIN = n:
-            # from n tokens on a separate column-sum kernel instead (measured at 6144 tokens, round 3: 13.88 / 13.93 vs 13.92 ms
-            # per step -- the per-thread LDS walk of the column-0 workgroups is not what bounds that product; off).
-            # Round 4: on the big-tile plan the grouped launch takes them itself, as column-sum workgroups in front of its tiles
-            # (gemm.hip colsum_tile / GroupArgs.cs): the descriptors carry dbias again and the two column-sum launches per layer
-            # (24 us each on the chain at 6144 tokens, 0.87 ms per step) are gone.
-            sep_dbias = (not big_wgrad) and T >= int(os.environ.get("UNIVL_DBIAS_COLSUM_MIN", "1000000000"))
+            # Bias gradients of the two projections whose upstream gradient no LayerNorm kernel sees (FFN1, QKV): the descriptors carry
+            # `dbias`; the pair launch and the big-tile grouped launch take them as column-sum workgroups of their own (gemm.hip
+            # colsum_tile, round 4), the 64-tile grouped launch from the operand tiles it stages anyway.
             w_ffn1 = _gemm_desc(dt, s_du, I, ws["a16"], H, I, H, T, trans_a=1, trans_b=1,
-                                out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=None if sep_dbias else fl.g(nm["b1"]),
-                                nt_out=self.nt_wgrad, **wg_tile, **gs.sumsq_args(nm["w1"], I, H))
-            if sep_dbias:
-                colsums.append(lambda _du=s_du, _g=fl.g(nm["b1"]): ops.colsum(_du, _g))
+                                out32=fl.g(nm["w1"]), ldc=H, accumulate=gs.acc(nm["w1"]), dbias=fl.g(nm["b1"]),
+                                **wg_tile, **gs.sumsq_args(nm["w1"], I, H))
             # attention-output LayerNorm / dropout backward (BertSelfOutput, module_bert.py:207-211), fed by the FFN1 dgrad
             dy = self.gbuf
             ln1 = ops.layernorm_desc(
@@ -966,7 +941,7 @@ class EncoderStack:
                                    residual=dz, ldr=H, ksplit=self.ksplit_for(I)), w_ffn1, ln1, 0):
                 ln_bwd(ln1)
             w_o = _gemm_desc(dt, s_dxd2, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
-                             out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"]), nt_out=self.nt_wgrad, **wg_tile, **gs.sumsq_args(nm["o_w"], H, H))
+                             out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"]), **wg_tile, **gs.sumsq_args(nm["o_w"], H, H))
             emit(_gemm_desc(dt, s_dxd2, H, fl.wop(nm["o_w"]), H, T, H, H, trans_b=1, out16=self.dctx, ldc=H), w_o)
             qkv, dqkv = ws["qkv"], s_dqkv
             plan.add("univl_attention_bwd", ops.attention_desc(
@@ -975,10 +950,8 @@ class EncoderStack:
                 dq=(dqkv, 0), lddq=3 * H, dk=(dqkv, H), lddk=3 * H, dv=(dqkv, 2 * H), lddv=3 * H), sm)
             w_qkv = _gemm_desc(dt, dqkv, 3 * H, xin16, H, 3 * H, H, T, trans_a=1, trans_b=1,
                                out32=fl.g_fused(nm["qkv_w"]), ldc=H, accumulate=gs.acc(nm["qkv_w"][0]),
-                               dbias=None if sep_dbias else fl.g_fused(nm["qkv_b"]), nt_out=self.nt_wgrad, **wg_tile,
+                               dbias=fl.g_fused(nm["qkv_b"]), **wg_tile,
                                **gs.sumsq_args(nm["qkv_w"], H, H))
-            if sep_dbias:
-                colsums.append(lambda _d=dqkv, _g=fl.g_fused(nm["qkv_b"]): ops.colsum(_d, _g.view(-1)))
             dx = self.garena[l, 1]
             # ... the QKV dgrad feeds the output LayerNorm backward of the layer BELOW (next iteration)
             ln2_folded = emit(_gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["qkv_w"]), H, T, H, 3 * H, trans_b=1,
@@ -986,35 +959,13 @@ class EncoderStack:
                                       ln2_desc(l - 1, dx) if l > 0 else None, 1)
             # the layer's four weight-gradient GEMMs only consume tensors the chain above produced (dxd, du, dxd2, dqkv
             # are distinct buffers): one grouped launch, after which the scratch may be reused by the next layer
-            ws_stream = sm
-            if not wgrads:
-                pass                                    # self.ride: every weight gradient went out with its dgrad
-            elif off:
-                plan.fork(sm, self.s_off)               # the other stack's stream picks them up once this chain got here
-                plan.add_gemm_group(wgrads, self.s_off)
-                ws_stream = self.s_off
-            elif sw is None:
+            if wgrads:                                  # (self.ride: empty -- every weight gradient went out with its dgrad)
                 plan.add_gemm_group(wgrads, sm)
-            else:                                       # beside the next layer's chain, on at most wg_blocks workgroups
-                # two streams, alternating with the scratch set: "everything enqueued so far on stream (l % 2)" is exactly
-                # the weight gradients of layers l, l+2, ... when the chain of layer l-2 asks for its scratch set back
-                plan.fork(sm, sw + (l % 2))
-                plan.add_gemm_group(wgrads, sw + (l % 2), max_blocks=self.wg_blocks)
-                ws_stream = sw + (l % 2)
-            # on the chain (default; measured at 128 pairs, interleaved: 12.61 / 12.62 ms per step) or with the layer's weight
-            # gradients on their stream (UNIVL_COLSUM_ON_CHAIN=0: 12.72 / 12.76 -- there they delay the group the step ends on)
-            for f in colsums:
-                plan.add_callable(f, sm if os.environ.get("UNIVL_COLSUM_ON_CHAIN", "1") == "1" else ws_stream)
             gin = dx
             if layer_hook is not None:
                 layer_hook(plan, self.prefix, l, sm)
             self.bwd_out = gin
             yield l
-        if sw is not None:
-            plan.join(sw, sm)                           # whatever follows on the chain's stream sees every weight gradient
-            plan.join(sw + 1, sm)
-        if self.s_off is not None:
-            plan.join(self.s_off, sm)
         self.bwd_out = gin
 
 

@@ -113,13 +113,10 @@ class EncoderPass:
         self.de_op = e(self.Tv, H, dtype=ct)
         self.dvnorm = e(self.Tv, D)            # grad wrt the normalised video (accumulated: encoder + MFM loss)
         m = cx.model
-        # UNIVL_WGRAD_OFFLOAD = n: the weight gradients of the text stack's last n layers run on the video stack's stream
-        n_off = int(os.environ.get("UNIVL_WGRAD_OFFLOAD", "0"))
         self.text = EncoderStack(fl, "bert", m.bert_config.num_hidden_layers, B, W, self.amask, cx.p, cx.seed_dev, cx.sites,
-                                 s_main=s_text, s_side=s_text, s_wgrad=s_text + 4,      # streams 4, 5
-                                 s_offload=s_vis, n_offload=n_off)
+                                 s_main=s_text, s_side=s_text)
         self.vis = EncoderStack(fl, "visual", m.visual_config.num_hidden_layers, B, F, self.vmask, cx.p, cx.seed_dev, cx.sites,
-                                s_main=s_vis, s_side=s_vis, s_wgrad=s_vis + 4)          # streams 6, 7
+                                s_main=s_vis, s_side=s_vis)
         self.off_t, self.off_v = cx.sites.next(), cx.sites.next()
         self.seq_out, self.seq_out16 = self.text.output()
         self.vis_out, self.vis_out16 = self.vis.output()
