@@ -370,3 +370,59 @@ def test_deep_weight_gradients_take_the_big_tile_without_fused_bias_gradients(mo
     # 2048 tokens: the weight gradients of the H-wide dgrad products still ride with them -- the former plan, untouched
     mid, mid_py, mid_pairs = groups(build_step(m, "joint", 128, 16, 16, True).backward_plan(True))
     assert mid_pairs > 0 and all((d.tile, d.stages, d.waves) == (0, 0, 0) for g in mid for d in g)
+
+
+def test_layernorm_fold_entry_points_validate_on_the_host():
+    """univl_gemm_ln / univl_gemm_pair_ln with dry_run: which (product, LayerNorm) pairs the launches carry is decided on the host from the
+    two descriptors alone (no device work) -- the plans ask exactly this question at build time.  Refused: a LayerNorm that does not read
+    the product's output, other widths, a product with a bf16 output, too few tiles per row block, the rectangular pair form (>= 384
+    rows) for the backward twin.  (Deterministic mode refuses everything: covered on the GPU, test_gemm_ln_fold_* -- switching the mode
+    allocates device scratch.)"""
+    import ctypes as C
+    import univl_amd
+    from univl_amd import ops
+    from univl_amd.engine import _gemm_desc
+    L = _lib.lib()
+    bf, dt = torch.bfloat16, _lib.DT_BF16
+    if univl_amd.deterministic():
+        pytest.skip("UNIVL_DETERMINISTIC is set")
+    if True:
+        T, H, I = 192, 768, 3072
+        a, w = torch.zeros(T, I, dtype=bf), torch.zeros(H, I, dtype=bf)
+        x, x2 = torch.zeros(T, H), torch.zeros(T, H)
+        gm, bt, st = torch.ones(H), torch.zeros(H), torch.zeros(T, 2)
+        o16 = torch.zeros(T, H, dtype=bf)
+        ctr = torch.zeros(2 * 3, dtype=torch.int32)
+        cp = C.c_void_p(ctr.data_ptr())
+
+        def fwd(g, ln):
+            return L.univl_gemm_ln(C.byref(g), C.byref(ln), cp, None, 0, 0, 0, 1, None)
+
+        g = _gemm_desc(dt, a, I, w, I, T, H, I, out32=x, ldc=H, ksplit=8)
+        ln = ops.layernorm_desc(dt, T, H, x=x, residual=x2, gamma=gm, beta=bt, y=x, stats=st, out16=o16)
+        assert fwd(g, ln) == 0
+        assert fwd(g, ops.layernorm_desc(dt, T, H, x=x2, gamma=gm, beta=bt, y=x2, stats=st, out16=o16)) == _lib.EUNSUPPORTED      # reads something else
+        assert fwd(_gemm_desc(dt, a, I, w, I, T, H, I, out16=o16, ldc=H), ln) == _lib.EUNSUPPORTED                              # bf16 product output
+        w2 = torch.zeros(2 * H, I, dtype=bf)
+        assert fwd(_gemm_desc(dt, a, I, w2, I, T, 2 * H, I, out32=torch.zeros(T, 2 * H), ldc=2 * H), ln) == _lib.EUNSUPPORTED    # N != 768
+        assert L.univl_gemm_ln(C.byref(g), C.byref(ln), None, None, 0, 0, 0, 1, None) != 0                                      # no counters
+        # backward twin
+        dY, W1, X = torch.zeros(T, I, dtype=bf), torch.zeros(I, H, dtype=bf), torch.zeros(T, H, dtype=bf)
+        da, dW = torch.zeros(T, H), torch.zeros(I, H)
+
+        def bwd(dg, wg, lb):
+            return L.univl_gemm_pair_ln(C.byref(dg), C.byref(wg), C.byref(lb), cp, 1, None)
+
+        dg = _gemm_desc(dt, dY, I, W1, H, T, H, I, trans_b=1, out32=da, ldc=H, ksplit=8)
+        wg = _gemm_desc(dt, dY, I, X, H, I, H, T, trans_a=1, trans_b=1, out32=dW, ldc=H)
+        lb = ops.layernorm_desc(dt, T, H, gamma=gm, y=x, stats=st, dout=da, dx32=x2, dxd16=o16, dgamma=torch.zeros(H), dbeta=torch.zeros(H))
+        assert bwd(dg, wg, lb) == 0
+        lb_other = ops.layernorm_desc(dt, T, H, gamma=gm, y=x, stats=st, dout=x2, dx32=x2, dxd16=o16)
+        assert bwd(dg, wg, lb_other) == _lib.EUNSUPPORTED                                                                       # other upstream gradient
+        T2 = 384                                                                                                                 # rectangular dgrad body
+        dY2, X2, da2 = torch.zeros(T2, I, dtype=bf), torch.zeros(T2, H, dtype=bf), torch.zeros(T2, H)
+        dg2 = _gemm_desc(dt, dY2, I, W1, H, T2, H, I, trans_b=1, out32=da2, ldc=H, ksplit=2)
+        wg2 = _gemm_desc(dt, dY2, I, X2, H, I, H, T2, trans_a=1, trans_b=1, out32=dW, ldc=H)
+        lb2 = ops.layernorm_desc(dt, T2, H, gamma=gm, y=torch.zeros(T2, H), stats=torch.zeros(T2, 2), dout=da2, dx32=torch.zeros(T2, H),
+                                 dxd16=torch.zeros(T2, H, dtype=bf))
+        assert L.univl_gemm_pair(C.byref(dg2), C.byref(wg2), 1, None) == 0 and bwd(dg2, wg2, lb2) == _lib.EUNSUPPORTED
