@@ -108,6 +108,8 @@ typedef struct UnivlGemm {
     int32_t flags;
     int32_t ksplit;        /* >1: split the contraction over gridDim.z, fp32 atomics into pre-zeroed C32 */
     int32_t tile;          /* 0 auto; 64 (64x64), 128 (128x128);
+                            * 256 (256x256 on the 8-phase body, csrc/gemm256.h: bf16, M and N multiples of 256, K slices multiples of
+                            *      128, not (T-major A, K-major B), no in-tile dbias -- else 128);
                             * 12864 / 64128 (128x64 / 64x128; bf16, K-major A, no sumsq / dbias, univl_gemm only -- else 128) */
     /* optional, no split-K: every wave stores the sum of squares of the FINAL values it wrote to
      *   sumsq[(m0 / sumsq_rows) * sumsq_stride + (((m0 % sumsq_rows) / tile) * tiles_x + tile_x) * waves + wave]
@@ -141,6 +143,13 @@ int univl_gemm_pair(const UnivlGemm* dgrad, const UnivlGemm* wgrad, int32_t dry_
  * what 2: out[0..2] <- tile number out[0] of an nx x ny x nz problem (a grouped launch's member);
  * what 3: out[0..2] <- the tile local workgroup out[0] of one half of a pair / rider launch computes. */
 int univl_gemm_tile_map(int32_t what, int32_t nx, int32_t ny, int32_t nz, int32_t gm, int32_t* out);
+
+/* Host-side evaluation of the LDS maps of the 256 x 256 product body (csrc/gemm256.h; no device work -- lets a CPU test prove that the
+ * LDS-DMA image and the fragment reads agree and are bank-conflict free):
+ * what 0: out[0..1] <- (row, k) of the first of the 8 elements at lane-linear LDS piece idx (0..1023) of a half-tile image;
+ * what 1: out[0..7] <- LDS byte offsets of the fragment reads of lane idx (0..63) for the 32-row block at arg (0, 32, 64, 96):
+ *         K-major (trans 0) out[0..3] per 16-deep k step, out[4..7] = -1; T-major (trans 1) two transpose reads per k step. */
+int univl_gemm256_layout(int32_t what, int32_t trans, int32_t idx, int32_t arg, int32_t* out);
 
 /* ------------------------------------------------------------------------------------------ LayerNorm
  * TF-style LayerNorm (until_module.py:40-53: biased variance, eps inside the sqrt) fused with what surrounds it

@@ -426,3 +426,53 @@ def test_layernorm_fold_entry_points_validate_on_the_host():
         lb2 = ops.layernorm_desc(dt, T2, H, gamma=gm, y=torch.zeros(T2, H), stats=torch.zeros(T2, 2), dout=da2, dx32=torch.zeros(T2, H),
                                  dxd16=torch.zeros(T2, H, dtype=bf))
         assert L.univl_gemm_pair(C.byref(dg2), C.byref(wg2), 1, None) == 0 and bwd(dg2, wg2, lb2) == _lib.EUNSUPPORTED
+
+
+@pytest.mark.parametrize("trans", [0, 1])
+def test_gemm256_lds_image_and_fragment_reads_agree_and_are_conflict_free(trans):
+    """The 256 x 256 product body (csrc/gemm256.h) fills 16-KB half-tile images by LDS-DMA (lane-linear destination, XOR-swizzled
+    SOURCE piece) and reads MFMA fragments back with the same XOR.  This rebuilds an image from the library's DMA map, emulates
+    ds_read_b128 / ds_read_b64_tr_b16 on the library's per-lane read offsets, and checks (a) lane l of a 32x32x16 fragment gets row /
+    column (l & 31), contraction indices 16 ks + 8 (l >> 5) + 0..7 in order -- for both operand layouts, so that A and B always agree
+    on the k slots; (b) the image is a bijection; (c) no bank conflicts within the LDS's per-instruction lane groups
+    (MI355X_MICROARCH.md, LDS table)."""
+    import ctypes as C
+    L = _lib.lib()
+    out = (C.c_int32 * 8)()
+    # image[byte // 2] = (row, k) of the bf16 element stored there
+    image = {}
+    for piece in range(1024):
+        assert L.univl_gemm256_layout(0, trans, piece, 0, out) == 0
+        row, k = out[0], out[1]
+        for e in range(8):
+            image[piece * 8 + e] = (row + e, k) if trans else (row, k + e)
+    assert sorted(image.values()) == [(r, k) for r in range(128) for k in range(64)]          # every element exactly once
+    b128_groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
+    b128_groups += [[l + 32 for l in g] for g in b128_groups]
+    for r32 in (0, 32, 64, 96):
+        offs = []
+        for lane in range(64):
+            assert L.univl_gemm256_layout(1, trans, lane, r32, out) == 0
+            offs.append(list(out))
+        for ks in range(4):
+            if not trans:
+                for lane in range(64):
+                    o = offs[lane][ks]
+                    assert o % 16 == 0 and 0 <= o < 16384
+                    got = [image[o // 2 + e] for e in range(8)]
+                    assert got == [(r32 + (lane & 31), 16 * ks + 8 * (lane >> 5) + e) for e in range(8)]
+                for g in b128_groups:                       # 16 lanes -> the 16 distinct 16-byte slots of the 256-byte bank row
+                    assert len({(offs[lane][ks] >> 4) & 15 for lane in g}) == 16
+            else:
+                for rd in range(2):
+                    addr = [offs[lane][2 * ks + rd] for lane in range(64)]
+                    assert all(a % 8 == 0 and 0 <= a < 16384 for a in addr)
+                    for lane in range(64):
+                        base, i = lane & ~15, lane & 15
+                        # ds_read_b64_tr_b16: lane i of a 16-lane group receives column i of the 4 x 16 block whose row j is supplied,
+                        # 4 columns each, by lanes 4 j .. 4 j + 3 of the group
+                        got = [image[addr[base + 4 * j + (i >> 2)] // 2 + (i & 3)] for j in range(4)]
+                        assert got == [(r32 + (lane & 31), 16 * ks + 8 * (lane >> 5) + 4 * rd + j) for j in range(4)]
+                    for half in (range(0, 32), range(32, 64)):      # 32 lanes x 8 bytes = every one of the 64 banks once
+                        banks = [((addr[lane] >> 2) + d) & 63 for lane in half for d in (0, 1)]
+                        assert len(set(banks)) == 64

@@ -314,6 +314,165 @@ def test_gemm_tile_and_wave_variants_wgrad(T):
                 assert torch.equal(o2, b_o2), ("group member 2", tile, stages, waves)
 
 
+# ---- the 256 x 256 "8-phase" body (csrc/gemm256.h): every layout, epilogue and launch form against fp64 on the host
+G256_SHAPES = [(256, 256, 128), (512, 768, 256), (768, 512, 640), (1536, 2304, 768), (3072, 768, 3072)]
+
+
+def _ref64(A, B, ta, tb):
+    a, b = A.double().cpu(), B.double().cpu()
+    return (a.T if ta else a) @ (b if tb else b.T)
+
+
+@pytest.mark.parametrize("M,N,K", G256_SHAPES)
+@pytest.mark.parametrize("layout", ["fwd", "dgrad", "wgrad"])
+def test_gemm256_layouts_against_fp64(M, N, K, layout):
+    """C = A_op . B_op^T on the 256 tile: forward (K-major, K-major), dgrad (K-major, T-major), wgrad (T-major, T-major); K = 128 runs
+    only the two tail tiles of the loop, 256 one steady trip + tail, 640 / 768 / 3072 several.  Operands are random and asymmetric (a
+    transposed operand or output cannot pass).  fp32 output: bf16 products summed in fp32, so the error against fp64 is round-off
+    class; the same launch repeated must be bit-identical (a race between the DMA stream and the fragment reads shows up as run-to-run
+    differences long before it shows up as a large error)."""
+    dtype = torch.bfloat16
+    ta, tb = layout == "wgrad", layout != "fwd"
+    A = gen(*((K, M) if ta else (M, K)), seed=11).to(DEV, dtype)
+    B = gen(*((K, N) if tb else (N, K)), seed=12).to(DEV, dtype)
+    ref = _ref64(A, B, ta, tb)
+    out = torch.empty(M, N, device=DEV)
+    out16 = torch.empty(M, N, device=DEV, dtype=dtype)
+    ops.gemm(A, B, M, N, K, trans_a=ta, trans_b=tb, out32=out, out16=out16, tile=256)
+    assert rel_err(out, ref) < 2e-5, layout
+    assert rel_err(out16, ref) < 6e-3, layout
+    # the same product on the older tiles agrees to fp32 round-off (different summation order: 32x32x16 against 16x16x32 chunks)
+    old = torch.empty(M, N, device=DEV)
+    ops.gemm(A, B, M, N, K, trans_a=ta, trans_b=tb, out32=old, tile=128)
+    assert rel_err(out, old) < 2e-5
+    first = out.clone()
+    for _ in range(10):
+        out.fill_(-1.0)
+        ops.gemm(A, B, M, N, K, trans_a=ta, trans_b=tb, out32=out, tile=256)
+        assert torch.equal(out, first), layout
+
+
+def test_gemm256_epilogues_split_k_and_fallbacks():
+    dtype = torch.bfloat16
+    M, N, K = 1536, 3072, 768
+    X = gen(M, K, seed=1).to(DEV, dtype)
+    W = gen(N, K, seed=2, scale=0.05).to(DEV, dtype)
+    bias = gen(N, seed=3).to(DEV)
+    pre = X.double().cpu() @ W.double().cpu().T + bias.double().cpu()
+    # FFN1 forward: bias + erf-GELU, saving the pre-activation (module_bert.py:226-235, until_module.py:28-33)
+    f = torch.empty(M, N, device=DEV, dtype=dtype)
+    u = torch.empty(M, N, device=DEV, dtype=dtype)
+    ops.gemm(X, W, M, N, K, out16=f, bias=bias, aux=u, gelu="fwd", tile=256)
+    gel = pre * 0.5 * (1.0 + torch.erf(pre / math.sqrt(2.0)))
+    assert rel_err(u, pre) < 6e-3
+    assert rel_err(f, gel) < 6e-3
+    # the branch-free erf of this body against libm's on the older tile: same bf16 results up to one rounding of a few elements
+    f_old = torch.empty_like(f)
+    u_old = torch.empty_like(u)
+    ops.gemm(X, W, M, N, K, out16=f_old, bias=bias, aux=u_old, gelu="fwd", tile=128)
+    assert torch.equal(u, u_old) or rel_err(u, u_old) < 4e-3
+    assert float((f.float() - f_old.float()).abs().max()) <= 2.0 ** -7 * float(f_old.float().abs().max())
+    assert float((f != f_old).float().mean()) < 2e-2
+    # FFN2 dgrad: dY . W2 with GELU' of the saved pre-activation (bf16 out)
+    dY = gen(M, K, seed=4).to(DEV, dtype)                     # [T, 768]
+    W2 = gen(K, N, seed=5, scale=0.05).to(DEV, dtype)         # nn.Linear(3072 -> 768) weight [768, 3072]: T-major B of the dgrad
+    du = torch.empty(M, N, device=DEV, dtype=dtype)
+    ops.gemm(dY, W2, M, N, K, trans_b=True, out16=du, aux=u, gelu="bwd", tile=256)
+    uf = u.double().cpu()
+    gp = 0.5 * (1.0 + torch.erf(uf / math.sqrt(2.0))) + uf * torch.exp(-0.5 * uf * uf) / math.sqrt(2.0 * math.pi)
+    assert rel_err(du, (dY.double().cpu() @ W2.double().cpu()) * gp) < 6e-3
+    # FFN1 dgrad: fp32 output + fp32 residual, unsplit and in three K slices (atomics into a zeroed output), alpha
+    dU = gen(M, N, seed=6).to(DEV, dtype)
+    R = gen(M, K, seed=7).to(DEV)
+    ref = dU.double().cpu() @ W.double().cpu() * 0.5 + R.double().cpu()
+    for ks in (1, 3, 2):
+        dx = torch.zeros(M, K, device=DEV)
+        ops.gemm(dU, W, M, K, N, trans_b=True, out32=dx, residual=R, ksplit=ks, alpha=0.5, tile=256)
+        assert rel_err(dx, ref) < 2e-5, ks
+    # accumulate + non-unit leading dimension of the output (a column block of a wider buffer)
+    wide = torch.full((M, 2 * K), 0.25, device=DEV)
+    ops.gemm(dU, W, M, K, N, trans_b=True, out32=wide[:, K:], accumulate=True, alpha=0.5, tile=256)
+    assert rel_err(wide[:, K:], ref - R.double().cpu() + 0.25) < 2e-5
+    assert float((wide[:, :K] - 0.25).abs().max()) == 0.0
+    # products the body does not carry fall back to the older tiles (same results as asking for them)
+    for (m, n, k, kw) in [(1500, 768, 768, {}), (1536, 700, 768, {}), (1536, 768, 704, {}), (1536, 768, 768, dict(ksplit=4))]:
+        a = gen(m, k, seed=8).to(DEV, dtype)
+        b = gen(n, k, seed=9).to(DEV, dtype)
+        o1, o2 = torch.zeros(m, n, device=DEV), torch.zeros(m, n, device=DEV)
+        ops.gemm(a, b, m, n, k, out32=o1, tile=256, **kw)
+        ops.gemm(a, b, m, n, k, out32=o2, tile=128, **kw)
+        assert rel_err(o1, a.double().cpu() @ b.double().cpu().T) < 2e-5
+        if not kw:
+            assert torch.equal(o1, o2)
+
+
+@pytest.mark.parametrize("T", [1536, 6144])
+def test_gemm256_weight_gradient_group_with_bias_gradients_and_norms(T):
+    """A layer's four weight gradients as ONE grouped launch on the 256 tile (what the backward plan issues at thousands of tokens):
+    beta = 0 and accumulate members, the fused q/k/v member with three gradient-norm tensors, bias gradients taken by the column-sum
+    roles in front of the tiles."""
+    dtype = torch.bfloat16
+    shapes = [("qkv", 2304, 768), ("o", 768, 768), ("ffn1", 3072, 768), ("ffn2", 768, 3072)]
+    dY = {n_: gen(T, N, seed=20 + i).to(DEV, dtype) for i, (n_, N, K) in enumerate(shapes)}
+    X = {n_: gen(T, K, seed=30 + i).to(DEV, dtype) for i, (n_, N, K) in enumerate(shapes)}
+    dW = {n_: torch.full((N, K), 0.5, device=DEV) for n_, N, K in shapes}
+    db = {n_: torch.zeros(N, device=DEV) for n_, N, K in shapes}
+    stride = (768 // 64) * (768 // 64) * 4
+    part = torch.zeros(3 * stride, device=DEV)
+    descs = []
+    for n_, N, K in shapes:
+        kw = dict(trans_a=True, trans_b=True, out32=dW[n_], accumulate=(n_ == "o"))
+        if n_ in ("qkv", "ffn1"):
+            kw["dbias"] = db[n_]
+        if n_ == "qkv":
+            kw.update(sumsq=part, sumsq_rows=768, sumsq_stride=stride)
+        descs.append(ops.gemm_desc(dY[n_], X[n_], N, K, T, **kw))
+    ops.gemm_group(descs)
+    for n_, N, K in shapes:
+        ref = dY[n_].double().cpu().T @ X[n_].double().cpu() + (0.5 if n_ == "o" else 0.0)
+        assert rel_err(dW[n_], ref) < 2e-5, n_
+        if n_ in ("qkv", "ffn1"):
+            assert rel_err(db[n_], dY[n_].double().cpu().sum(0)) < 1e-5, n_
+    assert rel_err(part.view(3, stride).sum(1), (dW["qkv"].double() ** 2).view(3, -1).sum(1).cpu()) < 1e-5
+    # ... and it IS the 256 body: a forced 128-tile group gives the same numbers only to round-off, not bit for bit
+    dW2 = {n_: torch.full((N, K), 0.5, device=DEV) for n_, N, K in shapes}
+    ops.gemm_group([ops.gemm_desc(dY[n_], X[n_], N, K, T, trans_a=True, trans_b=True, out32=dW2[n_], accumulate=(n_ == "o"), tile=128,
+                                  stages=2, waves=4) for n_, N, K in shapes])
+    assert all(rel_err(dW[n_], dW2[n_]) < 2e-5 for n_, _, _ in shapes)
+    assert not all(torch.equal(dW[n_], dW2[n_]) for n_, _, _ in shapes)
+
+
+def test_gemm256_under_concurrent_hbm_traffic_is_bit_stable():
+    """The loop keeps three half-tiles of LDS-DMA in flight across its barriers and reads a stage one phase after the counted wait that
+    retires it (gemm256.h).  A fragment read that overtakes its DMA returns the previous K tile's bytes -- only when the DMA is slow.
+    So: a side stream saturates HBM with copies of UNEVEN size while 40 launches per layout run; every launch must reproduce the quiet
+    run bit for bit (checked on every word)."""
+    dtype = torch.bfloat16
+    M, N, K = 1536, 2304, 768
+    side = torch.cuda.Stream()
+    big = [torch.empty(s, device=DEV, dtype=torch.uint8) for s in (1 << 28, 1 << 28)]
+    small = [torch.empty(s, device=DEV, dtype=torch.uint8) for s in (1 << 20, 1 << 20)]
+    for layout in ("fwd", "dgrad", "wgrad"):
+        ta, tb = layout == "wgrad", layout != "fwd"
+        A = gen(*((K, M) if ta else (M, K)), seed=41).to(DEV, dtype)
+        B = gen(*((K, N) if tb else (N, K)), seed=42).to(DEV, dtype)
+        quiet = torch.empty(M, N, device=DEV)
+        ops.gemm(A, B, M, N, K, trans_a=ta, trans_b=tb, out32=quiet, tile=256)
+        assert rel_err(quiet, _ref64(A, B, ta, tb)) < 2e-5
+        torch.cuda.synchronize()
+        outs = [torch.empty(M, N, device=DEV) for _ in range(40)]
+        with torch.cuda.stream(side):
+            for r in range(60):
+                big[1].copy_(big[0])
+                if r % 3 == 0:
+                    small[1].copy_(small[0])
+        for o in outs:
+            ops.gemm(A, B, M, N, K, trans_a=ta, trans_b=tb, out32=o, tile=256)
+        torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            assert torch.equal(o, quiet), (layout, i)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_fused_sum_of_squares(dtype):
     """UnivlGemm.sumsq: the wgrad epilogue accumulates the per-tensor sum of squares of what it stores (single tensor,

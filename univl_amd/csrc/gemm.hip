@@ -545,6 +545,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (BM != BN && BM * BN == 128 * 64) ?
     gemm_tile<T, TA, TB, BM, BN, NC, WGM, WGN>(p, bx, by, bz, gridDim.z);
 }
 
+#include "gemm256.h"
+
 struct ColsumArgs {                  // out[c] (+)= sum over rows of x[r, c]: the bias gradient of a weight-gradient product whose A is x
     const __bf16* x; long ld; int rows, n; float* out; int n_tiles, n_pad;
 };
@@ -665,6 +667,47 @@ int launch_group(const GroupArgs& g, int max_blocks, hipStream_t stream) {
     const int total = g.first[UNIVL_GEMM_GROUP_MAX] + g.cs_first[UNIVL_GEMM_GROUP_MAX];
     const int grid = (max_blocks > 0 && max_blocks < total) ? max_blocks : total;
     hipLaunchKernelGGL((gemm_group_kernel<T, TA, TB, BM, BN, NC, WGM, WGN>), dim3(grid), dim3(NT), smem, stream, g);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+// The grouped launch on the 256 x 256 body (gemm256.h): a layer's four weight-gradient products over thousands of tokens, one workgroup
+// per tile, bias-gradient roles in front as above.  The kernel-argument struct is read THROUGH THE KERNARG POINTER with a uniform
+// dynamic index (scalar loads of one member's arguments) instead of by-value selects over all four members -- those cost the older
+// grouped kernel 175 - 245 spilled SGPRs.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512, 2) void gemm256_group_kernel(GroupArgs by_value) {
+    (void)by_value;
+    const GroupArgs& g = *(const GroupArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int total = g.first[UNIVL_GEMM_GROUP_MAX];
+    const int ncs = g.cs_first[UNIVL_GEMM_GROUP_MAX];
+    const int v0 = blockIdx.x;
+    if (v0 < ncs) {
+        int m = 0;
+#pragma unroll
+        for (int i = 1; i < UNIVL_GEMM_GROUP_MAX; ++i) m += (v0 >= g.cs_first[i]) ? 1 : 0;
+        const ColsumArgs c = g.cs[m];
+        if (v0 - g.cs_first[m] < c.n_tiles) colsum_tile<512>(c, v0 - g.cs_first[m], smem_raw);
+        return;
+    }
+    const int w0 = v0 - ncs;
+    const int w = total >= 16 ? xcd_run(w0, total) : w0;
+    int idx = 0;
+#pragma unroll
+    for (int i = 1; i < UNIVL_GEMM_GROUP_MAX; ++i) idx += (w >= g.first[i]) ? 1 : 0;
+    const GemmArgs p = g.p[idx];
+    const int nx = g.nx[idx], ny = g.nxy[idx] / nx, nz = g.nz[idx];
+    int bx, by, bz;
+    tile_of(w - g.first[idx], nx, ny, nz, p.gm, bx, by, bz);
+    gemm256_tile<TA, TB>(p, bx, by, bz);
+}
+
+template <bool TA, bool TB>
+int launch_group256(const GroupArgs& g, hipStream_t stream) {
+    static bool attr_done[UNIVL_MAX_DEVICES] = {};
+    univl_allow_lds(gemm256_group_kernel<TA, TB>, G256_SMEM, attr_done);
+    const int total = g.first[UNIVL_GEMM_GROUP_MAX] + g.cs_first[UNIVL_GEMM_GROUP_MAX];
+    hipLaunchKernelGGL((gemm256_group_kernel<TA, TB>), dim3(total), dim3(512), G256_SMEM, stream, g);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }
@@ -929,9 +972,35 @@ constexpr long GEMM_BIG_MIN = 256;      // 128 x 128 tiles from this many of the
 constexpr int GEMM_GM = 8;              // row tiles per L2 band of the tile order (xcd map)
 constexpr long GEMM_NC64_MIN = 1024;    // grouped weight gradients contracting over at least this many tokens: 64-deep K steps, 4 waves
 
-static Choice choose(const UnivlGemm* d, int forced_tile, int forced_nc = 0, bool allow_rect = false) {
+// The 256 x 256 body (gemm256.h): bf16, M and N multiples of 256, equal K slices that are multiples of 128 (two K tiles per loop trip),
+// K-major x K-major / K-major x T-major / T-major x T-major, gradient-norm tensors that are whole tiles, no in-tile bias gradient
+// (in_group: the grouped launch takes a member's bias gradient as column-sum roles before the member gets here).
+static bool fits256(const UnivlGemm* d, bool in_group) {
+    if (d->dtype != UNIVL_BF16 || (d->trans_a && !d->trans_b) || d->M % 256 != 0 || d->N % 256 != 0) return false;
+    if (d->dbias && !in_group) return false;
+    if (d->sumsq && d->sumsq_rows % 256 != 0) return false;
+    const int ks = (d->ksplit < 1 || univl_deterministic()) ? 1 : d->ksplit;
+    return d->K % (128 * ks) == 0;
+}
+
+// From where on the 256 body is picked without being asked for (tile = 0): rows in the thousands AND enough tiles (x K slices) to
+// occupy most of the 256 compute units -- one workgroup per unit, so below that the smaller tiles' two or three workgroups per
+// unit win (scripts/mb_gemm256.py, profiles/r05_mb_gemm256.txt).
+constexpr int G256_MIN_ROWS = 1536;
+constexpr long G256_MIN_WG = 128;
+static bool auto256(const UnivlGemm* d, bool in_group) {
+    if (!fits256(d, in_group)) return false;
+    const int ks = (d->ksplit < 1 || univl_deterministic()) ? 1 : d->ksplit;
+    const long wg = (long)(d->M / 256) * (d->N / 256) * ks;
+    const int rows = d->trans_a ? d->K : d->M;            // tokens: the contraction of a weight gradient
+    return rows >= G256_MIN_ROWS && (in_group || wg >= G256_MIN_WG);
+}
+
+static Choice choose(const UnivlGemm* d, int forced_tile, int forced_nc = 0, bool allow_rect = false, bool in_group = false) {
     const bool bf16 = d->dtype == UNIVL_BF16;
-    const int want = forced_tile ? forced_tile : d->tile;
+    int want = forced_tile ? forced_tile : d->tile;
+    if ((want == 256 && fits256(d, in_group)) || (want == 0 && auto256(d, in_group))) return Choice{256, 2, 8};
+    if (want == 256) want = 128;                   // asked for, but not a product the body carries
     const long tiles128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
     const bool rect_ok = allow_rect && bf16 && !d->trans_a && !d->sumsq && !d->dbias;      // univl_gemm only (single launch)
     Choice c;
@@ -973,13 +1042,14 @@ static Choice choose(const UnivlGemm* d, int forced_tile, int forced_nc = 0, boo
     return c;
 }
 
-static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int forced_tile = 0, int forced_nc = 0, bool allow_rect = false) {
+static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int forced_tile = 0, int forced_nc = 0, bool allow_rect = false,
+                   bool in_group = false) {
     UNIVL_CHECK_ARG(d != nullptr, UNIVL_EINVAL, "univl_gemm: null descriptor");
     UNIVL_CHECK_ARG(d->dtype == UNIVL_F32 || d->dtype == UNIVL_BF16, UNIVL_EUNSUPPORTED, "univl_gemm: dtype %d", d->dtype);
     UNIVL_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, UNIVL_EINVAL, "univl_gemm: empty problem %dx%dx%d", d->M, d->N, d->K);
     UNIVL_CHECK_ARG(d->A && d->B && (d->C32 || d->C16), UNIVL_EINVAL, "univl_gemm: null operand");
-    UNIVL_CHECK_ARG(d->tile == 0 || d->tile == 64 || d->tile == 128 || d->tile == 12864 || d->tile == 64128, UNIVL_EINVAL,
-                    "univl_gemm: tile %d (0, 64, 128, 12864, 64128)", d->tile);
+    UNIVL_CHECK_ARG(d->tile == 0 || d->tile == 64 || d->tile == 128 || d->tile == 256 || d->tile == 12864 || d->tile == 64128, UNIVL_EINVAL,
+                    "univl_gemm: tile %d (0, 64, 128, 256, 12864, 64128)", d->tile);
     UNIVL_CHECK_ARG(d->stages == 0 || d->stages == 2, UNIVL_EINVAL, "univl_gemm: stages %d (0, 2)", d->stages);
     UNIVL_CHECK_ARG(d->waves == 0 || d->waves == 4 || d->waves == 8, UNIVL_EINVAL, "univl_gemm: waves %d (0, 4, 8)", d->waves);
     const int epc = d->dtype == UNIVL_BF16 ? 8 : 4;
@@ -992,11 +1062,11 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int 
     // tile choice: 128x128 once the grid fills the chip (>= 256 tiles, measured: +6 % at bs 128 over 384, same at bs 16), else
     // 64x64 for parallelism.  The small tile stages 4 chunks (128 bf16 / 64 f32) per barrier: at M <= a few hundred the kernel
     // is a latency chain of K steps (DMA -> barrier -> ds_read -> MFMA), so fewer, deeper steps win.
-    c = choose(d, forced_tile, forced_nc, allow_rect);
+    c = choose(d, forced_tile, forced_nc, allow_rect, in_group);
     // deterministic mode (common.h): no split-K -- the slices of a split product meet in fp32 atomics whose order is the hardware's;
     // one workgroup per output tile walks the whole contraction in order (the pre-zeroed arena is simply overwritten)
     ksplit = (d->ksplit < 1 || univl_deterministic()) ? 1 : d->ksplit;
-    const int BK = (d->dtype == UNIVL_BF16 ? 32 : 16) * c.nc;
+    const int BK = c.tile == 256 ? 128 : (d->dtype == UNIVL_BF16 ? 32 : 16) * c.nc;      // 256 body: K % (128 ksplit) == 0 (fits256)
     int klen = ((d->K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
     ksplit = (d->K + klen - 1) / klen;
     if (ksplit > 1) {
@@ -1039,6 +1109,33 @@ extern "C" int univl_gemm_tile_map(int32_t what, int32_t nx, int32_t ny, int32_t
     return UNIVL_OK;
 }
 
+// Host-side evaluation of the 256 x 256 body's LDS maps (gemm256.h; no device work): tests/test_host_cpu.py rebuilds a half-tile image
+// from the DMA map and checks that every fragment read returns the operand elements the MFMA expects, and that the reads are
+// bank-conflict free under the LDS's per-instruction lane groups.
+//   what 0: out[0..1] <- (row, k) of the FIRST of the 8 elements the DMA drops at lane-linear LDS piece idx (0..1023) of a half-tile
+//           image (K-major: 8 consecutive k of one row; T-major: 8 consecutive rows of one k);
+//   what 1: out[0..7] <- LDS byte offsets of the fragment reads of lane idx for the 32-row block at `arg` (a multiple of 32):
+//           K-major out[ks] (one 16-byte read per k step), T-major out[2 ks], out[2 ks + 1] (two 8-byte transpose reads per k step).
+extern "C" int univl_gemm256_layout(int32_t what, int32_t trans, int32_t idx, int32_t arg, int32_t* out) {
+    UNIVL_CHECK_ARG(out != nullptr && (what == 0 || what == 1) && idx >= 0 && idx < (what == 0 ? 1024 : 64) && arg >= 0 && arg < 128 &&
+                        arg % 32 == 0, UNIVL_EINVAL, "univl_gemm256_layout: what=%d idx=%d arg=%d", what, idx, arg);
+    constexpr long LD = 1 << 20;
+    if (what == 0) {
+        const long o = trans ? Op256<true>::src(idx, LD) : Op256<false>::src(idx, LD);
+        if (trans) { out[0] = (int)(o % LD); out[1] = (int)(o / LD); }
+        else { out[0] = (int)(o / LD); out[1] = (int)(o % LD); }
+        return UNIVL_OK;
+    }
+    if (trans) {
+        const Op256<true>::Lane l = Op256<true>::lane_offsets(idx, arg);
+        for (int ks = 0; ks < 4; ++ks) { out[2 * ks] = l.off[0] + 4096 * ks; out[2 * ks + 1] = l.off[0] + 4096 * ks + 1024; }
+    } else {
+        const Op256<false>::Lane l = Op256<false>::lane_offsets(idx, arg);
+        for (int ks = 0; ks < 4; ++ks) { out[ks] = l.off[ks]; out[4 + ks] = -1; }
+    }
+    return UNIVL_OK;
+}
+
 extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
     UNIVL_ON_STREAM_DEVICE(stream);
     GemmArgs a;
@@ -1054,6 +1151,11 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
     }
     const int ta = d->trans_a, tb = d->trans_b;
     if (d->dtype == UNIVL_BF16) {
+        if (c.tile == 256) {
+            if (!ta && !tb) return launch256<false, false>(a, ksplit, stream);
+            if (!ta && tb) return launch256<false, true>(a, ksplit, stream);
+            return launch256<true, true>(a, ksplit, stream);
+        }
         if (c.tile == 12864) {                       // K-major A only (choose): forward and dgrad products
             if (c.waves == 8) return tb ? launch<__bf16, false, true, 128, 64, 2, 4, 2>(a, ksplit, stream)
                                         : launch<__bf16, false, false, 128, 64, 2, 4, 2>(a, ksplit, stream);
@@ -1285,11 +1387,11 @@ extern "C" int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_block
     if (n == 1 && max_blocks <= 0) return univl_gemm(d, stream);
     GroupArgs g;
     // the group runs one kernel instantiation: the smallest tile / fewest waves any member would pick alone
-    int tile_all = 128, waves_all = 8;
+    int tile_all = max_blocks > 0 ? 128 : 256, waves_all = 8;       // the walking form (max_blocks) exists on the older tiles only
     for (int i = 0; i < n; ++i) {
         UNIVL_CHECK_ARG(d[i].dtype == d[0].dtype && d[i].trans_a == d[0].trans_a && d[i].trans_b == d[0].trans_b, UNIVL_EINVAL,
                         "univl_gemm_group: members must share dtype and operand layouts");
-        const Choice ci = choose(&d[i], 0);
+        const Choice ci = choose(&d[i], 0, 0, false, max_blocks <= 0);
         tile_all = ci.tile < tile_all ? ci.tile : tile_all;
         waves_all = ci.waves < waves_all ? ci.waves : waves_all;
     }
@@ -1313,7 +1415,7 @@ extern "C" int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_block
     // On the 128 tile (weight gradients over thousands of tokens) a member's bias gradient is taken by column-sum workgroups in front
     // of the tiles (colsum_tile) instead of the product's own column-0 workgroups, which were the stragglers of a one-round launch
     // (322 vs 138 us per layer at 6144 tokens, profiles/r03w / r03y2); round 3 used a separate column-sum launch on the chain.
-    const bool cs_roles = tile_all == 128 && d[0].dtype == UNIVL_BF16 && d[0].trans_a;
+    const bool cs_roles = tile_all >= 128 && d[0].dtype == UNIVL_BF16 && d[0].trans_a;
     for (int i = 0; i < UNIVL_GEMM_GROUP_MAX; ++i) {
         g.cs_first[i] = cs_total;
         g.cs[i] = ColsumArgs{nullptr, 0, 0, 0, nullptr, 0, 0};
@@ -1329,7 +1431,7 @@ extern "C" int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_block
         if (i >= n) { g.p[i] = g.p[0]; g.nx[i] = g.nxy[i] = g.nz[i] = 1; continue; }
         int ksplit;
         Choice ci;
-        const int rc = prepare(&d[i], g.p[i], ksplit, ci, tile_all, forced_nc);
+        const int rc = prepare(&d[i], g.p[i], ksplit, ci, tile_all, forced_nc, false, tile_all == 256);
         if (rc != UNIVL_OK) return rc;
         if (g.cs[i].x) g.p[i].dbias = nullptr;
         UNIVL_CHECK_ARG(ci.tile == tile_all, UNIVL_EINVAL, "univl_gemm_group: member %d cannot run the group's %d tile (sumsq_rows %d)", i, tile_all, d[i].sumsq_rows);
@@ -1351,6 +1453,11 @@ extern "C" int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_block
     UNIVL_CHECK_ARG(nc_all > 0, UNIVL_EINVAL, "univl_gemm_group: members disagree on the K-step depth (mixed contraction lengths)");
     if (d[0].dtype == UNIVL_BF16) {
         const bool w8 = waves_all == 8 && nc_all != 6;
+        if (tile_all == 256) {
+            if (!ta && !tb) return launch_group256<false, false>(g, stream);
+            if (!ta && tb) return launch_group256<false, true>(g, stream);
+            return launch_group256<true, true>(g, stream);
+        }
         if (tile_all == 128) { if (w8) UNIVL_GROUP_CASE(__bf16, 128, 128, 2, 2, 4); UNIVL_GROUP_CASE(__bf16, 128, 128, 2, 2, 2); }
         if (nc_all == 6) return launch_group<__bf16, true, true, 64, 64, 6>(g, max_blocks, stream);
         if (nc_all == 2) { if (w8) UNIVL_GROUP_CASE(__bf16, 64, 64, 2, 2, 4); UNIVL_GROUP_CASE(__bf16, 64, 64, 2, 2, 2); }
