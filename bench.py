@@ -176,8 +176,8 @@ OTHER_CONFIGS = [
     ("ft_align_48x48", ["--kind", "align"], {}, "align_full, align_full_cot"),
     ("cfg4_caption_128x96", ["--kind", "caption"], {}, "caption_full"),
     ("cfg5_pretrain_48x64_6_rows", ["--kind", "pretrain", "--batch", "6"], {}, "pretrain_full, pretrain_full_cot"),
-    ("dp_schedule_dry_run_4_pairs", ["--force-dp"], {"UNIVL_DP_DRYRUN": "1"}, "test_graphed_and_data_parallel_schedules_match_eager[joint_small]"),
-    ("dp_schedule_dry_run_16_pairs", ["--force-dp", "--batch", "16"], {"UNIVL_DP_DRYRUN": "1"}, "test_graphed_and_data_parallel_schedules_match_eager[joint_small]"),
+    ("dp_schedule_dry_run_4_pairs", ["--force-dp"], {"UNIVL_AB": "dp_dryrun=1"}, "test_graphed_and_data_parallel_schedules_match_eager[joint_small]"),
+    ("dp_schedule_dry_run_16_pairs", ["--force-dp", "--batch", "16"], {"UNIVL_AB": "dp_dryrun=1"}, "test_graphed_and_data_parallel_schedules_match_eager[joint_small]"),
 ]
 
 
@@ -314,7 +314,8 @@ def main():
 
     cpu_base = None
 
-    from univl_amd import _lib as _ulib
+    from univl_amd import _ab as _uab, _lib as _ulib
+    _uab.allow()                     # the measurement harness: UNIVL_AB overrides are honoured here (and reported in `config`)
     if world == 1 and not os.path.exists(_ulib.LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc"):
         from univl_amd import build as _ubuild          # harness convenience only; the product path never builds
         _ubuild.build(verbose=False)
@@ -625,7 +626,7 @@ def main():
                                optimizer_pipelined=bool(gstep is not None and gstep.pipeline),
                                optimizer_riding=bool(gstep is not None and gstep.ride),
                                host_inputs=bool(args.host_inputs), exchange=exchange, params=n_params,
-                               last_loss=round(last, 6)),
+                               last_loss=round(last, 6), ab_overrides=_uab.overrides()),
                    preheat=pre, pcie_inclusive=pcie, roofline=roofline, cpu_baseline=None)
     if dist is not None:
         dist.destroy_process_group()

@@ -400,7 +400,8 @@ int univl_gemm_rider(const UnivlGemm* gemm, const UnivlAdam* adam, int32_t chunk
  * a per-block arrival counter), instead of by a second launch behind a kernel boundary.  Same arithmetic per row as univl_layernorm_fwd
  * (the same device function); the product's sums meet in hardware order exactly as in any split-K product, so the entry point refuses
  * deterministic mode.  Optionally also carries BertAdam chunks like univl_gemm_rider (adam may be NULL with chunk_count 0).
- *   gemm: bf16, both operands K-major, fp32 output C32 == ln->x with ldc = N = 768, no C16 / GELU / ACCUM / sumsq, at most 4096 rows;
+ *   gemm: bf16, both operands K-major, fp32 output C32 == ln->x with ldc = N = 768, no C16 / GELU / ACCUM / sumsq, at most 1024 rows
+ *         (16 row blocks: the fold's last arrivals spin for the block's later ones, and the spinners must stay far below the resident slots);
  *   ln:   rows == gemm->M, N == 768, fp32 x, dtype bf16 (residual / dropout / y / stats / out32 / out16 as for univl_layernorm_fwd);
  *   counters: 2 * ceil(M / 64) int32 device words owned by this call site, ZERO before its first launch (the launch leaves them zero).
  * Returns UNIVL_EUNSUPPORTED for anything else (callers then enqueue univl_gemm / univl_gemm_rider + univl_layernorm_fwd);

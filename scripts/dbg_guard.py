@@ -1,7 +1,7 @@
 """Debugging aid: the golden parity test's sequence (eval surface, then one training forward/backward) with sentinel bands
 around every workspace (UNIVL_GUARD=1); reports the buffers next to which a kernel wrote, and the gradient-norm ratios."""
 import os, sys
-os.environ.setdefault("UNIVL_GUARD", "1")
+os.environ.setdefault("UNIVL_AB", "guard=1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
@@ -10,6 +10,8 @@ import torch
 import univl_oracle as O
 from make_golden import case_config
 from test_model_gpu import build, call
+from univl_amd import _ab as _uab
+_uab.allow()
 from univl_amd import engine
 
 name = sys.argv[1] if len(sys.argv) > 1 else "align_full"

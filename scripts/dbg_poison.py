@@ -1,6 +1,6 @@
 """Debugging aid: run one golden case with NaN-poisoned workspaces (UNIVL_POISON=1) and report where NaNs appear."""
 import os, sys
-os.environ.setdefault("UNIVL_POISON", "1")
+os.environ.setdefault("UNIVL_AB", "poison=1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)

@@ -14,13 +14,15 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["UNIVL_AUTO_GRAPH"] = "0"
+os.environ["UNIVL_AB"] = "auto_graph=0"
 import bench  # noqa: E402
 
 STEPS = 4
 
 
 def main():
+    from univl_amd import _ab as _uab
+    _uab.allow()
     from univl_amd import UniVL, BertAdam, clip_grad_norm_, ops
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     args = argparse.Namespace(batch=B, dtype="bf16", dropout=0.1)

@@ -1,9 +1,9 @@
 """Where the two encoder branches of the captured training step start and end, WITHOUT a profiler attached.
 
-    UNIVL_STAMPS=1 python scripts/probe_branches.py [--batch 4] [--steps 60]
-    UNIVL_PROBE_SKIP=visual python scripts/probe_branches.py          # the step without the video stack's layers (timing only)
+    UNIVL_AB=stamps=1 python scripts/probe_branches.py [--batch 4] [--steps 60]
+    UNIVL_AB=probe_skip=visual python scripts/probe_branches.py          # the step without the video stack's layers (timing only)
 
-With UNIVL_STAMPS=1 the plans carry one-thread timestamp kernels (univl_stamp: the device's 100 MHz wall clock) at the fork, at both
+With stamps=1 the plans carry one-thread timestamp kernels (univl_stamp: the device's 100 MHz wall clock) at the fork, at both
 branch starts / ends and at the join, forward and backward; this script replays the whole-step hipGraph (graphed.GraphedTrainStep, the
 bench configuration) and prints the median position of every stamp relative to the first one, next to the wall time of a step and the
 host time of one replay call.  Background: the rocprofv3 kernel trace of the round-3 step (profiles/r03z_graph_replay_kernel_trace.csv.gz)
@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true")
     a = ap.parse_args()
     args = argparse.Namespace(batch=a.batch, dtype="bf16", kind="joint", dropout=0.1)
+    from univl_amd import _ab as _uab
+    _uab.allow()
     from univl_amd import UniVL, BertAdam
     from univl_amd.graphed import GraphedTrainStep
     dev = torch.device("cuda", 0)
@@ -62,7 +64,7 @@ def main():
             v = buf.cpu().tolist()
             rel.append({n: v[i] for n, i in names.items()})
     med = lambda x: sorted(x)[len(x) // 2]
-    print("batch %d  pipeline %s  skip=%s  mode=%s ride=%s" % (a.batch, not a.no_pipeline, os.environ.get("UNIVL_PROBE_SKIP", "-"), gs.mode, gs.ride))
+    print("batch %d  pipeline %s  skip=%s  mode=%s ride=%s" % (a.batch, not a.no_pipeline, _uab.get("probe_skip") or "-", gs.mode, gs.ride))
     print("wall per step (replay call + float(loss)): median %.1f us, min %.1f;  host time of the replay call alone: median %.1f us" %
           (med(wall), min(wall), med(host)))
     if rel:

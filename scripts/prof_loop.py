@@ -3,6 +3,8 @@ import argparse, cProfile, os, pstats, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
+from univl_amd import _ab as _uab
+_uab.allow()
 from univl_amd import UniVL, BertAdam, clip_grad_norm_
 args = argparse.Namespace(batch=4, dtype="bf16", dropout=0.1)
 model = UniVL.from_pretrained("bert-base-uncased", "visual-base", "cross-base", "decoder-base", task_config=bench.task_config(args, 1)).to("cuda").train()

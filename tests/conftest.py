@@ -17,10 +17,30 @@ def pytest_configure(config):
                                        "a `-x` run has executed every deterministic-gate test before it gets there")
     # The library is built in-tree by __graft_entry__.build() and travels with the repository snapshot; if a snapshot
     # ever arrives without it, build it here (test harness only -- the product path itself never builds or falls back).
-    from univl_amd import _lib
+    from univl_amd import _ab, _lib
+    _ab.allow()                      # tests reach non-default plans through UNIVL_AB (the `ab` fixture below)
     if not os.path.exists(_lib.LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc"):
         from univl_amd import build as _b
         _b.build(verbose=False)
+
+
+@pytest.fixture
+def ab(monkeypatch):
+    """ab(key=value, ...) sets plan-builder overrides (univl_amd/_ab.py: the single UNIVL_AB variable) for the rest of the test;
+    ab(key=None) drops one again."""
+    state = {}
+
+    def set_(**kv):
+        for k, v in kv.items():
+            if v is None:
+                state.pop(k, None)
+            else:
+                state[k] = v
+        if state:
+            monkeypatch.setenv("UNIVL_AB", ",".join("%s=%s" % it for it in state.items()))
+        else:
+            monkeypatch.delenv("UNIVL_AB", raising=False)
+    return set_
 
 
 @pytest.fixture(scope="session")

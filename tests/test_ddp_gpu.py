@@ -32,6 +32,8 @@ def _setup_path():
     for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
+    from univl_amd import _ab
+    _ab.allow()                      # spawned workers do not pass through conftest.py
 
 
 def _model_and_batch(lo, hi):
@@ -204,7 +206,7 @@ def _worker_nccl(port, q):
         def train(dp, graphed, capture=True):
             model, args, kw = _model_and_batch(0, ROWS)
             if dp:
-                os.environ["UNIVL_DP_CAPTURE"] = "1" if capture else "0"
+                os.environ["UNIVL_AB"] = "dp_capture=%d" % (1 if capture else 0)
                 model.enable_data_parallel(force=True)
                 assert model._reducer is not None and model._reducer._avg and model._reducer.world == 1
                 assert model._reducer.capturable == capture
@@ -263,7 +265,7 @@ def test_reducer_on_rccl_world_size_one():
         for n in ref["final"]:
             assert float(abs(r["final"][n] - ref["final"][n]).max()) < 5e-5, (kind, n)
     # a library-held RCCL communicator (univl_amd.rccl): the exchange is part of the plan and the whole data-parallel iteration is ONE
-    # hipGraph; through torch's process group (UNIVL_DP_CAPTURE=0): captured segments with host-issued collectives between them
+    # hipGraph; through torch's process group (dp_capture=0): captured segments with host-issued collectives between them
     assert out["graph"]["mode"] == "whole" and out["graph_pg"]["mode"] == "segmented"
 
 
@@ -278,7 +280,6 @@ def _worker_ride(port, q):
         os.environ["MASTER_PORT"] = str(port)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ["UNIVL_DETERMINISTIC"] = "1"
-        os.environ["UNIVL_DP_CAPTURE"] = "1"
         import torch.distributed as dist
         torch.cuda.set_device(0)
         _setup_path()

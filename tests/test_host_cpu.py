@@ -160,8 +160,8 @@ def test_gemm_workgroup_to_tile_maps_are_bijections(gm):
                                      (dict(stage_two=True, task_type="caption", decoder_num_hidden_layers=1), "caption"),
                                      (dict(stage_two=True, do_pretrain=True, use_mil=True, decoder_num_hidden_layers=1), "pretrain")])
 @pytest.mark.parametrize("fresh", [True, False])
-def test_riding_weight_gradients_only_repackage_the_backward_plan(kw, kind, fresh, monkeypatch):
-    """UNIVL_WGRAD_RIDE: a weight-gradient GEMM goes out in the launch of the dgrad GEMM fed by the same upstream gradient
+def test_riding_weight_gradients_only_repackage_the_backward_plan(kw, kind, fresh, ab):
+    """wgrad_ride (univl_amd/_ab.py): a weight-gradient GEMM goes out in the launch of the dgrad GEMM fed by the same upstream gradient
     (univl_gemm_pair) instead of the layer's grouped launch.  Built on the CPU for every branch of UniVL.forward, the two
     backward plans must contain exactly the same GEMM descriptors (same shapes, flags, parameter / gradient / norm
     pointers), every other launch in the same order, and every pair must join the two halves of ONE nn.Linear: the dgrad
@@ -207,9 +207,9 @@ def test_riding_weight_gradients_only_repackage_the_backward_plan(kw, kind, fres
                 chain.append((name,))
         return chain, sorted(wgrads, key=repr), pairs
 
-    monkeypatch.setenv("UNIVL_WGRAD_RIDE", "0")
+    ab(wgrad_ride=0)
     base = build_step(m, kind, 2, 16, 16, True).backward_plan(fresh)
-    monkeypatch.setenv("UNIVL_WGRAD_RIDE", "1")
+    ab(wgrad_ride=None)
     ride = build_step(m, kind, 2, 16, 16, True).backward_plan(fresh)
     c0, w0, p0 = canon(base)
     c1, w1, p1 = canon(ride)
@@ -223,16 +223,16 @@ def test_riding_weight_gradients_only_repackage_the_backward_plan(kw, kind, fres
         assert dg.A == wg.A and dg.K == wg.M and dg.N == wg.N and dg.M == wg.K        # same upstream gradient dY [tokens, out]
 
 
-def test_adam_rider_plan_builds_on_cpu(monkeypatch):
-    """UNIVL_ADAM_RIDE (experimental): in the forward plan the four products of every text / video layer but the last become rider
+def test_adam_rider_plan_builds_on_cpu(ab):
+    """FlatParams.adam_ride (set by graphed.GraphedTrainStep): in the forward plan the four products of every text / video layer but the last become rider
     launches keyed by the NEXT layer of the same stack; nothing else changes, and the backward plan is untouched."""
     from univl_amd.steps import build_step
     m, cfg = _model("bf16")
     m._flat, m._seed_dev = FlatParams(list(m.named_parameters()), "cpu", torch.bfloat16), torch.zeros(1, dtype=torch.int64)
     m.train()
-    monkeypatch.setenv("UNIVL_ADAM_RIDE", "0")
+    m._flat.adam_ride = False
     base = build_step(m, "joint", 2, 16, 16, True)
-    monkeypatch.setenv("UNIVL_ADAM_RIDE", "1")
+    m._flat.adam_ride = True
     ride = build_step(m, "joint", 2, 16, 16, True)
     names0 = [op[3] for op in base.fwd.ops]
     names1 = [op[3] for op in ride.fwd.ops]
@@ -245,9 +245,9 @@ def test_adam_rider_plan_builds_on_cpu(monkeypatch):
     folds = [op for op in ride.fwd.ops if op[0] == "gemm_ln"]
     assert len(folds) == 2 * (L_t + L_v) and len([op for op in base.fwd.ops if op[0] == "gemm_ln"]) == len(folds)
     assert sum(1 for n in names1 if n == "univl_layernorm_fwd") == 2          # NormalizeVideo + the video embedding LayerNorm
-    monkeypatch.setenv("UNIVL_LN_FOLD", "0")
+    ab(ln_fold=0)
     unfolded = build_step(m, "joint", 2, 16, 16, True)
-    monkeypatch.delenv("UNIVL_LN_FOLD")
+    ab(ln_fold=None)
     assert sum(1 for op in unfolded.fwd.ops if op[3] == "univl_layernorm_fwd") == 2 + len(folds) and not [op for op in unfolded.fwd.ops if op[0] == "gemm_ln"]
     carried = {("layer", "bert", l) for l in range(1, L_t)} | {("layer", "visual", l) for l in range(1, L_v)}
     assert ride.fwd.rider_keys == carried
@@ -258,9 +258,9 @@ def test_adam_rider_plan_builds_on_cpu(monkeypatch):
     # ... and the backward twin: every LayerNorm backward of a stack but its topmost one rides in the pair launch of the dgrad that feeds it
     bw = [op[3] for op in ride.backward_plan(True).ops]
     assert bw.count("univl_gemm_pair_ln") == (2 * L_t - 1) + (2 * L_v - 1)
-    monkeypatch.setenv("UNIVL_LN_FOLD_BWD", "0")
+    ab(ln_fold_bwd=0)
     bw0 = [op[3] for op in build_step(m, "joint", 2, 16, 16, True).backward_plan(True).ops]
-    monkeypatch.delenv("UNIVL_LN_FOLD_BWD")
+    ab(ln_fold_bwd=None)
     assert bw0.count("univl_gemm_pair_ln") == 0 and bw0.count("univl_layernorm_bwd") == bw.count("univl_layernorm_bwd") + bw.count("univl_gemm_pair_ln")
 
 
@@ -327,9 +327,9 @@ def test_word_table_chunks_start_on_row_boundaries_and_plan_ops_are_capturable()
     assert [k for k, _ in p2.segments()] == ["graph", "eager", "graph"]
 
 
-def test_deep_weight_gradients_take_the_big_tile_without_fused_bias_gradients(monkeypatch):
+def test_deep_weight_gradients_take_the_big_tile_without_fused_bias_gradients(ab):
     """engine.EncoderStack where every dgrad product of a layer is on the 128 tile (>= 256 tiles of 128 x 128 for an H-wide output:
-    5462 tokens at H = 768 -- the weight gradients cannot ride with their dgrad there; UNIVL_WGRAD_BIG_MIN = tokens overrides), bf16:
+    5462 tokens at H = 768 -- the weight gradients cannot ride with their dgrad there; wgrad_big_min = tokens overrides), bf16:
     the layer's grouped weight gradients ask for the 128 tile on two stages and 4 waves; the two bias gradients (FFN1, QKV) stay in
     the descriptors and the C side takes them with column-sum workgroups of the same launch (round 4; round 3: two extra launches
     per layer).  Below, the plan is the former one (pairs).  Built on the CPU: the same weight-gradient outputs either way."""
@@ -352,10 +352,16 @@ def test_deep_weight_gradients_take_the_big_tile_without_fused_bias_gradients(mo
                 lambdas += 1
         return out, lambdas, pairs
 
-    monkeypatch.setenv("UNIVL_WGRAD_BIG_MIN", "1000000000")
+    ab(wgrad_big_min=1000000000)
     old, old_py, old_pairs = groups(build_step(m, "joint", B, W, W, True).backward_plan(True))
-    monkeypatch.delenv("UNIVL_WGRAD_BIG_MIN")
+    ab(wgrad_big_min=None, g256=0)
     new, new_py, new_pairs = groups(build_step(m, "joint", B, W, W, True).backward_plan(True))
+    # round 5 default (token count a multiple of 256): no tile request -- the C side runs the group on the 256 x 256 8-phase body
+    # (csrc/gemm256.h: auto256), bias gradients as column-sum roles as on the 128 tile
+    ab(g256=None)
+    g256, _, g256_pairs = groups(build_step(m, "joint", B, W, W, True).backward_plan(True))
+    assert len(g256) == layers and g256_pairs == 0
+    assert all((d.tile, d.stages, d.waves) == (0, 0, 0) and d.M % 256 == 0 and d.N % 256 == 0 and d.K % 256 == 0 for g in g256 for d in g)
     assert len(old) == len(new) == layers and old_pairs == new_pairs == 0      # no pair launches at this size either way
     assert new_py == old_py                              # no separate column-sum launches
     for go, gn in zip(old, new):

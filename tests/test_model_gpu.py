@@ -416,15 +416,14 @@ def test_default_atomic_mode_matches_deterministic(name, dtype):
     assert rel < (1e-4 if f32 else 4e-2), (name, rel)
 
 
-def test_large_batch_backward_paths_match_the_default_ones(monkeypatch):
+def test_large_batch_backward_paths_match_the_default_ones(ab):
     """Two backward forms that only switch on at large per-GPU batch -- position-table gradients by a gather over per-token rows
-    (UNIVL_DPOS_GATHER_MIN, default 32 rows per position) and the grouped weight gradients on the 128 tile with their bias gradients
-    taken by column-sum workgroups of the same launch (UNIVL_WGRAD_BIG_MIN, default 5462 tokens) -- forced on at the size of the
+    (dpos_gather_min, default 32 rows per position) and the grouped weight gradients on the 128 tile with their bias gradients
+    taken by column-sum workgroups of the same launch (wgrad_big_min, default 5462 tokens) -- forced on at the size of the
     golden case: every gradient tensor equals the default path's up to fp32 summation order (deterministic mode: the products
     themselves are bit-identical), and the golden gates hold."""
     ref = _grads_and_loss("joint_full", torch.bfloat16)
-    monkeypatch.setenv("UNIVL_DPOS_GATHER_MIN", "1")
-    monkeypatch.setenv("UNIVL_WGRAD_BIG_MIN", "1")
+    ab(dpos_gather_min=1, wgrad_big_min=1)
     new = _grads_and_loss("joint_full", torch.bfloat16)
     cfg, rows, dseed = case_config("joint_full")
     model, _ = build(cfg, torch.bfloat16)
@@ -803,16 +802,16 @@ def test_shaped_true_and_pretrain_without_captions():
     assert params["cls.predictions.transform.dense.weight"].grad is not None
 
 
-def test_sparse_word_table_bookkeeping_matches_dense_clear(monkeypatch):
+def test_sparse_word_table_bookkeeping_matches_dense_clear(ab):
     """Retrieval configurations clear only the word-table rows the previous backward wrote and take the table's gradient
     norm from those rows (engine.FlatParams.word_rows): same gradients, clip norm and parameters as the dense 94 MB clear +
-    streaming norm (UNIVL_SPARSE_ROWS=0), over changing batches, gradient accumulation and a foreign dense write."""
+    streaming norm (sparse_rows=0), over changing batches, gradient accumulation and a foreign dense write."""
     cfg, rows, dseed = case_config("joint_small")
     batches = [O.synthetic_batch(cfg, rows, seed=dseed + k) for k in range(4)]
     wname = "bert.embeddings.word_embeddings.weight"
 
     def run(sparse):
-        monkeypatch.setenv("UNIVL_SPARSE_ROWS", "1" if sparse else "0")
+        ab(sparse_rows=1 if sparse else 0)
         model, _ = build(cfg, torch.float32)
         model.train()
         opt = BertAdam(model.parameters(), lr=1e-4, warmup=-1, t_total=-1, weight_decay=0.01, max_grad_norm=1.0)
@@ -845,11 +844,11 @@ def test_sparse_word_table_bookkeeping_matches_dense_clear(monkeypatch):
 
 @pytest.mark.parametrize("ride", ["1", "0"])
 @pytest.mark.parametrize("name", ["joint_full", "caption_small", "pretrain_small"])
-def test_weight_gradient_packaging_matches_golden(golden_dir, name, ride, monkeypatch):
-    """UNIVL_WGRAD_RIDE=1 (default): every encoder weight-gradient GEMM goes out in the launch of the dgrad GEMM that consumes the
+def test_weight_gradient_packaging_matches_golden(golden_dir, name, ride, ab):
+    """wgrad_ride=1 (default): every encoder weight-gradient GEMM goes out in the launch of the dgrad GEMM that consumes the
     same upstream gradient (univl_gemm_pair); =0: the layer's grouped launch at the end of its chain.  Both give the loss and
     the gradients of the reference's golden vectors inside the ordinary bf16 gates, and the plan really is what the switch says."""
-    monkeypatch.setenv("UNIVL_WGRAD_RIDE", ride)
+    ab(wgrad_ride=int(ride))
     if ride == "0":                     # the default form is what every other golden test of this file runs
         test_forward_backward_vs_reference_golden(golden_dir, name, torch.bfloat16)
     cfg, rows, dseed = case_config(name)
@@ -865,14 +864,13 @@ def test_weight_gradient_packaging_matches_golden(golden_dir, name, ride, monkey
 
 
 @pytest.mark.parametrize("case", ["joint_full", "pretrain_small", "caption_small", "align_small"])
-def test_adam_update_riding_with_the_next_forward_matches_eager(case, monkeypatch):
-    """UNIVL_ADAM_RIDE=1 + GraphedTrainStep(pipeline_optimizer=True): the BertAdam update of iteration t is applied by the forward
+def test_adam_update_riding_with_the_next_forward_matches_eager(case):
+    """GraphedTrainStep(pipeline_optimizer=True): the BertAdam update of iteration t is applied by the forward
     of iteration t + 1 -- embedding tables, vectors and each stack's first layer as launches in front of it, the other layers'
     chunks as extra workgroups of the forward products of the layer before (univl_gemm_rider).  In deterministic mode the losses
     and the parameters are BIT-IDENTICAL to the eager loop's, iteration by iteration (same arithmetic per element, same gradients);
     the last update stays pending until flush()."""
     ref_l, ref_p, _ = _train("eager", case, dtype=torch.bfloat16)
-    monkeypatch.setenv("UNIVL_ADAM_RIDE", "1")
     l, p, info = _train("graph", case, dtype=torch.bfloat16)
     assert info["mode"] == "whole"
     assert l == ref_l, (l, ref_l)
@@ -880,8 +878,8 @@ def test_adam_update_riding_with_the_next_forward_matches_eager(case, monkeypatc
         assert torch.equal(p[n], ref_p[n]), (n, max_abs(p[n], ref_p[n]))
 
 
-def test_lazy_word_rows_update_is_bit_identical(monkeypatch):
-    """UnivlAdam.row_flags (UNIVL_ADAM_LAZY_ROWS, default on): chunks of word-table rows that never held a gradient take the
+def test_lazy_word_rows_update_is_bit_identical(ab):
+    """UnivlAdam.row_flags (adam_lazy_rows, default on): chunks of word-table rows that never held a gradient take the
     weight-decay-only form of the BertAdam update (10 instead of 30 bytes per parameter).  Same bits as the full update, over
     changing batches (the set of touched rows grows), gradient accumulation and a foreign write to the table's gradient."""
     cfg, rows, dseed = case_config("joint_small")
@@ -889,7 +887,7 @@ def test_lazy_word_rows_update_is_bit_identical(monkeypatch):
     wname = "bert.embeddings.word_embeddings.weight"
 
     def run(lazy):
-        monkeypatch.setenv("UNIVL_ADAM_LAZY_ROWS", "1" if lazy else "0")
+        ab(adam_lazy_rows=1 if lazy else 0)
         model, _ = build(cfg, torch.bfloat16)
         model.train()
         opt = BertAdam(model.parameters(), lr=1e-3, warmup=-1, t_total=-1, weight_decay=0.01, max_grad_norm=1.0)

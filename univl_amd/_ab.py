@@ -1,0 +1,98 @@
+"""The ONE place measurement / A-B overrides of the plan builder come from.
+
+Every plan choice in `univl_amd` is a function of the step descriptor (shapes, dtype, world size); its default is the measured-best
+setting and is what production runs.  For A/B measurements and for tests that must reach a non-default path, the defaults can be
+overridden through a single environment variable
+
+    UNIVL_AB="key=value,key=value"          e.g.  UNIVL_AB="ln_fold=0,splitk_tiles=0"
+
+parsed here, once per process.  Unknown keys are an error (a typo must not silently measure the default twice), and the variable is
+REFUSED unless the process has declared itself a measurement / test harness with `_ab.allow()` -- `bench.py`, `tests/conftest.py` and
+the scripts under `scripts/` do; a training script that inherits a stray UNIVL_AB from its shell fails at model construction instead
+of training a non-default plan.
+
+`KEYS` documents every override with its default; `get(key)` returns the override (converted to the default's type) or the default.
+"""
+import os
+
+# key -> (default, what it selects)
+KEYS = {
+    # ---- GEMM plan (engine.EncoderStack / DecoderStack, steps.py)
+    "wgrad_ride": (1, "weight gradients ride in their dgrad's launch (univl_gemm_pair); 0: the layer's grouped launch"),
+    "group_wgrad": (1, "a layer's non-riding weight gradients as ONE grouped launch; 0: one launch per member"),
+    "pair_form": ("", "'square': round 2's 64 x 64 form of the pair launch"),
+    "decoder_pair": (1, "pair launches in the decoder stack"),
+    "splitk_tiles": (128, "split the contraction of the N = 768 products while the 64 x 64 output grid has fewer tiles than this"),
+    "splitk_len": (384, "target slice depth of that split"),
+    "splitk_maxwg": (512, "cap on tiles x slices of that split"),
+    "splitk_mid": (1, "three-slice split of the deep (K >= 2304) N = 768 products at 128 .. 255 tiles"),
+    "splitk_mid_tiles": (256, "upper tile bound of that regime"),
+    "ln_fold": (1, "LayerNorm forward finished inside its product's launch (univl_gemm_ln) up to 512 tokens"),
+    "ln_fold_bwd": (1, "LayerNorm backward finished inside the dgrad pair launch (univl_gemm_pair_ln) below 384 tokens"),
+    "wgrad_big_min": (0, "token count from which a layer's grouped weight gradients take the big tile (0: where every dgrad does)"),
+    "g256": (1, "256 x 256 8-phase body (csrc/gemm256.h) for the grouped weight gradients / single products it is picked for; 0: the older tiles"),
+    "vocab_dgrad_split": (1, "split-K of the vocabulary dgrad (caption / pretrain heads)"),
+    "fused_sim": (1, "pooling + similarity + loss heads as fused launches up to 256 rows"),
+    "dpos_gather_min": (32, "rows per position from which position-table gradients are gathered instead of scatter-added"),
+    # ---- optimizer / step structure
+    "adam_ride": ("1", "BertAdam chunks ride with the next forward's products; '0': side-stream form; 'force': one graph even with a captured exchange"),
+    "adam_lazy_rows": (1, "weight-decay-only shortcut for word-table rows that never had a gradient"),
+    "adam_blocks": (0, "grid cap of the overlapped (non-riding) update"),
+    "pipeline_opt": (0, "experimental pipelined optimizer"),
+    "async_loss": (0, "experimental asynchronous loss read-back"),
+    "fused_norms": (1, "gradient norms from the weight-gradient epilogues"),
+    "sparse_rows": (1, "sparse bookkeeping of the word-table gradient"),
+    "sparse_emb": (1, "sparse exchange of the word-table gradient under data parallelism"),
+    "copy_kernel": (1, "input staging / loss hand-off as one copy kernel"),
+    "auto_graph": (1, "the unchanged training loop switches to graph replay on its own"),
+    "auto_dp": (1, "wrap in the bucketed reducer on its own when torch.distributed is initialised"),
+    "dp_capture": (1, "capture the RCCL exchange into the step graph"),
+    "dp_dryrun": (0, "measurement: the data-parallel schedule with the collectives not enqueued"),
+    # ---- measurement probes (results are meaningless)
+    "stamps": (0, "device timestamps between the nodes of the step"),
+    "probe_skip": ("", "a stack (bert | visual | cross) without its layer kernels"),
+    "probe_no_ln": ("", "fwd | bwd | both: the encoder LayerNorm launches left out"),
+    "poison": (0, "workspaces filled with NaN patterns"),
+    "guard": (0, "guard words around workspaces"),
+}
+
+_allowed = False
+_parsed = None
+
+
+def allow():
+    """Declare this process a measurement / test harness: UNIVL_AB is honoured from here on."""
+    global _allowed
+    _allowed = True
+
+
+def _parse():
+    global _parsed
+    raw = os.environ.get("UNIVL_AB", "")
+    if _parsed is not None and _parsed[0] == raw:
+        return _parsed[1]
+    out = {}
+    for item in [x for x in raw.split(",") if x.strip()]:
+        if "=" not in item:
+            raise RuntimeError("UNIVL_AB: expected key=value, got %r" % item)
+        k, v = (s.strip() for s in item.split("=", 1))
+        if k not in KEYS:
+            raise RuntimeError("UNIVL_AB: unknown key %r (known: %s)" % (k, ", ".join(sorted(KEYS))))
+        d = KEYS[k][0]
+        out[k] = type(d)(v) if not isinstance(d, int) else int(v)
+    if out and not _allowed:
+        raise RuntimeError("UNIVL_AB=%r is set, but this process is not a measurement or test harness (univl_amd._ab.allow()): "
+                           "A/B overrides of the plan builder are refused in training / evaluation runs" % raw)
+    _parsed = (raw, out)
+    return out
+
+
+def get(key):
+    if key not in KEYS:
+        raise KeyError("univl_amd._ab: unknown key %r" % key)
+    return _parse().get(key, KEYS[key][0])
+
+
+def overrides():
+    """The overrides in effect (for a bench line's `config`)."""
+    return dict(_parse())

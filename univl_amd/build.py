@@ -90,4 +90,8 @@ def _build_variant(tag, extra, force, verbose):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, trace="--trace" in sys.argv)
+    if "--variant" in sys.argv:        # python univl_amd/build.py --variant <tag> -DNAME=VALUE ...  ->  lib/libunivl_hip_<tag>.so (A/B builds, loaded with UNIVL_LIB=)
+        i = sys.argv.index("--variant")
+        _build_variant(sys.argv[i + 1], [x for x in sys.argv[i + 2:] if x.startswith("-D")], "--force" in sys.argv, True)
+    else:
+        build(force="--force" in sys.argv, trace="--trace" in sys.argv)

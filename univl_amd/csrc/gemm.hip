@@ -590,7 +590,7 @@ __device__ __forceinline__ void colsum_tile(const ColsumArgs& c, int tile, unsig
     if (tid < 64 && c0 + tid < c.n) {
         float sum = 0.f;
         for (int r = 0; r < RL; ++r) sum += red[r * 64 + tid];
-        c.out[c0 + tid] += sum;                        // the only writer of these 64 entries in this launch; the buffer is zeroed per backward
+        unsafeAtomicAdd(c.out + c0 + tid, sum);        // one owner per column in this launch (a single add: deterministic); atomic, so that launches on other streams may add to the same bias gradient
     }
 }
 
@@ -723,6 +723,13 @@ int launch_group256(const GroupArgs& g, hipStream_t stream) {
 // Arrival counters of the LayerNorm folds (ln_fold / ln_fold_bwd below): the last LN_SHARE workgroups to contribute to a 64-row block of a
 // product's output finish the LayerNorm work on that block.
 constexpr int LN_SHARE = 8;
+// Forward progress of the folds' spin (fold_arrive): the LN_SHARE - 1 earlier ones of a row block's last arrivals wait for the block's
+// LATER arrivals -- workgroups that may not have been dispatched yet (arrival order is not dispatch order).  That cannot deadlock as long
+// as the spinners can never occupy every resident-workgroup slot: at most 7 per row block spin, so a launch holds at most 7 x (row
+// blocks) spinning workgroups.  The entry points refuse more than 16 row blocks (1024 rows: 112 spinners against >= 512 slots of two
+// 512-thread workgroups per compute unit, also with a second fold launch running beside it on another stream); the plans fold up to
+// 512 rows (8 blocks).
+constexpr int LN_FOLD_MAX_BLOCKS = 16;
 
 struct LnFold {
     UnivlLayerNorm ln;
@@ -979,21 +986,30 @@ static bool fits256(const UnivlGemm* d, bool in_group) {
     if (d->dtype != UNIVL_BF16 || (d->trans_a && !d->trans_b) || d->M % 256 != 0 || d->N % 256 != 0) return false;
     if (d->dbias && !in_group) return false;
     if (d->sumsq && d->sumsq_rows % 256 != 0) return false;
+    // the epilogue moves 4 consecutive columns per lane: 16-byte fp32 / 8-byte bf16 accesses
+    if (d->ldc % 4 != 0 || (d->R && d->ldr % 4 != 0) || (d->aux && d->ldaux % 4 != 0) || !aligned16(d->C32) || !aligned16(d->R) ||
+        !aligned16(d->bias) || (((uintptr_t)d->C16 | (uintptr_t)d->aux) & 7) != 0) return false;
     const int ks = (d->ksplit < 1 || univl_deterministic()) ? 1 : d->ksplit;
     return d->K % (128 * ks) == 0;
 }
 
-// From where on the 256 body is picked without being asked for (tile = 0): rows in the thousands AND enough tiles (x K slices) to
-// occupy most of the 256 compute units -- one workgroup per unit, so below that the smaller tiles' two or three workgroups per
-// unit win (scripts/mb_gemm256.py, profiles/r05_mb_gemm256.txt).
+// From where on the 256 body is picked without being asked for (tile = 0).  One workgroup per compute unit, every workgroup of a launch
+// in the same phase: a launch costs its K loop (~1.1 us per 64-deep K tile with a third of the units busy, ~1.8 with all of them:
+// the units' LDS-DMA streams share the fabric) PLUS a prologue (1.6 us), an epilogue in which all units write at once (5 - 7 us of
+// HBM-bound stores with the matrix pipe idle) and a 5 us write-back drain behind it (profiles/r05c_trace_gemm256.txt).  So:
+//   * a layer's grouped weight gradients (contraction over >= 1536 tokens: 24+ K tiles per workgroup) always: 121 vs 147 us per layer at
+//     6144 tokens;
+//   * a single product only when it is ONE round that fills most of the chip (192 .. 256 workgroups): QKV forward at 6144 rows, 35 vs
+//     39.5 us; two-round shapes (FFN1 forward, FFN2 dgrad: 288 tiles) and the 72-tile N = 768 products lose to the 64 x 128 / 128 x 128
+//     tiles' two or three unsynchronised workgroups per unit (profiles/r05d_mb_rot.txt).
 constexpr int G256_MIN_ROWS = 1536;
-constexpr long G256_MIN_WG = 128;
+constexpr long G256_MIN_WG = 192, G256_MAX_WG = 256;
 static bool auto256(const UnivlGemm* d, bool in_group) {
     if (!fits256(d, in_group)) return false;
     const int ks = (d->ksplit < 1 || univl_deterministic()) ? 1 : d->ksplit;
     const long wg = (long)(d->M / 256) * (d->N / 256) * ks;
     const int rows = d->trans_a ? d->K : d->M;            // tokens: the contraction of a weight gradient
-    return rows >= G256_MIN_ROWS && (in_group || wg >= G256_MIN_WG);
+    return rows >= G256_MIN_ROWS && (in_group || (ks == 1 && wg >= G256_MIN_WG && wg <= G256_MAX_WG));
 }
 
 static Choice choose(const UnivlGemm* d, int forced_tile, int forced_nc = 0, bool allow_rect = false, bool in_group = false) {
@@ -1243,7 +1259,7 @@ static int pair_impl(const UnivlGemm* dgrad, const UnivlGemm* wgrad, const Univl
         // (ln_fold_bwd): square dgrad body only (below 384 tokens), fp32 output over N = 768 columns, pre-zeroed (atomics)
         UNIVL_CHECK_ARG(!univl_deterministic() && !drect && counters != nullptr && dgrad->C32 && !dgrad->C16 && dgrad->N == 768 &&
                             dgrad->ldc == 768 && !(dgrad->flags & (UNIVL_GEMM_GELU_FWD | UNIVL_GEMM_GELU_BWD | UNIVL_GEMM_ACCUM)) &&
-                            a.dnx * a.dnz >= LN_SHARE && ln->dtype == UNIVL_BF16 && ln->N == 768 && ln->rows == dgrad->M &&
+                            a.dnx * a.dnz >= LN_SHARE && a.dny <= LN_FOLD_MAX_BLOCKS && ln->dtype == UNIVL_BF16 && ln->N == 768 && ln->rows == dgrad->M &&
                             ln->dout == (const float*)dgrad->C32 && ln->gamma && ln->y && ln->stats && !ln->dpos &&
                             (const void*)ln->dx32 != (const void*)dgrad->C32,
                         UNIVL_EUNSUPPORTED, "univl_gemm_pair_ln: not a (dgrad, LayerNorm backward) pair this launch carries");
@@ -1339,7 +1355,7 @@ extern "C" int univl_gemm_ln(const UnivlGemm* gemm, const UnivlLayerNorm* ln, in
     UNIVL_CHECK_ARG(!univl_deterministic() && gemm->dtype == UNIVL_BF16 && !gemm->trans_a && !gemm->trans_b && c.tile == 64 && c.nc == 4 &&
                         !gemm->sumsq && !gemm->dbias && gemm->C32 && !gemm->C16 && gemm->N == 768 && gemm->ldc == 768 &&
                         !(gemm->flags & (UNIVL_GEMM_GELU_FWD | UNIVL_GEMM_GELU_BWD | UNIVL_GEMM_ACCUM)) && nx * ks >= LN_SHARE &&
-                        ny <= 64 && ln->dtype == UNIVL_BF16 && ln->N == 768 && ln->rows == gemm->M && !ln->x_f64 &&
+                        ny <= LN_FOLD_MAX_BLOCKS && ln->dtype == UNIVL_BF16 && ln->N == 768 && ln->rows == gemm->M && !ln->x_f64 &&
                         ln->x == (const void*)gemm->C32 && ln->gamma && ln->beta && (ln->out16 || ln->out32),
                     UNIVL_EUNSUPPORTED, "univl_gemm_ln: not a (product, LayerNorm) pair this launch carries");
     if (dry_run) return UNIVL_OK;

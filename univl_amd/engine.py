@@ -17,7 +17,7 @@ import weakref
 
 import torch
 
-from . import _lib, ops
+from . import _ab, _lib, ops
 
 @contextlib.contextmanager
 def no_gc():
@@ -41,8 +41,8 @@ def _workspace(dev, zeros=False):
     that a kernel reading something no kernel has written yet shows up in the outputs instead of depending on what the
     caching allocator happens to hand back; UNIVL_GUARD=1 puts a sentinel band before and after every buffer
     (check_guards() reports the buffers whose neighbourhood a kernel wrote into)."""
-    poison = os.environ.get("UNIVL_POISON", "0") == "1" and not zeros
-    guard = os.environ.get("UNIVL_GUARD", "0") == "1"
+    poison = bool(_ab.get("poison")) and not zeros
+    guard = bool(_ab.get("guard"))
 
     def e(*s, dtype=torch.float32):
         shape = tuple(s[0]) if (len(s) == 1 and isinstance(s[0], (tuple, list))) else tuple(s)
@@ -140,7 +140,7 @@ class FlatParams:
         # any optimizer created later) start at zero; every event after which a row's g / m / v can be non-zero without having gone
         # through univl_rows_append marks ALL rows (mark_all_word_rows).
         self.word_ever = None
-        if self.WORD in self.index and os.environ.get("UNIVL_ADAM_LAZY_ROWS", "1") != "0":
+        if self.WORD in self.index and _ab.get("adam_lazy_rows"):
             self.word_ever = torch.zeros(self.index[self.WORD][2][0], dtype=torch.uint8, device=self.device)
         self.word_ever_all = False
         self._gviews = {}
@@ -335,7 +335,7 @@ class Plan:
         """Independent GEMMs with the same operand layouts as ONE launch (univl_gemm_group), in chunks of GEMM_GROUP_MAX.
         max_blocks > 0: at most that many workgroups (the kernel walks its tiles)."""
         fn = _lib.lib().univl_gemm_group_limited
-        if os.environ.get("UNIVL_GROUP_WGRAD", "1") == "0":           # A/B switch: one launch per member
+        if not _ab.get("group_wgrad"):           # A/B: one launch per member
             for d in descs:
                 self.add("univl_gemm", d, stream)
             return
@@ -670,20 +670,20 @@ class EncoderStack:
         # kernels it now shares a launch with leave most compute units idle.  Measured 2.85 vs 3.11 ms per step at 4 pairs
         # (profiles/r02h_ab_wgrad_ride.txt).  bf16, 64 x 64 tiles only -- the C side refuses other pairs (univl_gemm_pair dry run)
         # and those weight gradients stay in the grouped launch.  UNIVL_WGRAD_RIDE=0: the grouped launch for all of them.
-        self.ride = os.environ.get("UNIVL_WGRAD_RIDE", "1") == "1" and flat.compute_dtype == torch.bfloat16
+        self.ride = bool(_ab.get("wgrad_ride")) and flat.compute_dtype == torch.bfloat16
         # The forward products of layer l can carry the BertAdam chunks of layer l + 1 (Plan.add_gemm_rider): switched on per model by
         # graphed.GraphedTrainStep(pipeline_optimizer=True) (flat.adam_ride), or for every model by UNIVL_ADAM_RIDE=1.
         # All passes of a stack through its layers in one forward (text / video: clean + masked pass; cross: up to three runs) are
         # enqueued one after the other on ONE stream, so a layer's update (carried by the FIRST pass through the layer before it)
         # is complete before anybody reads the layer.
-        self.adam_ride = ((getattr(flat, "adam_ride", False) or os.environ.get("UNIVL_ADAM_RIDE", "") == "1")
+        self.adam_ride = (getattr(flat, "adam_ride", False)
                           and flat.compute_dtype == torch.bfloat16 and prefix in ("bert", "visual", "cross"))
         # UNIVL_PROBE_SKIP=<prefix> (measurement only, scripts/probe_branches.py): this stack emits NO layer kernels, forward or
         # backward -- what the step costs without one of its two encoder branches (results are meaningless)
-        self.probe_skip = os.environ.get("UNIVL_PROBE_SKIP", "") == prefix
+        self.probe_skip = _ab.get("probe_skip") == prefix
         # UNIVL_PROBE_NO_LN=fwd|bwd|both (measurement only): the encoder layers' LayerNorm launches are left out of the plan -- the step
         # time then bounds from above what ANY fusion of those nodes into their neighbours could save (results are meaningless)
-        self.probe_no_ln = os.environ.get("UNIVL_PROBE_NO_LN", "")
+        self.probe_no_ln = _ab.get("probe_no_ln")
         # (Round 4, measured and removed: the video stack's first layer updated by a launch on the video stack's own stream instead of in
         # front of the whole forward -- 2.391 / 2.391 / 2.427 vs 2.392 / 2.396 / 2.397 ms per step, profiles/r04f_ab_update_slot.txt: the
         # prologue launches are HBM streams, two of them side by side each run at half speed.)
@@ -694,7 +694,7 @@ class EncoderStack:
         # step, fold vs two launches (profiles/r04p_ab_ln_fold.txt, r04q_ab_ln_fold_sizes.txt): 192 tokens 2.271 vs 2.333 ms (-2.6 %),
         # 384: 2.780 vs 2.829 (-1.7 %), 576: 3.144 vs 3.148, 768: 3.469 vs 3.415 (+1.6 %); FT-Align 3.193 vs 3.318 (-3.8 %).
         # UNIVL_LN_FOLD=0: two launches (A/B).  Deterministic mode falls back to the two launches (the C side refuses).
-        self.ln_fold = (flat.compute_dtype == torch.bfloat16 and B * S <= 512 and os.environ.get("UNIVL_LN_FOLD", "1") != "0"
+        self.ln_fold = (flat.compute_dtype == torch.bfloat16 and B * S <= 512 and bool(_ab.get("ln_fold"))
                         and prefix in ("bert", "visual", "cross"))
         self.key_mask = key_mask            # int64 [B,S] device tensor (static buffer)
         self.p = float(p_drop)
@@ -712,7 +712,7 @@ class EncoderStack:
         # ... and the backward twin (Plan.add_gemm_pair_ln: the LayerNorm backward behind the FFN1 / QKV dgrad, square pair form: < 384 tokens).
         # Measured (profiles/r04r_ab_ln_fold_bwd.txt, three interleaved pairs at 4 pairs): 2.231 vs 2.260 ms per step (-1.3 %; no fold at
         # all: 2.357), 288 tokens 2.656 vs 2.665, FT-Align 3.144 vs 3.184, pretrain 9.66 vs 9.75.  UNIVL_LN_FOLD_BWD=0: two launches (A/B).
-        self.ln_fold_bwd = self.ln_fold and T < 384 and os.environ.get("UNIVL_LN_FOLD_BWD", "1") != "0"
+        self.ln_fold_bwd = self.ln_fold and T < 384 and bool(_ab.get("ln_fold_bwd"))
         self.ln_ctr_b = torch.zeros(n_layers, 2, 2 * ((T + 63) // 64), dtype=torch.int32, device=dev) if self.ln_fold_bwd else None
         for l in range(n_layers):
             ws = dict(qkv=e(T, 3 * H, dtype=ct), lse=e(B, self.NH, S), ctx=e(T, H, dtype=ct),
@@ -739,20 +739,25 @@ class EncoderStack:
         #     workgroups pushed the weight-gradient tiles into a third round; the rectangular pair form (gemm.hip) fits them in one.
         self.tiles = ((T + 63) // 64) * (H // 64)
         # UNIVL_SPLITK_TILES: split the contraction of the N = 768 products while the 64 x 64 output grid has fewer tiles than this
-        self.splitk = splitk and self.tiles < int(os.environ.get("UNIVL_SPLITK_TILES", "128"))
-        self.splitk_mid = (splitk and not self.splitk and self.bf and self.tiles < int(os.environ.get("UNIVL_SPLITK_MID_TILES", "256"))
-                           and os.environ.get("UNIVL_SPLITK_MID", "1") != "0")
+        self.splitk = splitk and self.tiles < _ab.get("splitk_tiles")
+        self.splitk_mid = (splitk and not self.splitk and self.bf and self.tiles < _ab.get("splitk_mid_tiles")
+                           and bool(_ab.get("splitk_mid")))
         self.ks_h = self.ksplit_for(H) if self.splitk else 1
-        self.any_split = self.splitk or self.splitk_mid      # <=> the zero-once arenas are needed
+        self.any_split = self.splitk or self.splitk_mid
+        # the zero-once arenas are needed wherever contributions arrive as fp32 atomics: split products, and every product a LayerNorm
+        # fold rides on (univl_gemm_ln / univl_gemm_pair_ln force atomics also for unsplit products -- with splitk_tiles=0 the fold would
+        # otherwise add onto the previous step's output)
+        self.zero_y = self.any_split or self.ln_fold
+        self.zero_g = self.any_split or self.ln_fold_bwd
 
     def ksplit_for(self, K):
         if self.splitk_mid:
             return 3 if K >= 2304 else 1
         if not self.splitk:
             return 1
-        per = int(os.environ.get("UNIVL_SPLITK_LEN", "384"))
+        per = _ab.get("splitk_len")
         ks = max(1, (K + per - 1) // per)
-        cap = int(os.environ.get("UNIVL_SPLITK_MAXWG", "512"))
+        cap = _ab.get("splitk_maxwg")
         while ks > 1 and self.tiles * ks > cap:
             ks -= 1
         return ks
@@ -788,7 +793,7 @@ class EncoderStack:
         if self.probe_skip:
             return
         if zero_arena:
-            plan.add_zeros(([self.yarena] if self.any_split else []) + ([self.ln_ctr] if self.ln_ctr is not None else []), sm)
+            plan.add_zeros(([self.yarena] if self.zero_y else []) + ([self.ln_ctr] if self.ln_ctr is not None else []), sm)
         for l, ws in enumerate(self.layers):
             nm = self._names(l)
             plan.wait_point(("layer", self.prefix, l), sm)
@@ -866,7 +871,7 @@ class EncoderStack:
         if self.probe_skip:
             return
         if zero_arena:
-            plan.add_zeros(([self.garena] if self.any_split else []) + ([self.ln_ctr_b] if self.ln_ctr_b is not None else []), sm)
+            plan.add_zeros(([self.garena] if self.zero_g else []) + ([self.ln_ctr_b] if self.ln_ctr_b is not None else []), sm)
         # Weight gradients over thousands of tokens (UNIVL_WGRAD_BIG_MIN, bf16): the layer's grouped launch on the 128 x 128 tile
         # (two stages, 4 waves) with the two bias gradients it used to carry on a column-sum kernel instead.  The column-0
         # workgroups of a product with a fused bias gradient walk their staged A tile element by element every K step; with
@@ -876,10 +881,13 @@ class EncoderStack:
         # From where on: by default exactly where the weight gradients stop riding with their dgrad products anyway -- every dgrad of
         # the layer on the 128 tile (>= 256 tiles for the narrowest output, H columns: 5462 tokens at H = 768; gemm.hip choose /
         # univl_gemm_pair) -- which is the regime the measurements cover (6144 and 12288 tokens); UNIVL_WGRAD_BIG_MIN = tokens overrides.
-        big_min = os.environ.get("UNIVL_WGRAD_BIG_MIN")
-        big_wgrad = self.bf and (T >= int(big_min) if big_min else ((T + 127) // 128) * ((H + 127) // 128) >= 256)
-        wg_tile = dict(tile=128, stages=2, waves=4) if big_wgrad else {}
-        pair_square = os.environ.get("UNIVL_PAIR_FORM", "") == "square"
+        big_min = _ab.get("wgrad_big_min")
+        big_wgrad = self.bf and (T >= big_min if big_min else ((T + 127) // 128) * ((H + 127) // 128) >= 256)
+        # Round 5: from 1536 tokens on (multiples of 256) the grouped launch runs on the 256 x 256 8-phase body (csrc/gemm256.h; the C side
+        # picks it for tile = 0 -- `auto256`: 121 vs 147 us per layer at 6144 tokens, profiles/r05c_mb_gemm256.txt); g256=0 keeps the 128 tile.
+        g256 = self.bf and bool(_ab.get("g256")) and T % 256 == 0 and T >= 1536
+        wg_tile = {} if g256 else (dict(tile=128, stages=2, waves=4) if big_wgrad else {})
+        pair_square = _ab.get("pair_form") == "square"
         ln2_folded = False
         for l in range(self.L - 1, -1, -1):
             ws, nm = self.layers[l], self._names(l)
@@ -956,7 +964,7 @@ class EncoderStack:
             # ... the QKV dgrad feeds the output LayerNorm backward of the layer BELOW (next iteration)
             ln2_folded = emit(_gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["qkv_w"]), H, T, H, 3 * H, trans_b=1,
                                          out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ksplit_for(3 * H)), w_qkv,
-                                      ln2_desc(l - 1, dx) if l > 0 else None, 1)
+                                      ln2_desc(l - 1, dx) if (l > 0 and not wgrads) else None, 1)   # (a deferred weight gradient of this layer still reads s_dxd, which the folded LayerNorm overwrites)
             # the layer's four weight-gradient GEMMs only consume tensors the chain above produced (dxd, du, dxd2, dqkv
             # are distinct buffers): one grouped launch, after which the scratch may be reused by the next layer
             if wgrads:                                  # (self.ride: empty -- every weight gradient went out with its dgrad)
@@ -1024,7 +1032,7 @@ class DecoderStack:
     def build_forward(self, plan, x32, x16, enc16, training):
         fl, dt, H, I, B, Wd, Sk, Tq, Tkv, sm = self.flat, self.flat.dt, self.H, self.I, self.B, self.Wd, self.Sk, self.Tq, self.Tkv, self.sm
         p = self.p if training else 0.0
-        adam_ride = ((getattr(fl, "adam_ride", False) or os.environ.get("UNIVL_ADAM_RIDE", "") == "1")
+        adam_ride = (getattr(fl, "adam_ride", False)
                      and fl.compute_dtype == torch.bfloat16 and training)
         for l, ws in enumerate(self.layers):
             nm = self._names(l)
@@ -1087,7 +1095,7 @@ class DecoderStack:
         fl, dt, H, I, B, Wd, Sk, Tq, Tkv, sm = self.flat, self.flat.dt, self.H, self.I, self.B, self.Wd, self.Sk, self.Tq, self.Tkv, self.sm
         p = self.p if training else 0.0
         G = fl.g
-        ride = (os.environ.get("UNIVL_WGRAD_RIDE", "1") == "1" and os.environ.get("UNIVL_DECODER_PAIR", "1") != "0"
+        ride = (bool(_ab.get("wgrad_ride")) and bool(_ab.get("decoder_pair"))
                 and fl.compute_dtype == torch.bfloat16)
 
         def emit(wgrad, dgrad):

@@ -48,6 +48,7 @@ import os
 
 import torch
 
+from . import _ab
 from .engine import no_gc
 from .optimization import clip_grad_norm_
 from .steps import stage_input
@@ -64,9 +65,9 @@ class GraphedTrainStep:
         self.max_grad_norm = max_grad_norm
         self.warmup = int(warmup)
         self.persistent = bool(persistent_inputs)
-        self.pipeline = bool(pipeline_optimizer) or os.environ.get("UNIVL_PIPELINE_OPT", "0") == "1"
-        self.adam_blocks = int(os.environ.get("UNIVL_ADAM_BLOCKS", "0"))      # grid cap of the overlapped update (0: none)
-        self.async_loss = bool(async_loss) or os.environ.get("UNIVL_ASYNC_LOSS", "0") == "1"
+        self.pipeline = bool(pipeline_optimizer) or bool(_ab.get("pipeline_opt"))
+        self.adam_blocks = _ab.get("adam_blocks")      # grid cap of the overlapped update (0: none)
+        self.async_loss = bool(async_loss) or bool(_ab.get("async_loss"))
         # The pending update goes out as extra workgroups of the next forward's own launches (engine.Plan.add_gemm_rider) instead of a
         # second stream with one graph edge per layer: bf16, one process.  UNIVL_ADAM_RIDE=0: the side-stream form.  Measured on one MI355X
         # (profiles/r03b_ab_adam_ride.txt): 2.53 vs 2.74 ms per step at 4 pairs, 3.79 vs 4.23 at 16; bit-identical parameters
@@ -78,7 +79,7 @@ class GraphedTrainStep:
         # segmentation fault inside the replay; cause open).  One extra graph launch per iteration keeps the riding update in the
         # data-parallel step.  UNIVL_ADAM_RIDE=force: one graph anyway (the crashing form, for reproducing it); =0: no riders.
         red = getattr(model, "_reducer", None)
-        env = os.environ.get("UNIVL_ADAM_RIDE", "1")
+        env = _ab.get("adam_ride")
         self._ride_env = env
         self.ride = (self.pipeline and env != "0" and fl.compute_dtype == torch.bfloat16
                      and (red is None or red.capturable) and getattr(fl, "shard_reducer", None) is None)

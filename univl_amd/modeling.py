@@ -14,7 +14,7 @@ import os
 import torch
 from torch import nn
 
-from . import _lib, ops
+from . import _ab, _lib, ops
 from .engine import FlatParams, Plan
 from .parallel import BucketReducer, broadcast_parameters
 
@@ -324,7 +324,7 @@ def _loss_out(step):
     """A fresh 0-d tensor holding the step's loss (the step's own buffer is rewritten by the next forward).  A kernel node,
     not clone(): a device-to-device memcpy is a ~10 us node of the captured step."""
     out = torch.empty((), device=step.loss.device, dtype=step.loss.dtype)
-    if out.is_cuda and os.environ.get("UNIVL_COPY_KERNEL", "1") != "0":
+    if out.is_cuda and _ab.get("copy_kernel"):
         from . import ops
         ops.copy_many([(out, step.loss)])
     else:
@@ -395,7 +395,7 @@ class UniVL(UniVLPreTrainedModel):
             bert_config.intermediate_size == 3072, "kernels are specialised for H=768, 12 heads, I=3072"
 
         self.graph_backward = False
-        self.auto_graph = os.environ.get("UNIVL_AUTO_GRAPH", "1") != "0"
+        self.auto_graph = bool(_ab.get("auto_graph"))
         self._stage_one, self._stage_two = True, False
         if _check_attr("stage_two", tc):
             self._stage_one, self._stage_two = False, tc.stage_two
@@ -465,7 +465,7 @@ class UniVL(UniVLPreTrainedModel):
         loss.backward() through autograd so that DDP's bookkeeping for the anchor parameter stays consistent."""
         self._dp_checked = True
         import torch.distributed as dist
-        if os.environ.get("UNIVL_AUTO_DP", "1") == "0" or not (dist.is_available() and dist.is_initialized()):
+        if not _ab.get("auto_dp") or not (dist.is_available() and dist.is_initialized()):
             return
         if dist.get_world_size() > 1:
             self.enable_data_parallel()
@@ -564,7 +564,7 @@ class UniVL(UniVLPreTrainedModel):
         self._reducer = BucketReducer(fl.g32, process_group, loopback=loopback, force=force)
         if not self._reducer.active:
             self._reducer = None
-        elif os.environ.get("UNIVL_DP_CAPTURE", "1") != "0" and not loopback and fl.device.type == "cuda":
+        elif _ab.get("dp_capture") and not loopback and fl.device.type == "cuda":
             # RCCL: a communicator of our own, so that the exchange is captured into the step's hipGraph (univl_amd.rccl)
             try:
                 with torch.cuda.device(fl.device):

@@ -14,6 +14,8 @@ of every gradient during backward, plus a per-iteration unused-parameter bitmap 
 import torch
 import torch.distributed as dist
 
+from . import _ab
+
 
 class BucketReducer:
     """All-reduce (mean) contiguous slices of a flat gradient buffer, asynchronously, in a fixed order.
@@ -56,7 +58,7 @@ class BucketReducer:
         # UNIVL_DP_DRYRUN=1 (measurement only, bench.py --force-dp on one GPU): every stream fork / join, exchange point and
         # bookkeeping of the data-parallel schedule, but the collective itself is not enqueued -- separates what the SCHEDULE costs
         # from what RCCL's kernels cost (at world size 1 they still stream every bucket through HBM)
-        self.dryrun = os.environ.get("UNIVL_DP_DRYRUN", "0") == "1"
+        self.dryrun = bool(_ab.get("dp_dryrun"))
         self.measure = False
         self.timings = dict(collective_ms=0.0, exposed_ms=0.0, bytes=0, steps=0)
         self._ev = []

@@ -16,7 +16,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib, ops
+from . import _ab, _lib, ops
 from .engine import DecoderStack, EncoderStack, GradState, Plan, _SiteCounter, _gemm_desc
 
 H = 768
@@ -42,7 +42,7 @@ class Ctx:
         self.red = model._reducer
         # UNIVL_STAMPS=1 (measurement, scripts/probe_branches.py): device wall-clock stamps between the nodes of the step, so that the
         # start / end of the two encoder branches inside a captured replay can be read WITHOUT a profiler attached
-        self.stamps = {} if os.environ.get("UNIVL_STAMPS", "0") == "1" else None
+        self.stamps = {} if _ab.get("stamps") else None
         if self.stamps is not None:
             self.stamp_buf = torch.zeros(64, dtype=torch.int64, device=self.dev)
             model._stamps = (self.stamps, self.stamp_buf)
@@ -74,7 +74,7 @@ def stage_inputs(pairs):
     nodes of the captured step, ~10 us each in the round-2 kernel trace.  Everything else (host tensors, other dtypes, strided
     views) takes stage_input."""
     fast = []
-    use_kernel = os.environ.get("UNIVL_COPY_KERNEL", "1") != "0"        # A/B switch
+    use_kernel = bool(_ab.get("copy_kernel"))        # A/B
     for dst, src in pairs:
         src = torch.as_tensor(src)
         if (use_kernel and src.device == dst.device and dst.is_cuda and src.dtype == dst.dtype and src.numel() == dst.numel()
@@ -139,7 +139,7 @@ class EncoderPass:
         ST, SV = self.ST, self.SV
         # split-K accumulation targets; and the arrival counters of the LayerNorm folds (every launch leaves them zero: clearing them with
         # the arenas, in the same launch, only makes a step self-healing after a launch that did not complete)
-        fwd.add_zeros([st.yarena for st in (self.text, self.vis) if st.any_split] +
+        fwd.add_zeros([st.yarena for st in (self.text, self.vis) if st.zero_y] +
                       [st.ln_ctr for st in (self.text, self.vis) if st.ln_ctr is not None], ST)
         cx.stamp(fwd, "f_fork", ST)
         fwd.fork(ST, SV)           # the video encoder runs concurrently with the text encoder
@@ -170,7 +170,7 @@ class EncoderPass:
 
     def zero_list(self):
         """Accumulation buffers a backward clears before anything adds into them."""
-        return ([self.dseq, self.dvis, self.dvnorm] + [st.garena for st in (self.text, self.vis) if st.any_split] +
+        return ([self.dseq, self.dvis, self.dvnorm] + [st.garena for st in (self.text, self.vis) if st.zero_g] +
                 [st.ln_ctr_b for st in (self.text, self.vis) if st.ln_ctr_b is not None])
 
     def build_backward(self, bwd, gs, hook=None):
@@ -206,7 +206,7 @@ class EncoderPass:
     # (univl_rows_gather_sum) instead of B atomics per table element inside the fused kernels (128 pairs: embed_bwd 173 us, the video
     # embedding's LayerNorm backward 189 us -- profiles/r03q_bench_b128_kernel_stats.csv).  UNIVL_DPOS_GATHER_MIN=0: never.
     def _gather_dpos(self):
-        thr = int(os.environ.get("UNIVL_DPOS_GATHER_MIN", "32"))        # read when the plan is built (a test lowers it)
+        thr = _ab.get("dpos_gather_min")        # read when the plan is built (a test lowers it)
         return thr > 0 and self.B >= thr
 
     def _video_tail(self, bwd, gs, dxv):
@@ -295,7 +295,7 @@ class JointSim:
         self.norm = not bool(cx.tc.use_mil)
         # one launch for both poolings, one for the whole similarity-head backward (UNIVL_FUSED_SIM=0: the separate kernels); up to
         # 256 rows the per-row loop over the other modality's matrix is cheaper than two extra launches
-        self.fused = os.environ.get("UNIVL_FUSED_SIM", "1") != "0" and B <= 256
+        self.fused = bool(_ab.get("fused_sim")) and B <= 256
         self.lossfn = SimLoss(cx, loss_kind, B)
         self.loss = self.lossfn.loss
 
@@ -470,7 +470,7 @@ class VocabHead:
         # walks 239 K steps alone (a ~240 us latency chain at T = 512).  Split over the vocabulary so that ~512 workgroups share it
         # (fp32 atomics into the pre-zeroed dh; one slice in deterministic mode).  UNIVL_VOCAB_DGRAD_SPLIT=0: unsplit.
         ks = 1
-        if os.environ.get("UNIVL_VOCAB_DGRAD_SPLIT", "1") != "0":
+        if _ab.get("vocab_dgrad_split"):
             ks = max(1, min(16, 512 // max(1, ((T + 63) // 64) * (H // 64))))
         if ks > 1:
             bwd.add_zeros([self.dh], sm)
@@ -780,11 +780,11 @@ def build_step(model, kind, B, W, F, training):
         bwd = Plan()
         # Sparse exchange of the word-embedding gradient (94 MB dense, <= B*W non-zero rows): only where the token
         # gather is the table's sole gradient source (no tied decoder / MLM head in this step).
-        sparse = (cx.red is not None and kind in ("joint", "align") and os.environ.get("UNIVL_SPARSE_EMB", "1") != "0")
+        sparse = (cx.red is not None and kind in ("joint", "align") and bool(_ab.get("sparse_emb")))
         enc.sparse_word_grad = sparse
         # gradient norms from the wgrad epilogues: single-GPU only (after an all-reduce the local sums are not the
         # norms of the averaged gradients) and only where every matrix has one writer per backward
-        fuse = (cx.red is None and kind in ("joint", "align", "caption") and os.environ.get("UNIVL_FUSED_NORMS", "1") != "0")
+        fuse = (cx.red is None and kind in ("joint", "align", "caption") and bool(_ab.get("fused_norms")))
         gs = GradState(fl, fresh, fuse_sumsq=fuse)
         hook, buckets, sched = _ddp_hook(cx, fl, model, kind)
         # A layer reports its gradient slice to the exchange schedule only after its LAST writer in this backward: the
@@ -798,7 +798,7 @@ def build_step(model, kind, B, W, F, training):
         # (the token gather is the word table's only gradient source): the 94 MB table is not cleared as a whole, only the
         # rows the previous backward wrote (engine.FlatParams.word_rows).
         world = 1 if cx.red is None else max(1, cx.red.world)
-        rows_mode = (kind in ("joint", "align") and os.environ.get("UNIVL_SPARSE_ROWS", "1") != "0"
+        rows_mode = (kind in ("joint", "align") and bool(_ab.get("sparse_rows"))
                      and (cx.red is None or sparse)        # a dense all-reduce of the table fills rows nobody listed
                      and enc.Tt * (world if sparse else 1) <= fl.WORD_ROWS_CAP)
         zeros = [fl.sumsq, fl.partials] if fuse else []
