@@ -172,7 +172,12 @@ def cpu_baseline(batch_rows, budget_s=20.0):
 # configuration (tests/test_model_gpu.py golden fixtures of the real reference, tests/golden/<case>.npz).
 OTHER_CONFIGS = [
     ("cfg3_share_of_8_gpus_16_pairs", ["--batch", "16"], {}, "joint_b16"),
+    ("cfg3_share_of_4_gpus_32_pairs", ["--batch", "32"], {}, "joint_b32"),
+    ("cfg3_share_of_2_gpus_64_pairs", ["--batch", "64", "--steps", "10", "--warmup", "3"], {}, "joint_b64"),
     ("cfg3_on_one_gpu_128_pairs", ["--batch", "128", "--steps", "10", "--warmup", "3"], {}, "joint_b128"),
+    # the UNCHANGED training loop of main_task_retrieval.py:333-353 (model(...), loss.backward(), clip_grad_norm_, optimizer.step(),
+    # optimizer.zero_grad(), float(loss)) -- no GraphedTrainStep: per-plan graph replay + the BertAdam update riding with the next forward
+    ("unchanged_loop_4_pairs", ["--no-graph"], {}, "test_unchanged_training_loop_switches_to_graph_replay"),
     ("ft_align_48x48", ["--kind", "align"], {}, "align_full, align_full_cot"),
     ("cfg4_caption_128x96", ["--kind", "caption"], {}, "caption_full"),
     ("cfg5_pretrain_48x64_6_rows", ["--kind", "pretrain", "--batch", "6"], {}, "pretrain_full, pretrain_full_cot"),
@@ -424,6 +429,8 @@ def main():
         if gstep is not None:
             gstep.flush()            # a riding optimizer update is still pending: it belongs to the timed steps (conservative: the region
                                      # then holds steps + 1 updates, the first one left over by the warm-up)
+        else:
+            opt.flush()              # the unchanged loop (--no-graph): BertAdam.step() left its update to the next forward, same accounting
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

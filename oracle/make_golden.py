@@ -48,6 +48,9 @@ CASES = {
     # cfg3 (MSRVTT retrieval, global bs 128): 16 rows per GPU on 8 GPUs, 128 rows on one GPU
     "joint_b16": (dict(batch_size=16), 16, 1316),
     "joint_b128": (dict(batch_size=128), 128, 13128),
+    # ... and its 4- / 2-GPU shares: 32 / 64 rows per GPU (1536 / 3072 tokens: where the plans change to the 256 x 256 GEMM body, round 5)
+    "joint_b32": (dict(batch_size=32), 32, 1332),
+    "joint_b64": (dict(batch_size=64), 64, 1364),
     # FT-Align (--train_sim_after_cross) at 48x48: 16 (text, video) pairs x 96 tokens through the 2-layer cross encoder
     # (data seed picked so that no hinge argument of the 4x4 max-margin loss, margin + s_ij - s_ii, is closer than 0.07 to
     #  zero: with seed 2104 one sits at 8.5e-4, inside the bf16 noise of the logits (2e-3), and whether that hinge counts --
@@ -60,7 +63,7 @@ CASES = {
     "pretrain_full": (dict(batch_size=2, n_pair=3, stage_two=True, do_pretrain=True, use_mil=True,
                            task_type="retrieval", max_words=48, max_frames=64), 2, 4106),
 }
-FULL_CASES = ["joint_b16", "joint_b128", "align_full", "caption_full", "pretrain_full"]
+FULL_CASES = ["joint_b16", "joint_b32", "joint_b64", "joint_b128", "align_full", "caption_full", "pretrain_full"]
 
 
 def case_config(name):

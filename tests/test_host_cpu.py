@@ -373,9 +373,17 @@ def test_deep_weight_gradients_take_the_big_tile_without_fused_bias_gradients(ab
         for d in gn:
             assert (d.tile, d.stages, d.waves) == (128, 2, 4) and d.trans_a and d.trans_b and d.K == B * W
             assert d.sumsq_rows % 128 == 0                # the fused gradient norms stay legal on the 128 tile
-    # 2048 tokens: the weight gradients of the H-wide dgrad products still ride with them -- the former plan, untouched
+    # 2048 tokens (a multiple of 256 from 1536 on): round 5 -- no weight gradient rides any more, all four per layer in the grouped launch
+    mid, mid_py, mid_pairs = groups(build_step(m, "joint", 128, 16, 16, True).backward_plan(True))
+    assert mid_pairs == 0 and len(mid) == layers and all(len(g) == 4 and all((d.tile, d.stages, d.waves) == (0, 0, 0) for d in g) for g in mid)
+    # ... the former plan (g256=0): the weight gradients of the H-wide dgrad products ride with them
+    ab(g256=0)
     mid, mid_py, mid_pairs = groups(build_step(m, "joint", 128, 16, 16, True).backward_plan(True))
     assert mid_pairs > 0 and all((d.tile, d.stages, d.waves) == (0, 0, 0) for g in mid for d in g)
+    # ... and 1200 tokens (not a multiple of 256): pair launches as before
+    ab(g256=None)
+    small, _, small_pairs = groups(build_step(m, "joint", 75, 16, 16, True).backward_plan(True))
+    assert small_pairs > 0
 
 
 def test_layernorm_fold_entry_points_validate_on_the_host():

@@ -611,7 +611,11 @@ struct GroupArgs {
 // weight-gradient launch (engine.EncoderStack, UNIVL_WGRAD_BLOCKS) occupies only that many workgroups while the next
 // layer's latency-bound dgrad chain runs beside it on another stream.
 template <typename T, bool TA, bool TB, int BM, int BN, int NC, int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_group_kernel(GroupArgs g) {
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_group_kernel(GroupArgs by_value) {
+  // Read the argument struct THROUGH THE KERNARG POINTER: a member's arguments are then scalar loads with a uniform dynamic index.
+  // (By-value selects over all four members cost 175 - 245 spilled SGPRs per instantiation -- VERDICT r4.)
+  (void)by_value;
+  const GroupArgs& g = *(const GroupArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   const int total = g.first[UNIVL_GEMM_GROUP_MAX];
   const int ncs = g.cs_first[UNIVL_GEMM_GROUP_MAX];
   const bool remap = (g.p[0].flags & UNIVL_GEMM_XCD_MAP) && (int)gridDim.x >= total + ncs && total >= 16;   // one workgroup per tile
@@ -620,11 +624,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_group_kernel(GroupArgs
         int m = 0;
 #pragma unroll
         for (int i = 1; i < UNIVL_GEMM_GROUP_MAX; ++i) m += (v0 >= g.cs_first[i]) ? 1 : 0;
-        ColsumArgs c = g.cs[0];
-        int cf = g.cs_first[0];
-#pragma unroll
-        for (int i = 1; i < UNIVL_GEMM_GROUP_MAX; ++i)
-            if (m == i) { c = g.cs[i]; cf = g.cs_first[i]; }
+        const ColsumArgs c = g.cs[m];
+        const int cf = g.cs_first[m];
         if constexpr (sizeof(T) == 2) { if (v0 - cf < c.n_tiles) colsum_tile<64 * WGM * WGN>(c, v0 - cf, smem_raw); }
         if ((int)gridDim.x < total + ncs) __syncthreads();
         continue;
@@ -634,12 +635,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_group_kernel(GroupArgs
     int idx = 0;
 #pragma unroll
     for (int i = 1; i < UNIVL_GEMM_GROUP_MAX; ++i) idx += (w >= g.first[i]) ? 1 : 0;
-    // uniform select (no dynamic indexing of the kernel-argument struct)
-    GemmArgs p = g.p[0];
-    int first = g.first[0], nx = g.nx[0], nxy = g.nxy[0], nz = g.nz[0];
-#pragma unroll
-    for (int i = 1; i < UNIVL_GEMM_GROUP_MAX; ++i)
-        if (idx == i) { p = g.p[i]; first = g.first[i]; nx = g.nx[i]; nxy = g.nxy[i]; nz = g.nz[i]; }
+    const GemmArgs p = g.p[idx];
+    const int first = g.first[idx], nx = g.nx[idx], nxy = g.nxy[idx], nz = g.nz[idx];
     const int local = w - first;
     int bx, by, bz;
     if (remap) {
@@ -1027,6 +1024,14 @@ static Choice choose(const UnivlGemm* d, int forced_tile, int forced_nc = 0, boo
         return c;
     }
     c.tile = (want >= 128 || (want == 0 && tiles128 >= GEMM_BIG_MIN)) ? 128 : 64;
+    if (want == 0 && c.tile == 64 && rect_ok && d->waves == 0) {
+        // Round 5: between the regimes -- fewer than 256 tiles of 128 x 128, but at least 256 of 64 x 128 (N = 768 outputs at 2731+ rows,
+        // N = 2304 at 911+): the half tile beats the 64 x 64 tile by 15 - 25 % (3072 rows: QKV dgrad 31.6 vs 39.6 us, FFN1 dgrad 39.5 vs
+        // 50.6, FFN2 forward 33.8 vs 39.9; 1536 rows: QKV forward 14.4 vs 18.4; profiles/r05a_mb_gemm256_first_version.txt), while
+        // below that the 64 tile's extra parallelism wins (1536 rows, N = 768: 22 - 28 vs 29 - 37 us).
+        const long tiles_r = (long)((d->M + 63) / 64) * ((d->N + 127) / 128);
+        if (tiles_r >= GEMM_BIG_MIN) return Choice{64128, 2, 8};
+    }
     if (want == 0 && c.tile == 128 && rect_ok && d->waves == 0) {
         // fill of the resident-workgroup slots in the last round: tiles / (rounds x slots)
         const long tiles_r = (long)((d->M + 63) / 64) * ((d->N + 127) / 128);

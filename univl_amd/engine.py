@@ -670,7 +670,14 @@ class EncoderStack:
         # kernels it now shares a launch with leave most compute units idle.  Measured 2.85 vs 3.11 ms per step at 4 pairs
         # (profiles/r02h_ab_wgrad_ride.txt).  bf16, 64 x 64 tiles only -- the C side refuses other pairs (univl_gemm_pair dry run)
         # and those weight gradients stay in the grouped launch.  UNIVL_WGRAD_RIDE=0: the grouped launch for all of them.
-        self.ride = bool(_ab.get("wgrad_ride")) and flat.compute_dtype == torch.bfloat16
+        # Round 5: from 1536 tokens on (multiples of 256, bf16) NO weight gradient rides -- all four go into the layer's grouped launch,
+        # which the C side runs on the 256 x 256 8-phase body (csrc/gemm256.h), and every dgrad is a launch of its own on the tile
+        # `choose` picks for it.  The pair launches were built for a few hundred tokens; at 3072 the QKV / FFN1 pairs (square 64 x 64
+        # dgrad body walking a 2304 / 3072-deep contraction + 128 x 64 weight-gradient tiles) ran 112 us each, 36 of them per step = 4.0
+        # of the 9.2 ms of the 64-pair step (profiles/r05f_bench_b64_kernel_stats.csv), against ~32 + ~40 us for the two dgrads alone
+        # and 68 us for the layer's whole group.  g256=0 (univl_amd/_ab.py): the former plans.
+        self.g256 = flat.compute_dtype == torch.bfloat16 and bool(_ab.get("g256")) and (B * S) % 256 == 0 and B * S >= 1536
+        self.ride = bool(_ab.get("wgrad_ride")) and flat.compute_dtype == torch.bfloat16 and not self.g256
         # The forward products of layer l can carry the BertAdam chunks of layer l + 1 (Plan.add_gemm_rider): switched on per model by
         # graphed.GraphedTrainStep(pipeline_optimizer=True) (flat.adam_ride), or for every model by UNIVL_ADAM_RIDE=1.
         # All passes of a stack through its layers in one forward (text / video: clean + masked pass; cross: up to three runs) are
@@ -885,8 +892,7 @@ class EncoderStack:
         big_wgrad = self.bf and (T >= big_min if big_min else ((T + 127) // 128) * ((H + 127) // 128) >= 256)
         # Round 5: from 1536 tokens on (multiples of 256) the grouped launch runs on the 256 x 256 8-phase body (csrc/gemm256.h; the C side
         # picks it for tile = 0 -- `auto256`: 121 vs 147 us per layer at 6144 tokens, profiles/r05c_mb_gemm256.txt); g256=0 keeps the 128 tile.
-        g256 = self.bf and bool(_ab.get("g256")) and T % 256 == 0 and T >= 1536
-        wg_tile = {} if g256 else (dict(tile=128, stages=2, waves=4) if big_wgrad else {})
+        wg_tile = {} if self.g256 else (dict(tile=128, stages=2, waves=4) if big_wgrad else {})
         pair_square = _ab.get("pair_form") == "square"
         ln2_folded = False
         for l in range(self.L - 1, -1, -1):

@@ -62,6 +62,8 @@ class GraphedTrainStep:
         calls may pass the same tensors refilled in place (no copy at all), and any OTHER batch passed later is copied INTO them,
         i.e. the caller's first batch is overwritten; a caller that keeps or mutates that batch must not use this mode."""
         self.model, self.opt = model, optimizer
+        model.auto_ride = False          # this object schedules the optimizer update itself (BertAdam.step() must not defer on its own)
+        optimizer.flush()
         self.max_grad_norm = max_grad_norm
         self.warmup = int(warmup)
         self.persistent = bool(persistent_inputs)

@@ -10,6 +10,7 @@ the static plans of `univl_amd.engine` -- there is no PyTorch compute path and n
 import json
 import logging
 import os
+import weakref
 
 import torch
 from torch import nn
@@ -494,6 +495,16 @@ class UniVL(UniVLPreTrainedModel):
         if o is not None and not self._in_pipelined_call:
             o.flush()
 
+    def named_parameters(self, *a, **kw):
+        """(parameters() goes through here.)  A BertAdam update that optimizer.step() left for the next forward (the unchanged training
+        loop, _adopt_pending_update) is applied before anybody is handed the parameters through the module API; the training loop
+        itself asks for them only between backward and step (clip_grad_norm_(model.parameters(), ...), main_task_retrieval.py:347),
+        where nothing is pending."""
+        o = self.__dict__.get("_pending_update")
+        if o is not None and getattr(o, "_auto_deferred", False):
+            self._flush_pending()
+        return super().named_parameters(*a, **kw)
+
     def state_dict(self, *a, **kw):
         self._flush_pending()
         fl = self._flat
@@ -548,6 +559,11 @@ class UniVL(UniVLPreTrainedModel):
                 with torch.cuda.device(p0.device):         # fixed-order reductions (bit-reproducible runs): include/univl_hip.h
                     _lib.set_deterministic(True)
             self._flat = FlatParams(named, p0.device, self.compute_dtype)
+            self._flat.owner = weakref.ref(self)
+            # forward plans are built with rider slots (engine.Plan.add_gemm_rider: a plain product unless an update rides) wherever a
+            # BertAdam update CAN ride with the next forward -- the captured step of graphed.GraphedTrainStep and, round 5, the unchanged
+            # training loop (optimization.BertAdam.step defers itself, UniVL.forward applies it: _adopt_pending_update)
+            self._flat.adam_ride = self.compute_dtype == torch.bfloat16 and _ab.get("adam_ride") != "0"
             self._seed_dev = torch.zeros(1, device=p0.device, dtype=torch.int64)
             self._steps = {}
         return self._flat
@@ -650,8 +666,19 @@ class UniVL(UniVLPreTrainedModel):
         host-issued collectives) and replayed from then on -- the unchanged training loop of main_task_retrieval.py:333-352
         then runs close to the fully captured step of graphed.GraphedTrainStep.  UNIVL_AUTO_GRAPH=0 turns it off; inside
         somebody else's capture the plan is always enqueued directly."""
-        hot = self.auto_graph and st.calls > self.AUTO_GRAPH_AFTER and not plan.rider_keys    # rider plans differ from run to run
+        hot = self.auto_graph and st.calls > self.AUTO_GRAPH_AFTER
         if (self.graph_backward or hot) and not torch.cuda.is_current_stream_capturing():
+            if plan.rider_keys:
+                # a captured plan holds the riding update's descriptor and chunk ranges: replay only while they are the ones captured
+                # (steady state of a training loop: same optimizer tables, same buffers), else capture again
+                rd = plan.riders
+                sig = None if rd is None else (bytes(rd["desc"]), tuple(sorted(rd["ranges"].items())), int(rd.get("max_blocks", 0)))
+                if plan._segments is not None and getattr(plan, "_rider_sig", None) != sig:
+                    plan._segments = None
+                if plan._segments is None and sig is not None:
+                    import ctypes as C                  # the rider kernels' large-LDS opt-in must not happen inside the capture
+                    _lib.check(_lib.lib().univl_gemm_rider_prime(C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm_rider_prime")
+                plan._rider_sig = sig
             plan.run_graphed()
         else:
             plan.run()
@@ -700,7 +727,9 @@ class UniVL(UniVLPreTrainedModel):
             raise RuntimeError("UniVL.forward: the caption path needs input_caption_ids / decoder_mask / output_caption_ids")
         if not self._dp_checked:
             self._auto_data_parallel()
-        self._flush_pending()
+        adopted = self._adopt_pending_update()
+        if not adopted:
+            self._flush_pending()
         fl = self.flat
         if getattr(fl, "shard_reducer", None) is not None:
             fl.shard_reducer.join()            # the all-gather of the updated shadow must have landed
@@ -726,6 +755,27 @@ class UniVL(UniVLPreTrainedModel):
             return _loss_out(st)
         finally:
             st.fwd.riders = None
+            if adopted:
+                self._rider_update = None
+
+    def _adopt_pending_update(self):
+        """The unchanged training loop (main_task_retrieval.py:333-353): optimizer.step() left its BertAdam update pending
+        (optimization.BertAdam.step: auto-deferred), and THIS forward applies it -- the chunk groups the plan cannot carry as launches in
+        front of it, the rest as extra workgroups of its own products (_start_riding_update) -- exactly what the captured step of
+        graphed.GraphedTrainStep does.  Anything else that reads the parameters flushes the update first (_flush_pending)."""
+        o = self._pending_update
+        if (o is None or self._in_pipelined_call or self._rider_update is not None or not getattr(o, "has_pending", False)
+                or not getattr(o, "_auto_deferred", False)):
+            return False
+        fl = self.flat
+        if not getattr(fl, "adam_ride", False) or getattr(fl, "shard_reducer", None) is not None or torch.cuda.is_current_stream_capturing():
+            return False
+        self._rider_update = dict(desc=o._last_desc, groups=o.chunk_groups(), max_blocks=0)
+        o._deferred = False                   # from here on the update counts as applied (launch_deferred's bookkeeping)
+        o._auto_deferred = False
+        fl.shadow_valid = True
+        self.auto_ride_count = getattr(self, "auto_ride_count", 0) + 1
+        return True
 
     def _start_riding_update(self, st, ru):
         """Riding optimizer update (univl_amd.graphed, UNIVL_ADAM_RIDE): the BertAdam update of the previous iteration is applied BY this
