@@ -40,8 +40,11 @@ GATES = {
     torch.float32: dict(hidden=1e-3, sim=1e-3, logits=1e-3, loss=1e-3, gnorm=1e-3, gsample=2e-3, gtop=2e-3, gmedian=1e-3,
                         gp95=1e-3, gglobal=1e-3, gcos=1e-5),
     # round 4: tightened to ~1.3 x the worst measured value of the cases that use them (cfg1-3, cfg4): gnorm 3.2e-3, gtop 1.3e-2,
-    # gmedian 1.0e-2, gp95 1.5e-2, gglobal 1.2e-2, gcos 7.1e-5 -- and see check_against_reference_bf16 for the yardstick
-    torch.bfloat16: dict(hidden=5e-2, sim=1e-2, logits=1e-2, loss=1e-2, gnorm=6e-3, gsample=4e-2, gtop=2e-2, gmedian=1.5e-2,
+    # gmedian 1.0e-2, gp95 1.5e-2, gglobal 1.2e-2, gcos 7.1e-5 -- and see check_against_reference_bf16 for the yardstick.
+    # round 5: gnorm 6e-3 -> 8.5e-3: the worst per-tensor norm error of joint_b128 measures 6.6e-3 with the grouped weight gradients on the
+    # 256 x 256 body (32x32x16 MFMA chunks: another fp32 summation order over 6144 tokens; 4.6e-3 on the 128 tile) -- 0.47 x the
+    # reference's own bf16 autocast run on that case (1.41e-2, tests/golden/bf16_autocast_noise.json), which stays the binding gate
+    torch.bfloat16: dict(hidden=5e-2, sim=1e-2, logits=1e-2, loss=1e-2, gnorm=8.5e-3, gsample=4e-2, gtop=2e-2, gmedian=1.5e-2,
                          gp95=2e-2, gglobal=1.3e-2, gcos=1.5e-4),
 }
 # Branch-specific bf16 GRADIENT gates.
@@ -262,6 +265,8 @@ def plan_ops(model):
     """names of every enqueue of the model's built step plans (forward + both backward forms)"""
     out = []
     for st in model._steps.values():
+        if not hasattr(st, "fwd"):
+            continue                   # the evaluation entry points keep other objects in the same cache
         out += [op[3] for op in st.fwd.ops]
         for fresh in (True, False):
             try:
@@ -679,6 +684,7 @@ def _train(kind, case, steps=5, lr=1e-5, dtype=torch.float32):
             opt.zero_grad()
             losses.append(float(loss))
         mode = "eager"
+        opt.flush()          # bf16: step() leaves its update to the next forward; the parameters are read below past the module API (flat.w32)
     used = model.used_parameter_names()
     final = {n: model.flat.w32(n).detach().float().cpu() for n in (used[0], used[3], used[len(used) // 2], used[-1])}
     red = model._reducer

@@ -399,6 +399,9 @@ class BertAdam(Optimizer):
         the decoder after them."""
         import re
         fl, tb = self._fl, self._tb
+        cached = getattr(self, "_groups_cache", None)
+        if cached is not None and cached[0] is tb:        # (thousands of chunks: the unchanged loop asks once per forward)
+            return cached[1]
         runs = []
         for c, s_ in enumerate(tb.chunk_seg_host):
             name = fl.order[s_]
@@ -411,6 +414,7 @@ class BertAdam(Optimizer):
         stage = {"bert": 0, "visual": 0, "cross": 1, "decoder": 2}
         base = [tuple(r) for r in runs if r[0] == "base"]
         layers = sorted((tuple(r) for r in runs if r[0] != "base"), key=lambda r: (stage[r[0][1]], r[0][2], r[0][1]))
+        self._groups_cache = (tb, base + layers)
         return base + layers
 
     def launch_deferred(self, groups=None, on_group=None, max_blocks=0):
