@@ -24,6 +24,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // 16-byte staging register.  A NATIVE vector, not HIP's uint4 struct: arrays of the struct type handed through
 // inlined helpers were demoted to scratch memory by hipcc (ROCm 7.2), arrays of native vectors stay in VGPRs.
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 #define UNIVL_WAVE 64
 

@@ -165,6 +165,22 @@ template <typename T, bool TR, int ROWS, int BK, int NT = 256> struct Tile {
         const int b = e * (int)sizeof(T);
         return reinterpret_cast<const T*>(stage + byte_of(r, b >> 4) + (b & 15));
     }
+    // T-major bf16 fragment as two INLINE-ASM transpose reads (lo: k-slots 4g .. 4g+3, hi: 16+4g .. 16+4g+3 of the chunk).  Round 5: for
+    // the builtin (Mma::tr_pair) hipcc cannot prove that the read does not alias the LDS-DMA of the NEXT tile, which gemm_tile has
+    // just issued, and emits `s_waitcnt vmcnt(0)` in front of the first transpose read of every K step -- the double buffer of every
+    // dgrad / weight-gradient product was a single buffer (DMA round trip + multiply per step, never overlapped).  hipcc does not
+    // count an asm load: the caller waits (lgkmcnt(0) naming every destination) before it uses lo / hi (guide 5.7 item 1, form ii).
+    __device__ static __forceinline__ void frag_tr(const unsigned char* stage, int r16, int c, int lane, u32x2_t& lo, u32x2_t& hi) {
+        static_assert(TR && sizeof(T) == 2, "transpose reads: T-major bf16 tiles");
+        typedef __attribute__((address_space(3))) unsigned char lds_u8;
+        const int g = lane >> 4, i = lane & 15;
+        const int krow = c * 32 + 4 * g + (i >> 2);
+        const int cb = (r16 + 4 * (i & 3)) * 2;
+        const unsigned a0 = (unsigned)(size_t)(lds_u8*)(stage + byte_of(krow, cb >> 4) + (cb & 15));
+        const unsigned a1 = (unsigned)(size_t)(lds_u8*)(stage + byte_of(krow + 16, cb >> 4) + (cb & 15));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+    }
     // fragment for the 16 tile rows starting at `r16`, chunk `c` (contraction offset c*CH)
     __device__ static __forceinline__ typename Mma<T>::frag frag(const unsigned char* stage, int r16, int c, int lane) {
         const int g = lane >> 4, i = lane & 15;
@@ -286,10 +302,35 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             typename Mma<T>::frag fa[MI], fb[NI];
+            if constexpr (sizeof(T) == 2 && (TA || TB)) {
+                // bf16 with a T-major operand: its transpose reads go out as inline asm (Tile::frag_tr), all of the chunk first, then
+                // ONE wait that names every destination, then the fragments are put together and multiplied
+                u32x2_t al[MI], ah[MI], bl[NI], bh[NI];
 #pragma unroll
-            for (int a = 0; a < MI; ++a) fa[a] = TileA::frag(cA, wm0 + 16 * a, c, lane);
+                for (int a = 0; a < MI; ++a) {
+                    if constexpr (TA) TileA::frag_tr(cA, wm0 + 16 * a, c, lane, al[a], ah[a]);
+                    else fa[a] = TileA::frag(cA, wm0 + 16 * a, c, lane);
+                }
 #pragma unroll
-            for (int b = 0; b < NI; ++b) fb[b] = TileB::frag(cB, wn0 + 16 * b, c, lane);
+                for (int b = 0; b < NI; ++b) {
+                    if constexpr (TB) TileB::frag_tr(cB, wn0 + 16 * b, c, lane, bl[b], bh[b]);
+                    else fb[b] = TileB::frag(cB, wn0 + 16 * b, c, lane);
+                }
+#pragma unroll
+                for (int a = 0; a < MI; ++a) { if constexpr (TA) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(al[a]), "+v"(ah[a])); }
+#pragma unroll
+                for (int b = 0; b < NI; ++b) { if constexpr (TB) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bl[b]), "+v"(bh[b])); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < MI; ++a) { if constexpr (TA) fa[a] = __builtin_bit_cast(typename Mma<T>::frag, u32x4_t{al[a][0], al[a][1], ah[a][0], ah[a][1]}); }
+#pragma unroll
+                for (int b = 0; b < NI; ++b) { if constexpr (TB) fb[b] = __builtin_bit_cast(typename Mma<T>::frag, u32x4_t{bl[b][0], bl[b][1], bh[b][0], bh[b][1]}); }
+            } else {
+#pragma unroll
+                for (int a = 0; a < MI; ++a) fa[a] = TileA::frag(cA, wm0 + 16 * a, c, lane);
+#pragma unroll
+                for (int b = 0; b < NI; ++b) fb[b] = TileB::frag(cB, wn0 + 16 * b, c, lane);
+            }
 #pragma unroll
             for (int a = 0; a < MI; ++a)
 #pragma unroll

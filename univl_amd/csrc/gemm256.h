@@ -41,7 +41,6 @@
 #pragma once
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 constexpr int G256_HALF = 16384;                 // one operand half-tile image
 constexpr int G256_STAGE = 4 * G256_HALF;        // A0 A1 B0 B1
