@@ -613,6 +613,19 @@ def main():
                                                 "is a lower bound for the replayed step)")
                 except Exception as ex:      # noqa: BLE001
                     exchange["timing_error"] = "%s: %s" % (type(ex).__name__, ex)
+            if dist is not None and world > 1:
+                # first contact with N > 1: EVERY rank's view of the exchange in the one line rank 0 prints (a slow link or a rank
+                # that fell back shows up here, not in a log nobody collects)
+                mine = dict(rank=rank, backend=exchange["backend"], wire_dtype=exchange["wire_dtype"], captured=exchange["captured_in_step_graph"],
+                            exposed_ms=exchange.get("exposed_ms"), collective_ms=exchange.get("collective_ms"), algbw_gbs=exchange.get("algbw_gbs"),
+                            timing_error=exchange.get("timing_error"))
+                per_rank = [None] * world
+                dist.all_gather_object(per_rank, mine)
+                exchange["per_rank"] = per_rank
+                ex_ms = [r["exposed_ms"] for r in per_rank if r and r.get("exposed_ms") is not None]
+                if ex_ms:
+                    exchange["exposed_ms_max_over_ranks"] = max(ex_ms)
+                    exchange["exposed_fraction_of_step"] = round(max(ex_ms) / ms_per_step, 4)
     if rank == 0:
         names = dict(joint=("video-text pairs/sec (retrieval finetune, 48x48)", "YouCookII-shape retrieval finetune (FT-Joint) training step: BERT-base text "
                             "encoder (12 L) + 6-layer visual encoder"),

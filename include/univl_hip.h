@@ -89,6 +89,9 @@ int univl_allreduce_bucket(void* buf, size_t n, int dtype, int average, void* co
 #define UNIVL_GEMM_XCD_MAP 64      /* internal: XCD-aware workgroup -> tile map (always on since round 4) */
 #define UNIVL_GEMM_PROBE_NOSTORE 128 /* internal, only in the -DUNIVL_TRACE measurement build (UNIVL_GEMM_PROBE=1 there): the epilogue computes but does not store; the product library never sets or tests it */
 #define UNIVL_GEMM_PROBE_NT_B 256   /* internal, only in the -DUNIVL_TRACE measurement build (UNIVL_GEMM_NT_B=1 there): non-temporal LDS-DMA of the B operand */
+#define UNIVL_GEMM_AUX_F32 512     /* aux holds the GELU pre-activation in fp32 (ldaux in floats) instead of the compute type: removes the one
+                                    * non-operand rounding between FFN1 and its GELU' (A/B measurement of DESIGN.md section 2; costs 2 x the
+                                    * bytes of that buffer both ways) */
 #define UNIVL_GEMM_NT_OUT 32       /* fp32 output written with non-temporal stores: a weight gradient is read next by the optimizer, a whole backward later */
 typedef struct UnivlGemm {
     int32_t dtype, trans_a, trans_b;

@@ -155,3 +155,53 @@ def test_sharded_exchange_gloo_world2_and_world4():
         for p in procs:
             p.join(timeout=60)
         assert res == [(r, True) for r in range(world)], (world, res)
+
+
+def _worker_capture_fallback(rank, world, port, q):
+    """enable_capture() with a communicator whose construction fails on ONE rank (mocked univl_amd.rccl): both ranks must raise, together,
+    and the process-group exchange must keep working on both -- a rank that fell back alone would leave the other one hanging in the
+    first collective of the path it left (parallel.BucketReducer._agree)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import univl_amd.rccl as R
+
+    class FailingOnRank1:
+        def __init__(self, pg):
+            if dist.get_rank() == 1:
+                raise OSError("ncclCommInitRank returned 2 (mock)")
+            self.destroyed = False
+
+        def destroy(self):
+            self.destroyed = True
+
+    R._rccl = lambda: None
+    R.RcclComm = FailingOnRank1
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    red = BucketReducer(g)
+    red._avg = True                       # what an "nccl" group sets: enable_capture() only runs for RCCL groups
+    msg = None
+    try:
+        red.enable_capture()
+    except RuntimeError as ex:
+        msg = str(ex)
+    red._avg = False
+    ok = msg is not None and "at least one rank" in msg and red.rccl is None and not red.capturable and red._cstream is None
+    red.reduce_ranges([(0, 1000)])        # the host-issued exchange through the process group, on both ranks
+    red.join()
+    ok = ok and torch.allclose(g, torch.arange(1000, dtype=torch.float32) * (sum(range(1, world + 1)) / world))
+    q.put((rank, bool(ok), msg))
+    dist.destroy_process_group()
+
+
+def test_capture_failure_on_one_rank_falls_back_on_every_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_capture_fallback, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[:2] for r in res] == [(0, True), (1, True)], res

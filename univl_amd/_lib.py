@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UNIVL_LIB") or os.path.join(_HERE, "lib", "libunivl_hip.so")   # UNIVL_LIB: A/B builds
 
 DT_F32, DT_BF16 = 0, 1
-GEMM_ACCUM, GEMM_GELU_FWD, GEMM_GELU_BWD, GEMM_DBIAS_ATOMIC, GEMM_NT_OUT = 1, 2, 4, 16, 32
+GEMM_ACCUM, GEMM_GELU_FWD, GEMM_GELU_BWD, GEMM_DBIAS_ATOMIC, GEMM_NT_OUT, GEMM_AUX_F32 = 1, 2, 4, 16, 32, 512
 GEMM_GROUP_MAX = 4
 EUNSUPPORTED = -3          # csrc/common.h: the entry point does not carry this case (callers fall back)
 

@@ -260,7 +260,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     constexpr int PM = PRE ? MI : 1;
     float bv[NI];
     float rpre[PM][NI][4];
-    T upre[PM][NI][4];
+    float upre[PM][NI][4];
     {
         int pcol[NI];
 #pragma unroll
@@ -274,6 +274,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 for (int b = 0; b < NI; ++b) bv[b] = 0.0f;
             }
             const T* auxp = reinterpret_cast<const T*>(p.aux);
+            const float* auxf = reinterpret_cast<const float*>(p.aux);
+            const bool aux32 = (p.flags & UNIVL_GEMM_AUX_F32) != 0;
             if (p.R && first_slice) {
 #pragma unroll
                 for (int a = 0; a < MI; ++a)
@@ -290,7 +292,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                     for (int b = 0; b < NI; ++b)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            upre[a][b][r] = auxp[(long)min(m0 + wm0 + 16 * a + 4 * g + r, p.M - 1) * p.ldaux + pcol[b]];
+                        {
+                            const long o = (long)min(m0 + wm0 + 16 * a + 4 * g + r, p.M - 1) * p.ldaux + pcol[b];
+                            upre[a][b][r] = aux32 ? auxf[o] : to_f32<T>(auxp[o]);
+                        }
             }
         }
     }
@@ -403,6 +408,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     const bool nt_out = (p.flags & UNIVL_GEMM_NT_OUT) != 0;
     T* C16 = reinterpret_cast<T*>(p.C16);
     T* aux = reinterpret_cast<T*>(p.aux);
+    float* auxf32 = reinterpret_cast<float*>(p.aux);
+    const bool aux_f32 = (p.flags & UNIVL_GEMM_AUX_F32) != 0;
     long orow[MI][4];
     int ocol[NI];
     bool vrow[MI][4], vcol[NI];
@@ -456,23 +463,26 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
             for (int b = 0; b < NI; ++b)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (vrow[a][r] && vcol[b]) aux[orow[a][r] * p.ldaux + ocol[b]] = from_f32<T>(ev[b][r]);
+                    if (vrow[a][r] && vcol[b]) {
+                        if (aux_f32) auxf32[orow[a][r] * p.ldaux + ocol[b]] = ev[b][r];
+                        else aux[orow[a][r] * p.ldaux + ocol[b]] = from_f32<T>(ev[b][r]);
+                    }
                     ev[b][r] = gelu_f(ev[b][r]);
                 }
         }
         if (p.flags & UNIVL_GEMM_GELU_BWD) {
-            T uv[NI][4];
+            float uv[NI][4];
 #pragma unroll
             for (int b = 0; b < NI; ++b)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if constexpr (PRE) uv[b][r] = upre[a][b][r];
-                    else uv[b][r] = aux[orow[a][r] * p.ldaux + ocol[b]];
+                    else uv[b][r] = aux_f32 ? auxf32[orow[a][r] * p.ldaux + ocol[b]] : to_f32<T>(aux[orow[a][r] * p.ldaux + ocol[b]]);
                 }
 #pragma unroll
             for (int b = 0; b < NI; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ev[b][r] *= gelu_grad_f(to_f32<T>(uv[b][r]));
+                for (int r = 0; r < 4; ++r) ev[b][r] *= gelu_grad_f(uv[b][r]);
         }
         if ((p.flags & UNIVL_GEMM_ACCUM) && !atomic) {
             float cv[NI][4];
@@ -1023,6 +1033,7 @@ constexpr long GEMM_NC64_MIN = 1024;    // grouped weight gradients contracting 
 static bool fits256(const UnivlGemm* d, bool in_group) {
     if (d->dtype != UNIVL_BF16 || (d->trans_a && !d->trans_b) || d->M % 256 != 0 || d->N % 256 != 0) return false;
     if (d->dbias && !in_group) return false;
+    if (d->flags & UNIVL_GEMM_AUX_F32) return false;          // (A/B measurement form of the GELU epilogues: the older tiles only)
     if (d->sumsq && d->sumsq_rows % 256 != 0) return false;
     // the epilogue moves 4 consecutive columns per lane: 16-byte fp32 / 8-byte bf16 accesses
     if (d->ldc % 4 != 0 || (d->R && d->ldr % 4 != 0) || (d->aux && d->ldaux % 4 != 0) || !aligned16(d->C32) || !aligned16(d->R) ||

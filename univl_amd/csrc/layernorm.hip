@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(UnivlLayerNorm p) {
 // block combines its 4 waves through LDS and issues one fp32 atomic per column per block.
 constexpr int LN_RPW = 4;
 
-template <int N>
+template <int N, int NW = 4>
 __device__ __forceinline__ void block_colsum(float (*red)[N], const float (&part)[N / 256][4], float* dst, int lane, int wave) {
     if (dst == nullptr) return;
     __syncthreads();
@@ -31,8 +31,10 @@ __device__ __forceinline__ void block_colsum(float (*red)[N], const float (&part
 #pragma unroll
         for (int e = 0; e < 4; ++e) red[wave][4 * lane + 256 * j + e] = part[j][e];
     __syncthreads();
-    for (int c = threadIdx.x; c < N; c += 256) {
-        const float s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    for (int c = threadIdx.x; c < N; c += 64 * NW) {
+        float s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+#pragma unroll
+        for (int w = 4; w < NW; w += 4) s += (red[w][c] + red[w + 1][c]) + (red[w + 2][c] + red[w + 3][c]);
         unsafeAtomicAdd(dst + c, s);
     }
 }
@@ -52,10 +54,15 @@ __device__ __forceinline__ void block_colsum_store(float (*red)[N], const float 
 // DET: dgamma / dbeta / dbias partials per block in det_part[3][gridDim.x][N], the last block to arrive adds them in block order;
 // position-row gradients are not scattered here: the fp32 dx rows (p.dx32, which the host points at scratch when the caller gave
 // none) are summed per position by ln_dpos_gather_kernel afterwards.
-template <int N, typename TO, bool DET = false>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(UnivlLayerNorm p, int rpw, float* det_part = nullptr, int* det_counter = nullptr) {
+// NW = 8 (512 threads; round 5, thousands of rows): every workgroup ends in 3 x N fp32 atomics onto the same 3 N addresses, and an
+// address takes one update at a time -- at 6144 rows and 384 four-wave workgroups the column sums were 9 of the kernel's 24 us
+// (profiles/r05l_mb_ln_parts.txt: 15.1 us without them) while only 6 waves per compute unit kept one row each in flight.  (Sixteen
+// waves would halve the updates again, but cap the kernel at 128 VGPRs: 23 spilled.)
+template <int N, typename TO, bool DET = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void ln_bwd_kernel(UnivlLayerNorm p, int rpw, float* det_part = nullptr, int* det_counter = nullptr) {
     constexpr int NV = N / 256;
-    __shared__ float red[4][N];
+    static_assert(!DET || NW == 4, "the deterministic form keeps its 4-wave summation order");
+    __shared__ float red[NW][N];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t* sp = p.seed_dev ? p.seed_dev : reinterpret_cast<const uint64_t*>(p.gamma);
     const uint64_t sdv = *sp;
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(UnivlLayerNorm p, int rpw, 
         ga[j][0] = t.x; ga[j][1] = t.y; ga[j][2] = t.z; ga[j][3] = t.w;
     }
     for (int rr = 0; rr < rpw; ++rr) {
-        const int row = (blockIdx.x * 4 + wave) * rpw + rr;
+        const int row = (blockIdx.x * NW + wave) * rpw + rr;
         if (row >= p.rows) break;
         const float mean = p.stats[2 * (long)row], rstd = p.stats[2 * (long)row + 1];
         float dy[NV][4], xh[NV][4];
@@ -150,9 +157,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(UnivlLayerNorm p, int rpw, 
         }
     } else {
     // block reduction of the three column sums, one LDS pass each (pointers are block-uniform)
-    block_colsum<N>(red, dg, p.dgamma, lane, wave);
-    block_colsum<N>(red, db, p.dbeta, lane, wave);
-    block_colsum<N>(red, dbi, p.dbias, lane, wave);
+    block_colsum<N, NW>(red, dg, p.dgamma, lane, wave);
+    block_colsum<N, NW>(red, db, p.dbeta, lane, wave);
+    block_colsum<N, NW>(red, dbi, p.dbias, lane, wave);
     }
 }
 
@@ -248,6 +255,22 @@ extern "C" int univl_layernorm_bwd(const UnivlLayerNorm* d, hipStream_t stream) 
         if (q.dpos)
             hipLaunchKernelGGL(ln_dpos_gather_kernel, dim3((unsigned)(((long)q.pos_period * d->N + 255) / 256)), block, 0, stream,
                                q.dx32, d->rows, q.pos_period, d->N, q.dpos);
+        UNIVL_LAUNCH_CHECK();
+        return UNIVL_OK;
+    }
+    // 8 waves x 3 rows from 3072 rows on: 20.5 vs 23.7 us at 6144 rows, 14.4 vs 16.7 at 3072 (profiles/r05m_mb_ln_nw.txt)
+    int nw = (d->rows >= 3072 && d->N == 768 && !d->dpos) ? 8 : 4;
+#ifdef UNIVL_TRACE
+    if (const char* e = getenv("UNIVL_LN_NW")) { if (atoi(e) == 4 || atoi(e) == 8) nw = atoi(e); }      // measurement build only
+#endif
+    if (nw == 8 && d->N == 768) {
+        int rp = 3;
+#ifdef UNIVL_TRACE
+        if (const char* e = getenv("UNIVL_LN_RPW")) { if (atoi(e) > 0) rp = atoi(e); }
+#endif
+        dim3 g16((d->rows + 8 * rp - 1) / (8 * rp)), b16(512);
+        if (bf) hipLaunchKernelGGL((ln_bwd_kernel<768, __bf16, false, 8>), g16, b16, 0, stream, *d, rp);
+        else hipLaunchKernelGGL((ln_bwd_kernel<768, float, false, 8>), g16, b16, 0, stream, *d, rp);
         UNIVL_LAUNCH_CHECK();
         return UNIVL_OK;
     }

@@ -612,7 +612,7 @@ class Plan:
 
 def _gemm_desc(dt, A, lda, B, ldb, M, N, K, *, trans_a=0, trans_b=0, out32=None, out16=None, ldc=0, bias=None,
                residual=None, ldr=0, aux=None, ldaux=0, gelu=None, accumulate=False, dbias=None, ksplit=1, tile=0,
-               sumsq=None, sumsq_rows=0, sumsq_stride=0, nt_out=False, stages=0, waves=0):
+               sumsq=None, sumsq_rows=0, sumsq_stride=0, nt_out=False, stages=0, waves=0, aux_f32=False):
     d = _lib.Gemm()
     d.dtype, d.trans_a, d.trans_b, d.M, d.N, d.K = dt, trans_a, trans_b, M, N, K
     d.A, d.lda, d.B, d.ldb = A.data_ptr(), lda, B.data_ptr(), ldb
@@ -633,6 +633,8 @@ def _gemm_desc(dt, A, lda, B, ldb, M, N, K, *, trans_a=0, trans_b=0, out32=None,
         flags |= _lib.GEMM_GELU_FWD
     elif gelu == "bwd":
         flags |= _lib.GEMM_GELU_BWD
+    if aux_f32:
+        flags |= _lib.GEMM_AUX_F32
     d.flags, d.ksplit, d.tile = flags, ksplit, tile
     d.sumsq, d.sumsq_rows, d.sumsq_stride = (sumsq.data_ptr() if sumsq is not None else None), sumsq_rows, sumsq_stride
     d.stages, d.waves = stages, waves
@@ -712,6 +714,8 @@ class EncoderStack:
         f32 = torch.float32
         e = _workspace(dev)
         self.layers = []
+        # A/B measurement (gelu_pre_f32=1): the saved FFN1 pre-activation in fp32 instead of bf16
+        self.u_f32 = self.bf and bool(_ab.get("gelu_pre_f32"))
         # fp32 GEMM outputs that may be produced by split-K atomics live in two arenas zeroed ONCE per pass
         self.yarena = e(n_layers, 2, T, H)
         self.garena = e(n_layers, 2, T, H)
@@ -723,7 +727,7 @@ class EncoderStack:
         self.ln_ctr_b = torch.zeros(n_layers, 2, 2 * ((T + 63) // 64), dtype=torch.int32, device=dev) if self.ln_fold_bwd else None
         for l in range(n_layers):
             ws = dict(qkv=e(T, 3 * H, dtype=ct), lse=e(B, self.NH, S), ctx=e(T, H, dtype=ct),
-                      y1=self.yarena[l, 0], st1=e(T, 2), a32=e(T, H), u=e(T, I, dtype=ct), f=e(T, I, dtype=ct),
+                      y1=self.yarena[l, 0], st1=e(T, 2), a32=e(T, H), u=e(T, I, dtype=f32 if self.u_f32 else ct), f=e(T, I, dtype=ct),
                       y2=self.yarena[l, 1], st2=e(T, 2), o32=e(T, H))
             ws["a16"] = e(T, H, dtype=ct) if self.bf else ws["a32"]
             ws["o16"] = e(T, H, dtype=ct) if self.bf else ws["o32"]
@@ -847,7 +851,7 @@ class EncoderStack:
                         stats=ws["st1"], out32=ws["a32"], out16=ws["a16"] if self.bf else None, p_pre=p, off_pre=ws["off"][1],
                         seed_dev=self.seed_dev), 0)
             gemm(_gemm_desc(dt, ws["a16"], H, fl.wop(nm["w1"]), H, T, I, H, out16=ws["f"], ldc=I,
-                            bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd"))
+                            bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd", aux_f32=self.u_f32))
             gemm_ln(_gemm_desc(dt, ws["f"], I, fl.wop(nm["w2"]), I, T, H, I, out32=ws["y2"], ldc=H,
                                bias=fl.w32(nm["b2"]), ksplit=self.ksplit_for(I)),
                     ops.layernorm_desc(
@@ -938,7 +942,7 @@ class EncoderStack:
             w_ffn2 = _gemm_desc(dt, s_dxd, H, ws["f"], I, H, I, T, trans_a=1, trans_b=1,
                                 out32=fl.g(nm["w2"]), ldc=I, accumulate=gs.acc(nm["w2"]), **wg_tile, **gs.sumsq_args(nm["w2"], H, I))
             emit(_gemm_desc(dt, s_dxd, H, fl.wop(nm["w2"]), I, T, I, H, trans_b=1, out16=s_du,
-                            ldc=I, aux=ws["u"], ldaux=I, gelu="bwd"), w_ffn2)
+                            ldc=I, aux=ws["u"], ldaux=I, gelu="bwd", aux_f32=self.u_f32), w_ffn2)
             # Bias gradients of the two projections whose upstream gradient no LayerNorm kernel sees (FFN1, QKV): the descriptors carry
             # `dbias`; the pair launch and the big-tile grouped launch take them as column-sum workgroups of their own (gemm.hip
             # colsum_tile, round 4), the 64-tile grouped launch from the operand tiles it stages anyway.

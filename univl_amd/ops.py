@@ -48,7 +48,7 @@ def probe_layouts():
 
 def gemm_desc(A, B, M, N, K, *, trans_a=False, trans_b=False, out32=None, out16=None, bias=None, residual=None, aux=None,
               gelu=None, accumulate=False, dbias=None, dbias_atomic=False, ksplit=1, tile=0, alpha=1.0, sumsq=None,
-              sumsq_rows=0, sumsq_stride=0, stages=0, waves=0):
+              sumsq_rows=0, sumsq_stride=0, stages=0, waves=0, aux_f32=False):
     _require_gpu(A, B, out32, out16)
     d = _lib.Gemm()
     d.dtype = dtype_code(A.dtype)
@@ -74,6 +74,8 @@ def gemm_desc(A, B, M, N, K, *, trans_a=False, trans_b=False, out32=None, out16=
         flags |= _lib.GEMM_GELU_BWD
     if dbias_atomic:
         flags |= _lib.GEMM_DBIAS_ATOMIC
+    if aux_f32:
+        flags |= _lib.GEMM_AUX_F32
     d.flags, d.ksplit, d.tile = flags, ksplit, tile
     d.sumsq, d.sumsq_rows, d.sumsq_stride = _p(sumsq), sumsq_rows, sumsq_stride
     d.stages, d.waves = int(stages), int(waves)

@@ -66,7 +66,7 @@ class BucketReducer:
     def _agree(self, ok):
         """MIN over the ranks of a local 0 / 1 outcome, through the torch process group (never through the communicator under test)."""
         if self.world > 1:
-            flag = torch.tensor([1 if ok else 0], device="cuda", dtype=torch.int32)
+            flag = torch.tensor([1 if ok else 0], device=self.g.device, dtype=torch.int32)      # (the group's device: cuda for RCCL)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
             ok = int(flag)
         return bool(ok)
@@ -87,8 +87,19 @@ class BucketReducer:
         if not self._agree(err is None):
             raise RuntimeError("librccl is not loadable on at least one rank (%s)" % (err,))
         # RcclComm: rank 0's unique id (or None, if ncclGetUniqueId failed there) is broadcast to everybody -- a consistent outcome --
-        # and ncclCommInitRank is RCCL's own collective
-        self.rccl = _r.RcclComm(self.pg)
+        # and ncclCommInitRank is RCCL's own collective; an exception that only ONE rank sees (ncclCommInitRank's return code, a missing
+        # symbol) still goes through the agreement: every rank falls back together
+        err = None
+        try:
+            self.rccl = _r.RcclComm(self.pg)
+        except Exception as ex:      # noqa: BLE001
+            import sys
+            print("[univl_amd] rank %d: RCCL communicator construction failed (%s: %s)" % (self.rank, type(ex).__name__, ex), file=sys.stderr)
+            err = ex
+        if not self._agree(err is None):
+            if self.rccl is not None:
+                self.disable_capture()
+            raise RuntimeError("RCCL communicator construction failed on at least one rank")
         self._cstream = torch.cuda.Stream()
         err = None
         try:
@@ -108,7 +119,8 @@ class BucketReducer:
         self.capturable = False
         if self.rccl is not None:
             try:
-                torch.cuda.synchronize()
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
                 self.rccl.destroy()
             finally:
                 self.rccl, self._cstream, self._inflight = None, None, False
