@@ -218,6 +218,15 @@ typedef struct UnivlAttention {
 int univl_attention_fwd(const UnivlAttention* d, hipStream_t stream);
 int univl_attention_bwd(const UnivlAttention* d, hipStream_t stream);
 
+/* univl_attention_bwd with the dgrad of the attention-output projection (dctx = dY . W_o: the dense of BertSelfOutput, module_bert.py:207,
+ * differentiated) computed INSIDE the launch: every workgroup first multiplies the 64 x 64 block of dctx that belongs to its own (batch
+ * row, head) -- sequences of at most 64 positions, head width 64 -- and runs the attention backward on it from LDS; dctx never goes
+ * through global memory (at->dout is not written) and one launch leaves the backward chain.  dq / dk / dv are bit-identical to
+ * univl_gemm(odgrad) + univl_attention_bwd(at).  owgrad (optional): the weight gradient of the same projection (dY^T . ctx), riding
+ * as extra workgroups like in univl_gemm_pair.  bf16 only; UNIVL_EUNSUPPORTED where the launch does not carry the pair; dry_run != 0
+ * validates without launching. */
+int univl_attention_bwd_fused(const UnivlAttention* at, const UnivlGemm* odgrad, const UnivlGemm* owgrad, int32_t dry_run, hipStream_t stream);
+
 /* ------------------------------------------------------------------------------------- text embeddings
  * BertEmbeddings / DecoderEmbeddings (module_bert.py:132-146, module_decoder.py:309-320):
  * gather word + position (+ token type) -> LayerNorm -> dropout.  Backward scatter-adds into the tables. */

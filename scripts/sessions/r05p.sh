@@ -1,0 +1,13 @@
+#!/bin/bash
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q --no-header -rfE -p no:cacheprovider -x -k "attention" > gpurun_out/r05p_pytest.log 2>&1
+echo "pytest exit $?"; tail -n 25 gpurun_out/r05p_pytest.log | cut -c1-250
+for ab in "" "attn_fuse_bwd=0"; do
+  for b in 4 16 128; do
+    UNIVL_AB=$ab timeout 300 python bench.py --child --batch $b --steps 20 --warmup 5 2>/dev/null | python -c "
+import json,sys
+j=json.loads(sys.stdin.readline()); print('[$ab] batch $b ms/step', j['ms_per_step'], j.get('preheat',{}).get('block_ms'), 'loss', j['config']['last_loss'])"
+  done
+done 2>&1 | tee gpurun_out/r05p_steps.txt

@@ -203,6 +203,13 @@ def test_riding_weight_gradients_only_repackage_the_backward_plan(kw, kind, fres
                 pairs.append((dg, wg))
                 if kind_ == "pair_ln":           # the LayerNorm backward fed by this dgrad, finished inside the launch (round 4)
                     chain.append(("univl_layernorm_bwd",))
+            elif kind_ == "attn_fused":          # round 5: the attention-output dgrad inside the attention backward, its weight gradient riding
+                ds = plan.descs[i]
+                chain.append(("gemm",) + rec(ds[0]))
+                chain.append(("univl_attention_bwd",))
+                if len(ds) > 1:
+                    wgrads.append(("gemm",) + rec(ds[1]))
+                    pairs.append((ds[0], ds[1]))
             elif kind_ in ("call", "py", "eager"):
                 chain.append((name,))
         return chain, sorted(wgrads, key=repr), pairs

@@ -820,6 +820,68 @@ def test_attention_fwd_bwd(dtype, B, Sq, Sk, causal):
     assert rel_err(dkv.float()[:, H * D:].reshape(B, Sk, -1), v.grad) < t
 
 
+@pytest.mark.parametrize("B,S,p_drop,masked", [(4, 48, 0.1, False), (4, 48, 0.0, True), (3, 20, 0.1, True), (2, 64, 0.0, False), (5, 33, 0.1, True)])
+def test_attention_bwd_with_the_output_dgrad_inside_equals_the_two_launches(B, S, p_drop, masked):
+    """univl_attention_bwd_fused (round 5): every workgroup of the attention backward first multiplies the 64 x 64 block of
+    dctx = dY . W_o that belongs to its (batch row, head) and works on it from LDS.  Same chunk order per output element, same bf16
+    rounding of dctx as the dgrad's epilogue: dq / dk / dv are BIT-IDENTICAL to univl_gemm + univl_attention_bwd, with ragged key
+    masks, a fully masked row, dropout regenerated from the seed, sequences that are not multiples of 16 -- and so is the weight
+    gradient that rides in the launch (with its gradient-norm partials) to the product alone."""
+    dtype, H, D = torch.bfloat16, 12, 64
+    dt = ops.dtype_code(dtype)
+    T, HD = B * S, H * D
+    qkv = gen(T, 3 * HD, seed=1).to(DEV, dtype)
+    g = torch.Generator().manual_seed(7)
+    lens = torch.randint(1, S + 1, (B,), generator=g)
+    lens[0] = S
+    mask = (torch.arange(S)[None] < lens[:, None]).long()
+    if B > 1:
+        mask[1] = 0
+    km = mask.to(DEV) if masked else None
+    ctx = torch.zeros(T, HD, device=DEV, dtype=dtype)
+    lse = torch.zeros(B, H, S, device=DEV)
+    seed = torch.full((1,), 1234, dtype=torch.int64, device=DEV)
+    args = (dt, B, H, S, S, (qkv, 0), 3 * HD, (qkv, HD), 3 * HD, (qkv, 2 * HD), 3 * HD, ctx, HD, lse)
+    kw = dict(key_mask=km, p_drop=p_drop, offset=5 << 40, seed_dev=seed)
+    ops.attention_fwd(*args, **kw)
+    dY = gen(T, HD, seed=2).to(DEV, dtype)                         # gradient wrt the attention-output projection's output
+    Wo = gen(HD, HD, seed=3, scale=0.05).to(DEV, dtype)            # nn.Linear(768, 768).weight [out, in]
+    # ---- the two launches
+    dctx = torch.zeros(T, HD, device=DEV, dtype=dtype)
+    ops.gemm(dY, Wo, T, HD, HD, trans_b=True, out16=dctx)
+    dqkv = torch.zeros(T, 3 * HD, device=DEV, dtype=dtype)
+    bw = dict(dout=dctx, lddo=HD, dq=(dqkv, 0), lddq=3 * HD, dk=(dqkv, HD), lddk=3 * HD, dv=(dqkv, 2 * HD), lddv=3 * HD)
+    ops.attention_bwd(*args, **kw, **bw)
+    assert float(dqkv.float().abs().max()) > 0
+    gW = torch.zeros(HD, HD, device=DEV)
+    stride = (HD // 64) * (HD // 64) * 4
+    part = torch.zeros(stride, device=DEV)
+    ops.gemm(dY, ctx, HD, HD, T, trans_a=True, trans_b=True, out32=gW, sumsq=part, sumsq_stride=stride)
+    # ---- one launch: dctx never exists in global memory (the buffer named as dout stays untouched)
+    dctx2 = torch.full((T, HD), 7.0, device=DEV, dtype=dtype)
+    dqkv2 = torch.zeros(T, 3 * HD, device=DEV, dtype=dtype)
+    bw2 = dict(dout=dctx2, lddo=HD, dq=(dqkv2, 0), lddq=3 * HD, dk=(dqkv2, HD), lddk=3 * HD, dv=(dqkv2, 2 * HD), lddv=3 * HD)
+    at = ops.attention_desc(*args, **kw, **bw2)
+    od = ops.gemm_desc(dY, Wo, T, HD, HD, trans_b=True, out16=dctx2)
+    gW2 = torch.zeros(HD, HD, device=DEV)
+    part2 = torch.zeros(stride, device=DEV)
+    ow = ops.gemm_desc(dY, ctx, HD, HD, T, trans_a=True, trans_b=True, out32=gW2, sumsq=part2, sumsq_stride=stride)
+    assert ops.attention_bwd_fused(at, od, ow)
+    assert torch.equal(dqkv2, dqkv), float((dqkv2.float() - dqkv.float()).abs().max())
+    assert torch.equal(gW2, gW)
+    assert rel_err(part2.sum().reshape(1), (gW.double() ** 2).sum().cpu().reshape(1)) < 1e-5
+    assert float((dctx2.float() - 7.0).abs().max()) == 0.0
+    # ... and without a riding weight gradient; repeated launches reproduce the bits (the product's stages and the attention images
+    # share LDS: a missing barrier between them shows up as run-to-run differences)
+    for _ in range(5):
+        dqkv2.zero_()
+        assert ops.attention_bwd_fused(at, od, None)
+        assert torch.equal(dqkv2, dqkv)
+    # sequences beyond 64 positions, fp32, a split product: not carried
+    at_long = ops.attention_desc(dt, 1, H, 80, 80, (qkv, 0), 3 * HD, (qkv, HD), 3 * HD, (qkv, 2 * HD), 3 * HD, ctx, HD, lse, **bw2)
+    assert not ops.attention_bwd_fused(at_long, ops.gemm_desc(dY, Wo, 80, HD, HD, trans_b=True, out16=dctx2), None, dry_run=True)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_maximum_sequence_and_limit(dtype):
     """Largest sequence the single-pass kernels hold in LDS (384 bf16 / 256 fp32) and the loud failure one past it."""

@@ -216,6 +216,49 @@ template <typename T, bool TR, int ROWS, int BK, int NT = 256> struct Tile {
     }
 };
 
+// The multiply of one staged K step: NC chunks, MI x NI accumulator tiles of this wave (sub-tile origin wm0, wn0).
+template <typename T, bool TA, bool TB, int MI, int NI, int NC, typename TileA, typename TileB>
+__device__ __forceinline__ void tile_mma(const unsigned char* cA, const unsigned char* cB, const int wm0, const int wn0, const int lane,
+                                         f32x4_t (&acc)[MI][NI]) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        typename Mma<T>::frag fa[MI], fb[NI];
+        if constexpr (sizeof(T) == 2 && (TA || TB)) {
+            // bf16 with a T-major operand: its transpose reads go out as inline asm (Tile::frag_tr), all of the chunk first, then
+            // ONE wait that names every destination, then the fragments are put together and multiplied
+            u32x2_t al[MI], ah[MI], bl[NI], bh[NI];
+#pragma unroll
+            for (int a = 0; a < MI; ++a) {
+                if constexpr (TA) TileA::frag_tr(cA, wm0 + 16 * a, c, lane, al[a], ah[a]);
+                else fa[a] = TileA::frag(cA, wm0 + 16 * a, c, lane);
+            }
+#pragma unroll
+            for (int b = 0; b < NI; ++b) {
+                if constexpr (TB) TileB::frag_tr(cB, wn0 + 16 * b, c, lane, bl[b], bh[b]);
+                else fb[b] = TileB::frag(cB, wn0 + 16 * b, c, lane);
+            }
+#pragma unroll
+            for (int a = 0; a < MI; ++a) { if constexpr (TA) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(al[a]), "+v"(ah[a])); }
+#pragma unroll
+            for (int b = 0; b < NI; ++b) { if constexpr (TB) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bl[b]), "+v"(bh[b])); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < MI; ++a) { if constexpr (TA) fa[a] = __builtin_bit_cast(typename Mma<T>::frag, u32x4_t{al[a][0], al[a][1], ah[a][0], ah[a][1]}); }
+#pragma unroll
+            for (int b = 0; b < NI; ++b) { if constexpr (TB) fb[b] = __builtin_bit_cast(typename Mma<T>::frag, u32x4_t{bl[b][0], bl[b][1], bh[b][0], bh[b][1]}); }
+        } else {
+#pragma unroll
+            for (int a = 0; a < MI; ++a) fa[a] = TileA::frag(cA, wm0 + 16 * a, c, lane);
+#pragma unroll
+            for (int b = 0; b < NI; ++b) fb[b] = TileB::frag(cB, wn0 + 16 * b, c, lane);
+        }
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NI; ++b) acc[a][b] = Mma<T>::mma(fa[a], fb[b], acc[a][b]);
+    }
+}
+
 // Two LDS stages: tile t+1 streams in while tile t is multiplied (one wait + barrier per K step).  WGM x WGN waves; every wave owns a
 // (BM / WGM) x (BN / WGN) sub-tile.  (Measured and removed in round 4, numbers in DESIGN.md section 8: a three-stage ring with counted
 // waits, a 256 x 128 tile on that ring, a "burst" form with the whole contraction slice in one DMA burst.)
@@ -304,43 +347,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     float dbias_acc = 0.0f;
 
     auto compute = [&](const unsigned char* cA, const unsigned char* cB) {
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            typename Mma<T>::frag fa[MI], fb[NI];
-            if constexpr (sizeof(T) == 2 && (TA || TB)) {
-                // bf16 with a T-major operand: its transpose reads go out as inline asm (Tile::frag_tr), all of the chunk first, then
-                // ONE wait that names every destination, then the fragments are put together and multiplied
-                u32x2_t al[MI], ah[MI], bl[NI], bh[NI];
-#pragma unroll
-                for (int a = 0; a < MI; ++a) {
-                    if constexpr (TA) TileA::frag_tr(cA, wm0 + 16 * a, c, lane, al[a], ah[a]);
-                    else fa[a] = TileA::frag(cA, wm0 + 16 * a, c, lane);
-                }
-#pragma unroll
-                for (int b = 0; b < NI; ++b) {
-                    if constexpr (TB) TileB::frag_tr(cB, wn0 + 16 * b, c, lane, bl[b], bh[b]);
-                    else fb[b] = TileB::frag(cB, wn0 + 16 * b, c, lane);
-                }
-#pragma unroll
-                for (int a = 0; a < MI; ++a) { if constexpr (TA) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(al[a]), "+v"(ah[a])); }
-#pragma unroll
-                for (int b = 0; b < NI; ++b) { if constexpr (TB) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bl[b]), "+v"(bh[b])); }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int a = 0; a < MI; ++a) { if constexpr (TA) fa[a] = __builtin_bit_cast(typename Mma<T>::frag, u32x4_t{al[a][0], al[a][1], ah[a][0], ah[a][1]}); }
-#pragma unroll
-                for (int b = 0; b < NI; ++b) { if constexpr (TB) fb[b] = __builtin_bit_cast(typename Mma<T>::frag, u32x4_t{bl[b][0], bl[b][1], bh[b][0], bh[b][1]}); }
-            } else {
-#pragma unroll
-                for (int a = 0; a < MI; ++a) fa[a] = TileA::frag(cA, wm0 + 16 * a, c, lane);
-#pragma unroll
-                for (int b = 0; b < NI; ++b) fb[b] = TileB::frag(cB, wn0 + 16 * b, c, lane);
-            }
-#pragma unroll
-            for (int a = 0; a < MI; ++a)
-#pragma unroll
-                for (int b = 0; b < NI; ++b) acc[a][b] = Mma<T>::mma(fa[a], fb[b], acc[a][b]);
-        }
+        tile_mma<T, TA, TB, MI, NI, NC, TileA, TileB>(cA, cB, wm0, wn0, lane, acc);
         if (want_dbias) {
             // bias gradient = sum over the contraction (tokens) of A_op rows; A is T-major: [BK][BM]
             if (tid < BM) {
@@ -902,6 +909,104 @@ int launch_pair(const PairArgs& a, hipStream_t stream, const LnFold* f = nullptr
     return UNIVL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the attention-output dgrad (dctx = dY . W_o, module_bert.py:207 differentiated) INSIDE the attention backward.  At a few
+// hundred tokens the backward of a layer was five dependent launches; two of them -- the pair launch of this dgrad (36 tiles, 13 us)
+// and the attention backward that consumes its output (9.5 us) -- exchange nothing but a [tokens, 768] bf16 matrix whose (batch row,
+// head) block is EXACTLY one 64 x 64 product tile (head width 64 = tile width; sequences of at most 64 positions).  So every workgroup of
+// the attention backward computes the dO block of its own (batch row, head) first -- the K loop of gemm_tile on the sequence's rows
+// and the head's columns of W_o, rounded to bf16 exactly as the dgrad's epilogue did -- writes it into the LDS images the attention
+// body reads (attn_body.h: FUSED), and carries on.  No cross-workgroup hand-off, one launch and one [tokens, 768] round trip through
+// HBM less per layer; dQ / dK / dV are BIT-IDENTICAL to the two launches (same chunk order per output element).  The weight gradient
+// that rode with the dgrad (dW_o = dY^T . ctx) rides here: its tiles take the workgroups behind the attention roles.
+// K loop of gemm_tile alone (no epilogue): acc <- A_op[m0.., K] . B_op[n0.., K]^T, K a multiple of the step depth.
+template <typename T, bool TA, bool TB, int BM, int BN, int NC, int WGM, int WGN>
+__device__ __forceinline__ void gemm_acc_only(const T* A, long lda, const T* B, long ldb, int M, int N, int K, int m0, int n0,
+                                              f32x4_t (&acc)[BM / WGM / 16][BN / WGN / 16], unsigned char* smem) {
+    constexpr int BK = NC * Mma<T>::CH, NT = 64 * WGM * WGN;
+    using TileA = Tile<T, TA, BM, BK, NT>;
+    using TileB = Tile<T, TB, BN, BK, NT>;
+    constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
+    unsigned char* sA = smem;
+    unsigned char* sB = sA + 2 * TileA::BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const T* pa[TileA::PER_THREAD];
+    const T* pb[TileB::PER_THREAD];
+    TileA::init(pa, A, lda, m0, 0, M, tid);
+    TileB::init(pb, B, ldb, n0, 0, N, tid);
+    const long stepA = TileA::kstep(lda), stepB = TileB::kstep(ldb);
+    const int nfull = K / BK;
+    TileA::issue(pa, sA, tid);
+    TileB::issue(pb, sB, tid);
+    TileA::advance(pa, stepA);
+    TileB::advance(pb, stepB);
+    __syncthreads();
+    for (int t = 0; t < nfull; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nfull) {
+            TileA::issue(pa, sA + (cur ^ 1) * TileA::BYTES, tid);
+            TileB::issue(pb, sB + (cur ^ 1) * TileB::BYTES, tid);
+            TileA::advance(pa, stepA);
+            TileB::advance(pb, stepB);
+        }
+        tile_mma<T, TA, TB, MI, NI, NC, TileA, TileB>(sA + cur * TileA::BYTES, sB + cur * TileB::BYTES, wm0, wn0, lane, acc);
+        __syncthreads();
+    }
+}
+
+#include "attn_body.h"
+
+struct AttnFusedArgs {
+    UnivlAttention at;
+    int Sk_pad, Sq_pad;
+    const __bf16* dY; long lddy;        // upstream gradient of the attention-output projection [tokens, K]
+    const __bf16* W; long ldw;          // its weight, [K][H * 64] as the dgrad reads it (T-major B)
+    int K;
+    int n_attn, n_attn_pad;             // attention-role workgroups (2 per (batch row, head)), padded to a multiple of 8
+    GemmArgs w;                         // the riding weight gradient (nw = 0: none)
+    int nw, wnx, wny, wnz;
+};
+
+template <int TRIPS, bool DUAL, int NCW>
+__global__ __launch_bounds__(256) void attn_bwd_odgrad_kernel(AttnFusedArgs a) {
+    const int w0 = blockIdx.x;
+    if (w0 < a.n_attn_pad) {
+        if (w0 >= a.n_attn) return;
+        const int bh = w0 >> 1, role = w0 & 1;              // one query block (role 0: dQ) and one key block (role 1: dK, dV)
+        const int b = bh / a.at.H, h = bh % a.at.H;
+        f32x4_t acc[2][2];
+        gemm_acc_only<__bf16, false, true, 64, 64, 4, 2, 2>(a.dY + (long)b * a.at.Sq * a.lddy, a.lddy, a.W, a.ldw, a.at.Sq, a.at.H * 64, a.K,
+                                                            0, h * 64, acc, smem_raw);
+        // (the K loop's last barrier is behind us: every wave is done with the stages, the attention images may overwrite them)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+        const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+        const int Sq = a.at.Sq, Sq_pad = a.Sq_pad;
+        auto dow = [&](void* img_, int pitch) {
+            __bf16* img = reinterpret_cast<__bf16*>(img_);
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = wm0 + 16 * ta + 4 * g + r, col = wn0 + 16 * tb + i;
+                        // the images hold Sq_pad rows (32 or 64); rows beyond the sequence are zero, as stage_pair fills them
+                        if (row < Sq_pad) img[row * pitch + col] = row < Sq ? (__bf16)acc[ta][tb][r] : (__bf16)0.0f;
+                    }
+        };
+        attn_bwd_body<__bf16, TRIPS, DUAL, true>(a.at, a.Sk_pad, a.Sq_pad, 1, 0.125f, bh, role, smem_raw, dow);
+    } else {
+        int bx, by, bz;
+        pair_tile(w0 - a.n_attn_pad, a.nw, a.wnx, a.wny, a.wnz, a.w.flags, a.w.gm, bx, by, bz);
+        gemm_tile<__bf16, true, true, 64, 64, NCW, 2, 2>(a.w, bx, by, bz, a.wnz);
+    }
+}
+
 // EXPERIMENTAL (UNIVL_ADAM_RIDE=1 with graphed.GraphedTrainStep(pipeline_optimizer=True)): a forward product and a range of BertAdam
 // chunks in ONE launch.  The fused update is one 0.8 ms HBM stream (30 B per parameter) at the end of a step whose forward is a chain
 // of latency-bound kernels on a third of the compute units; its only ordering constraints are "after the clip of its own backward"
@@ -1347,6 +1452,70 @@ extern "C" int univl_gemm_pair_ln(const UnivlGemm* dgrad, const UnivlGemm* wgrad
     UNIVL_ON_STREAM_DEVICE(stream);
     UNIVL_CHECK_ARG(ln != nullptr && counters != nullptr, UNIVL_EINVAL, "univl_gemm_pair_ln: null argument");
     return pair_impl(dgrad, wgrad, ln, counters, dry_run, stream);
+}
+
+// univl_attention_bwd with the attention-output dgrad that produces its upstream gradient computed inside the launch, and (optionally)
+// the weight gradient of the same projection riding in it (attn_bwd_odgrad_kernel above).  bf16, sequences of at most 64 positions,
+// odgrad: K-major dY [tokens, K] x T-major W [K, H * 64] -> bf16 at->dout (which is NOT written: nothing else reads it), K a multiple
+// of 128, no epilogue; owgrad: what univl_gemm_pair would take on the 64 tile (may be NULL).  UNIVL_EUNSUPPORTED otherwise: callers
+// enqueue univl_gemm_pair / univl_gemm + univl_attention_bwd.
+extern "C" int univl_attention_bwd_fused(const UnivlAttention* at, const UnivlGemm* odgrad, const UnivlGemm* owgrad, int32_t dry_run,
+                                         hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    UNIVL_CHECK_ARG(at != nullptr && odgrad != nullptr, UNIVL_EINVAL, "univl_attention_bwd_fused: null descriptor");
+    int rc = attn_check(at, "univl_attention_bwd_fused", true);
+    if (rc) return rc;
+    using C = AttnCfg<__bf16>;
+    const int Sk_pad = (at->Sk + 31) / 32 * 32, Sq_pad = (at->Sq + 31) / 32 * 32;
+    const UnivlGemm* g = odgrad;
+    UNIVL_CHECK_ARG(at->dtype == UNIVL_DT_BF16 && Sk_pad <= 64 && Sq_pad <= 64 && g->dtype == UNIVL_BF16 && !g->trans_a && g->trans_b &&
+                        g->M == at->B * at->Sq && g->N == at->H * 64 && g->K % 128 == 0 && g->K >= 128 && g->C16 == at->dout && !g->C32 &&
+                        g->ldc == at->lddo && !g->bias && !g->R && !g->dbias && !g->sumsq && g->alpha == 1.0f && g->ksplit <= 1 &&
+                        (g->flags & ~(UNIVL_GEMM_XCD_MAP)) == 0 && aligned16(g->A) && aligned16(g->B) && g->lda % 8 == 0 && g->ldb % 8 == 0,
+                    UNIVL_EUNSUPPORTED, "univl_attention_bwd_fused: not an (attention backward, attention-output dgrad) pair this launch carries");
+    AttnFusedArgs a;
+    a.at = *at;
+    a.Sk_pad = Sk_pad; a.Sq_pad = Sq_pad;
+    a.dY = reinterpret_cast<const __bf16*>(g->A); a.lddy = g->lda;
+    a.W = reinterpret_cast<const __bf16*>(g->B); a.ldw = g->ldb;
+    a.K = g->K;
+    a.n_attn = 2 * at->B * at->H;
+    a.n_attn_pad = (a.n_attn + 7) / 8 * 8;
+    a.nw = 0; a.wnx = a.wny = a.wnz = 1;
+    bool wone = false;
+    if (owgrad != nullptr) {
+        int ksw;
+        Choice cw;
+        rc = prepare(owgrad, a.w, ksw, cw);
+        if (rc != UNIVL_OK) return rc;
+        UNIVL_CHECK_ARG(owgrad->dtype == UNIVL_BF16 && owgrad->trans_a && owgrad->trans_b && cw.tile == 64 && (cw.nc == 4 || cw.nc == 6) &&
+                            !owgrad->dbias, UNIVL_EUNSUPPORTED, "univl_attention_bwd_fused: the riding weight gradient must be a bf16 (T-major, T-major) product on the 64 tile");
+        wone = cw.nc == 6;
+        a.wnx = (owgrad->N + 63) / 64; a.wny = (owgrad->M + 63) / 64; a.wnz = ksw;
+        a.nw = a.wnx * a.wny * a.wnz;
+    } else {
+        a.w = GemmArgs{};
+    }
+    if (dry_run) return UNIVL_OK;
+    constexpr bool DUAL = true;
+    // LDS: the product's two stages (64 KB), then -- in the same bytes -- the attention images + the dO tile of role 0
+    const size_t smemA = (size_t)Sk_pad * (C::PT + 2 * C::PK) * 2 + Sk_pad * 4 + 64 * C::PK * 2;
+    const size_t smemB = (size_t)Sq_pad * (2 * C::PT + 2 * C::PK) * 2 + (Sk_pad + 2 * Sq_pad) * 4;
+    size_t smem = 4 * (size_t)64 * 128 * 2;
+    smem = smem > smemA ? smem : smemA;
+    smem = smem > smemB ? smem : smemB;
+    constexpr int TR = (64 * 8 + 511) / 512;
+    static bool done4[UNIVL_MAX_DEVICES] = {}, done6[UNIVL_MAX_DEVICES] = {};
+    const dim3 grid(a.n_attn_pad + a.nw);
+    if (wone) {
+        univl_allow_lds(attn_bwd_odgrad_kernel<TR, DUAL, 6>, 160 * 1024, done6);
+        hipLaunchKernelGGL((attn_bwd_odgrad_kernel<TR, DUAL, 6>), grid, dim3(256), smem, stream, a);
+    } else {
+        univl_allow_lds(attn_bwd_odgrad_kernel<TR, DUAL, 4>, 160 * 1024, done4);
+        hipLaunchKernelGGL((attn_bwd_odgrad_kernel<TR, DUAL, 4>), grid, dim3(256), smem, stream, a);
+    }
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
 }
 
 static const size_t RIDER_SMEM = 4 * (size_t)Tile<__bf16, false, 64, 128, 512>::BYTES;          // two stages of A and B

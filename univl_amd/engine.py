@@ -355,6 +355,13 @@ class Plan:
         self.descs[len(self.ops)] = [dgrad, wgrad]
         self.ops.append(("pair", fn, arr, "univl_gemm_pair", stream))
 
+    def add_attn_bwd_fused(self, attn, odgrad, owgrad, stream=0):
+        """The attention backward with the attention-output dgrad that feeds it computed inside the launch, the weight gradient of
+        that projection riding as extra workgroups (univl_attention_bwd_fused; owgrad may be None)."""
+        self.keep += [attn, odgrad, owgrad]
+        self.descs[len(self.ops)] = [odgrad] + ([owgrad] if owgrad is not None else [])
+        self.ops.append(("attn_fused", _lib.lib().univl_attention_bwd_fused, (attn, odgrad, owgrad), "univl_attention_bwd_fused", stream))
+
     def add_gemm_pair_ln(self, dgrad, wgrad, ln_desc, counters, stream=0):
         """add_gemm_pair with the LayerNorm BACKWARD that consumes the dgrad's fp32 output finished inside the launch
         (univl_gemm_pair_ln); falls back to the two launches at run time where the library refuses (deterministic mode)."""
@@ -490,6 +497,13 @@ class Plan:
                 rc = a(C.byref(b[0]), C.byref(b[1]), 0, h)
                 if rc != 0:
                     _lib.check(rc, name)
+            elif kind == "attn_fused":
+                h = handles.get(sidx)
+                if h is None:
+                    h = handles[sidx] = C.c_void_p(self._stream(sidx, cur).cuda_stream)
+                rc = a(C.byref(b[0]), C.byref(b[1]), C.byref(b[2]) if b[2] is not None else None, 0, h)
+                if rc != 0:
+                    _lib.check(rc, name)
             elif kind == "record":
                 ev = torch.cuda.Event()
                 ev.record(self._stream(sidx, cur))
@@ -588,6 +602,12 @@ class Plan:
                 out.append((lambda h, d=arg[0]: _lib.lib().univl_gemm(C.byref(d), h), self.descs[i]))
             elif kind == "pair" and name.startswith(prefix):
                 out.append((lambda h, fn=fn, arg=arg: fn(C.byref(arg[0]), C.byref(arg[1]), 0, h), self.descs[i]))
+            elif kind == "attn_fused" and prefix == "univl_gemm":
+                # the dense contractions inside the fused launch, replayed the way they ran before it existed (the family's accounting)
+                if arg[2] is not None:
+                    out.append((lambda h, arg=arg: _lib.lib().univl_gemm_pair(C.byref(arg[1]), C.byref(arg[2]), 0, h), self.descs[i]))
+                else:
+                    out.append((lambda h, arg=arg: _lib.lib().univl_gemm(C.byref(arg[1]), h), self.descs[i]))
             elif kind == "pair_ln" and name.startswith(prefix):
                 if carried:
                     out.append((lambda h, fn=fn, arg=arg: fn(C.byref(arg[0][0]), C.byref(arg[0][1]), C.byref(arg[1]), C.c_void_p(arg[2].data_ptr()), 0, h),
@@ -678,7 +698,7 @@ class EncoderStack:
         # dgrad body walking a 2304 / 3072-deep contraction + 128 x 64 weight-gradient tiles) ran 112 us each, 36 of them per step = 4.0
         # of the 9.2 ms of the 64-pair step (profiles/r05f_bench_b64_kernel_stats.csv), against ~32 + ~40 us for the two dgrads alone
         # and 68 us for the layer's whole group.  g256=0 (univl_amd/_ab.py): the former plans.
-        self.g256 = flat.compute_dtype == torch.bfloat16 and bool(_ab.get("g256")) and (B * S) % 256 == 0 and B * S >= 1536
+        self.g256 = flat.compute_dtype == torch.bfloat16 and bool(_ab.get("g256")) and (B * S) % 256 == 0 and B * S >= _ab.get("g256_min_rows")
         self.ride = bool(_ab.get("wgrad_ride")) and flat.compute_dtype == torch.bfloat16 and not self.g256
         # The forward products of layer l can carry the BertAdam chunks of layer l + 1 (Plan.add_gemm_rider): switched on per model by
         # graphed.GraphedTrainStep(pipeline_optimizer=True) (flat.adam_ride), or for every model by UNIVL_ADAM_RIDE=1.
@@ -960,12 +980,25 @@ class EncoderStack:
                 ln_bwd(ln1)
             w_o = _gemm_desc(dt, s_dxd2, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
                              out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"]), **wg_tile, **gs.sumsq_args(nm["o_w"], H, H))
-            emit(_gemm_desc(dt, s_dxd2, H, fl.wop(nm["o_w"]), H, T, H, H, trans_b=1, out16=self.dctx, ldc=H), w_o)
+            o_dgrad = _gemm_desc(dt, s_dxd2, H, fl.wop(nm["o_w"]), H, T, H, H, trans_b=1, out16=self.dctx, ldc=H)
             qkv, dqkv = ws["qkv"], s_dqkv
-            plan.add("univl_attention_bwd", ops.attention_desc(
+            attn_b = ops.attention_desc(
                 dt, B, self.NH, S, S, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx"], H, ws["lse"],
                 key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev, dout=self.dctx, lddo=H,
-                dq=(dqkv, 0), lddq=3 * H, dk=(dqkv, H), lddk=3 * H, dv=(dqkv, 2 * H), lddv=3 * H), sm)
+                dq=(dqkv, 0), lddq=3 * H, dk=(dqkv, H), lddk=3 * H, dv=(dqkv, 2 * H), lddv=3 * H)
+            # Round 5: the attention-output dgrad computed INSIDE the attention backward (one launch and one [tokens, 768] round trip
+            # less on the chain; sequences of at most 64 positions), its weight gradient riding there where weight gradients ride
+            # (below 1536 tokens: at 6144 every one of the 3072 role workgroups walks a K loop of its own in front of the attention body --
+            #  11.87 vs 11.32 ms per step at 128 pairs; 2.26 vs 2.31 at 4 pairs, 3.37 vs 3.43 at 16: profiles/r05p_ab_attn_fuse_bwd.txt)
+            w_ride = w_o if self.ride else None
+            if (self.bf and T < 1536 and bool(_ab.get("attn_fuse_bwd")) and
+                    _lib.lib().univl_attention_bwd_fused(C.byref(attn_b), C.byref(o_dgrad), C.byref(w_ride) if w_ride is not None else None, 1, None) == 0):
+                plan.add_attn_bwd_fused(attn_b, o_dgrad, w_ride, sm)
+                if w_ride is None:
+                    wgrads.append(w_o)
+            else:
+                emit(o_dgrad, w_o)
+                plan.add("univl_attention_bwd", attn_b, sm)
             w_qkv = _gemm_desc(dt, dqkv, 3 * H, xin16, H, 3 * H, H, T, trans_a=1, trans_b=1,
                                out32=fl.g_fused(nm["qkv_w"]), ldc=H, accumulate=gs.acc(nm["qkv_w"][0]),
                                dbias=fl.g_fused(nm["qkv_b"]), **wg_tile,

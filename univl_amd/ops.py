@@ -180,6 +180,17 @@ def attention_bwd(*a, **kw):
     _lib.check(_lib.lib().univl_attention_bwd(_BYREF(d), _stream()), "attention_bwd")
 
 
+def attention_bwd_fused(attn, odgrad, owgrad=None, dry_run=False):
+    """univl_attention_bwd with the attention-output dgrad that produces its upstream gradient computed inside the launch, the weight
+    gradient of that projection optionally riding (univl_attention_bwd_fused).  Returns False where the C side does not carry the pair."""
+    rc = _lib.lib().univl_attention_bwd_fused(_BYREF(attn), _BYREF(odgrad), _BYREF(owgrad) if owgrad is not None else None,
+                                              int(bool(dry_run)), _stream())
+    if rc == _lib.EUNSUPPORTED:
+        return False
+    _lib.check(rc, "attention_bwd_fused")
+    return True
+
+
 def embed_text_desc(dtype, B, S, ids, word, pos, gamma, beta, *, type_ids=None, type_emb=None, eps=1e-12, y=None,
                     stats=None, out32=None, out16=None, p_post=0.0, seed=0, off_post=0, seed_dev=None, dout=None,
                     dword=None, dpos=None, dtype_emb=None, dgamma=None, dbeta=None, drows=None):
