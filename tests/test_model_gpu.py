@@ -939,7 +939,7 @@ def test_weight_gradient_packaging_matches_golden(golden_dir, name, ride, ab):
         # (round 5: the attention-output projection's pair became the fused attention backward, which carries that weight gradient)
         layers = cfg.text_num_hidden_layers + cfg.visual_num_hidden_layers
         assert kinds.count("univl_gemm_pair") + kinds.count("univl_gemm_pair_ln") + kinds.count("univl_attention_bwd_fused") >= 4 * layers
-        assert kinds.count("univl_attention_bwd_fused") >= layers and kinds.count("univl_attention_bwd") == 0
+        assert kinds.count("univl_attention_bwd_fused") >= layers      # (decoder / cross stacks keep univl_attention_bwd where Sq != Sk or > 64)
     else:
         assert kinds.count("univl_gemm_pair") == 0 and kinds.count("univl_gemm_group") >= cfg.text_num_hidden_layers + cfg.visual_num_hidden_layers
 
