@@ -227,6 +227,13 @@ int univl_attention_bwd(const UnivlAttention* d, hipStream_t stream);
  * validates without launching. */
 int univl_attention_bwd_fused(const UnivlAttention* at, const UnivlGemm* odgrad, const UnivlGemm* owgrad, int32_t dry_run, hipStream_t stream);
 
+/* univl_attention_fwd with the query / key / value projection (module_bert.py:172-174) computed INSIDE the launch: every workgroup
+ * multiplies the 64 x 192 block of q | k | v that belongs to its (batch row, head), stores it to the qkv buffer (bit-identical to
+ * univl_gemm(qkv)) and attends on it from LDS -- self-attention over at most 64 positions, bf16.  adam / chunk_*: BertAdam chunks
+ * riding in the launch like in univl_gemm_rider (NULL / 0: none).  UNIVL_EUNSUPPORTED where the launch does not carry the pair. */
+int univl_attention_fwd_fused(const UnivlAttention* at, const UnivlGemm* qkv, const struct UnivlAdam* adam, int32_t chunk_begin,
+                              int32_t chunk_count, int32_t max_blocks, int32_t dry_run, hipStream_t stream);
+
 /* ------------------------------------------------------------------------------------- text embeddings
  * BertEmbeddings / DecoderEmbeddings (module_bert.py:132-146, module_decoder.py:309-320):
  * gather word + position (+ token type) -> LayerNorm -> dropout.  Backward scatter-adds into the tables. */

@@ -243,9 +243,13 @@ def test_adam_rider_plan_builds_on_cpu(ab):
     ride = build_step(m, "joint", 2, 16, 16, True)
     names0 = [op[3] for op in base.fwd.ops]
     names1 = [op[3] for op in ride.fwd.ops]
+    L0_fused = cfg.text_num_hidden_layers + cfg.visual_num_hidden_layers
     assert [n.replace("univl_gemm_rider", "univl_gemm") for n in names1] == names0
     # (desc, key, slot, nslots) of every launch that can carry chunks: plain rider launches and the (product + LayerNorm) launches
     riders = [op[2] for op in ride.fwd.ops if op[0] == "rider"] + [(op[2][0],) + op[2][3:] for op in ride.fwd.ops if op[0] == "gemm_ln" and op[2][3] is not None]
+    # round 5: the q | k | v projection of a layer is computed inside the attention forward launch, which carries its quarter of the chunks
+    riders += [(op[2][1],) + op[2][2:] for op in ride.fwd.ops if op[0] == "attn_fwd_fused" and op[2][2] is not None]
+    assert sum(1 for n in names1 if n == "univl_attention_fwd_fused") == L0_fused and "univl_attention_fwd" not in names1
     L_t, L_v = cfg.text_num_hidden_layers, cfg.visual_num_hidden_layers
     assert len(riders) == 4 * ((L_t - 1) + (L_v - 1))
     # K8 / K10: the attention-output and FFN2 products of every layer carry their LayerNorm (round 4); no separate launch is left for those

@@ -882,6 +882,56 @@ def test_attention_bwd_with_the_output_dgrad_inside_equals_the_two_launches(B, S
     assert not ops.attention_bwd_fused(at_long, ops.gemm_desc(dY, Wo, 80, HD, HD, trans_b=True, out16=dctx2), None, dry_run=True)
 
 
+@pytest.mark.parametrize("B,S,p_drop,masked", [(4, 48, 0.1, False), (4, 48, 0.0, True), (3, 20, 0.1, True), (2, 64, 0.0, False), (5, 33, 0.1, True)])
+def test_attention_fwd_with_the_qkv_projection_inside_equals_the_two_launches(B, S, p_drop, masked):
+    """univl_attention_fwd_fused (round 5): the workgroup of a (batch row, head) multiplies its 64 x 192 block of q | k | v, stores it
+    and attends on it from LDS.  The qkv buffer, the attention output and the log-sum-exp are BIT-IDENTICAL to univl_gemm +
+    univl_attention_fwd (ragged key masks, a fully masked row, dropout, sequences that are not multiples of 16); rows of the qkv buffer
+    that belong to no sequence position are not touched."""
+    dtype, H, D = torch.bfloat16, 12, 64
+    dt = ops.dtype_code(dtype)
+    T, HD = B * S, H * D
+    x = gen(T, HD, seed=1).to(DEV, dtype)
+    W = gen(3 * HD, HD, seed=2, scale=0.05).to(DEV, dtype)
+    bias = gen(3 * HD, seed=3).to(DEV)
+    g = torch.Generator().manual_seed(7)
+    lens = torch.randint(1, S + 1, (B,), generator=g)
+    lens[0] = S
+    mask = (torch.arange(S)[None] < lens[:, None]).long()
+    if B > 1:
+        mask[1] = 0
+    km = mask.to(DEV) if masked else None
+    seed = torch.full((1,), 4321, dtype=torch.int64, device=DEV)
+    kw = dict(key_mask=km, p_drop=p_drop, offset=3 << 40, seed_dev=seed)
+
+    def run(fused):
+        qkv = torch.full((T + 2, 3 * HD), 5.0, device=DEV, dtype=dtype)[:T]      # (two guard rows behind the buffer)
+        ctx = torch.zeros(T, HD, device=DEV, dtype=dtype)
+        lse = torch.zeros(B, H, S, device=DEV)
+        args = (dt, B, H, S, S, (qkv, 0), 3 * HD, (qkv, HD), 3 * HD, (qkv, 2 * HD), 3 * HD, ctx, HD, lse)
+        if fused:
+            assert ops.attention_fwd_fused(ops.attention_desc(*args, **kw), ops.gemm_desc(x, W, T, 3 * HD, HD, out16=qkv, bias=bias))
+        else:
+            ops.gemm(x, W, T, 3 * HD, HD, out16=qkv, bias=bias)
+            ops.attention_fwd(*args, **kw)
+        torch.cuda.synchronize()
+        return qkv.clone(), ctx, lse
+
+    q0, c0, l0 = run(False)
+    assert rel_err(q0.float(), x.double().cpu() @ W.double().cpu().T + bias.double().cpu()) < 6e-3
+    for _ in range(4):
+        q1, c1, l1 = run(True)
+        assert torch.equal(q1, q0), float((q1.float() - q0.float()).abs().max())
+        assert torch.equal(c1, c0), float((c1.float() - c0.float()).abs().max())
+        assert torch.equal(l1, l0)
+    # not carried: cross attention shapes (Sq != Sk), more than 64 positions, a causal mask
+    qkv = torch.zeros(160, 3 * HD, device=DEV, dtype=dtype)
+    ctx = torch.zeros(160, HD, device=DEV, dtype=dtype)
+    lse = torch.zeros(2, H, 80, device=DEV)
+    at = ops.attention_desc(dt, 2, H, 80, 80, (qkv, 0), 3 * HD, (qkv, HD), 3 * HD, (qkv, 2 * HD), 3 * HD, ctx, HD, lse)
+    assert not ops.attention_fwd_fused(at, ops.gemm_desc(x[:160] if T >= 160 else torch.zeros(160, HD, device=DEV, dtype=dtype), W, 160, 3 * HD, HD, out16=qkv), dry_run=True)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_maximum_sequence_and_limit(dtype):
     """Largest sequence the single-pass kernels hold in LDS (384 bf16 / 256 fp32) and the loud failure one past it."""

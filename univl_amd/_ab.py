@@ -30,6 +30,7 @@ KEYS = {
     "ln_fold": (1, "LayerNorm forward finished inside its product's launch (univl_gemm_ln) up to 512 tokens"),
     "ln_fold_bwd": (1, "LayerNorm backward finished inside the dgrad pair launch (univl_gemm_pair_ln) below 384 tokens"),
     "wgrad_big_min": (0, "token count from which a layer's grouped weight gradients take the big tile (0: where every dgrad does)"),
+    "attn_fuse_fwd": (1, "the q | k | v projection computed inside the attention forward launch (univl_attention_fwd_fused); 0: two launches"),
     "attn_fuse_bwd": (1, "the attention-output dgrad computed inside the attention backward launch (univl_attention_bwd_fused); 0: two launches"),
     "g256": (1, "256 x 256 8-phase body (csrc/gemm256.h) for the grouped weight gradients / single products it is picked for; 0: the older tiles"),
     "g256_min_rows": (1536, "token count (a multiple of 256) from which the plans drop the pair launches for separate dgrads + the grouped 256-body launch"),

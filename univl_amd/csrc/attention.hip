@@ -22,106 +22,11 @@ namespace {
 
 #include "attn_body.h"
 
-// ------------------------------------------------------------------------------------------------ forward
+// ------------------------------------------------------------------------------------------------ forward (body: attn_body.h)
 template <typename T, int MAXKT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(UnivlAttention p, int Sk_pad, float scale) {
-    using C = AttnCfg<T>;
-    using M = Mma<T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* sK = reinterpret_cast<T*>(smem_raw);                     // K-major reads only: PK image
-    T* sV = sK + Sk_pad * C::PK;                                // transpose reads only: PT image
-    float* sM = reinterpret_cast<float*>(sV + Sk_pad * C::PT);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
-    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
-    const T* Kg = reinterpret_cast<const T*>(p.k) + (long)b * (p.bsk ? p.bsk : (long)p.Sk * p.ldk) + h * HD;
-    const T* Vg = reinterpret_cast<const T*>(p.v) + (long)b * (p.bsv ? p.bsv : (long)p.Sk * p.ldv) + h * HD;
-    // per-wave operands straight from global memory are requested BEFORE the K/V staging round trip (clamped rows:
-    // lanes / waves beyond Sq read a valid row and never store), so the kernel pays one global latency, not two
-    const int q0 = blockIdx.y * 64 + wave * 16;
-    const int q = q0 + i;
-    const bool qv = q < p.Sq;
-    const int qc = min(q, p.Sq - 1);
-    const T* Qg = reinterpret_cast<const T*>(p.q) + ((long)b * p.Sq + qc) * p.ldq + h * HD;
-    typename M::frag fq[C::NCD];
-#pragma unroll
-    for (int c = 0; c < C::NCD; ++c) fq[c] = M::gmem_kmajor(Qg + c * C::CH, g);
-    const uint64_t seed = seed_fetch(p);
-    const MaskRegs mk = mask_fetch(p.key_mask, p.q, b, p.Sk, tid);
-    constexpr int TRIPS = (MAXKT * 16 * (HD / C::EPC) <= 1024) ? (MAXKT * 16 * (HD / C::EPC) + 511) / 512 : 0;
-    stage_pair<T, TRIPS, C::PK, 0, C::PT, 0>(sK, nullptr, Kg, p.ldk, sV, nullptr, Vg, p.ldv, p.Sk, Sk_pad, tid);
-    mask_store(sM, mk, p.key_mask != nullptr, p.Sk, Sk_pad, tid);
-    __syncthreads();
-    if (q0 >= p.Sq) return;
-
-    const int nkt = Sk_pad / 16;
-    f32x4_t s[MAXKT];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < MAXKT; ++kt) {
-        s[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (kt < nkt) {
-#pragma unroll
-            for (int c = 0; c < C::NCD; ++c)
-                s[kt] = M::mma(M::lds_kmajor(sK + (kt * 16 + i) * C::PK + c * C::CH, g), fq[c], s[kt]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + 4 * g + r;
-                const float v = s[kt][r] * scale + key_bias(sM, key, q, p.Sk, p.causal);
-                s[kt][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < MAXKT; ++kt) {
-        if (kt < nkt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = expf(s[kt][r] - mx);
-                s[kt][r] = e;
-                sum += e;
-            }
-        }
-    }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    if (p.lse && qv && g == 0) p.lse[((long)bh) * p.Sq + q] = mx + logf(sum);
-    const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-    const uint64_t drow = ((uint64_t)bh * p.Sq + q) * (uint64_t)p.Sk;
-#pragma unroll
-    for (int kt = 0; kt < MAXKT; ++kt) {
-        if (kt < nkt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = s[kt][r] * inv;
-                if (p.p_drop > 0.f) v *= dropout_scale(seed, p.offset, drow + (uint64_t)(kt * 16 + 4 * g + r), p.p_drop, inv_keep);
-                s[kt][r] = v;
-            }
-        }
-    }
-    // O^T[d, q] = sum_key V^T[d, key] P^T[key, q]
-    f32x4_t o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kc = 0; kc < MAXKT / C::TPC; ++kc) {
-        if (kc * C::TPC < nkt) {
-            const typename M::frag fp = M::from_acc(s[kc * C::TPC], s[kc * C::TPC + C::TPC - 1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                o[dt] = M::mma(M::lds_tmajor(sV + (kc * C::CH) * C::PT + dt * 16, C::PT, lane), fp, o[dt]);
-        }
-    }
-    if (qv) {
-        T* Og = reinterpret_cast<T*>(p.out) + ((long)b * p.Sq + q) * p.ldo + h * HD;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) store4<T>(Og + dt * 16 + 4 * g, o[dt], 1.0f);
-    }
+    attn_fwd_body<T, MAXKT, false>(p, Sk_pad, scale, (int)blockIdx.x, (int)blockIdx.y, smem_raw);
 }
 
 // ------------------------------------------------------------------------------------------------ backward (body: attn_body.h)

@@ -1007,6 +1007,95 @@ __global__ __launch_bounds__(256) void attn_bwd_odgrad_kernel(AttnFusedArgs a) {
     }
 }
 
+// The forward twin: the query / key / value projection (module_bert.py:172-174: three nn.Linear on the layer input) INSIDE the attention
+// forward.  A workgroup owns one (batch row, head): it multiplies the 64 x 192 block  x[rows of the sequence] . [W_q | W_k | W_v][head]^T
+// (+ bias), stores it to the qkv buffer the backward reads (same bf16 bits as the product's own epilogue), keeps it in the LDS images of
+// attn_fwd_body (FUSED) and runs the attention on it: the attention launch and its [tokens, 2304] read leave the forward chain.  The
+// launch carries BertAdam chunks like gemm_adam_kernel (workgroups behind the attention ones): the forward launches of a layer are
+// bound by the optimizer bytes that ride in them (16 us against 10 without), so the longer per-workgroup product (384 KB through
+// one compute unit instead of 192) hides behind them.  Eight waves (2 x 4: 32 x 48 outputs each) multiply, the first four attend.
+struct AttnFwdFusedArgs {
+    UnivlAttention at;
+    int Sk_pad;
+    const __bf16* X; long ldx;          // layer input [tokens, K]
+    const __bf16* W; long ldw;          // [3 * H * 64, K]: q | k | v weights, K-major
+    const float* bias;                  // [3 * H * 64] or null
+    __bf16* qkv; long ldqkv;            // [tokens, 3 * H * 64]
+    int K;
+    int n_attn, n_attn_pad;
+};
+
+template <bool NT>
+__global__ __launch_bounds__(512, 2) void attn_fwd_qkv_kernel(AttnFwdFusedArgs a, UnivlAdam ad, int c0, int c1) {
+    const int w0 = blockIdx.x;
+    if (w0 >= a.n_attn_pad) {
+        const int nb = (int)gridDim.x - a.n_attn_pad;
+        for (int c = c0 + (w0 - a.n_attn_pad); c < c1; c += nb) adam_chunk<NT, 512>(ad, c);
+        return;
+    }
+    if (w0 >= a.n_attn) return;
+    using TileA = Tile<__bf16, false, 64, 64, 512>;
+    using TileB = Tile<__bf16, false, 192, 64, 512>;
+    const int bh = w0, b = bh / a.at.H, h = bh % a.at.H;
+    const int HD3 = a.at.H * 64, Sq = a.at.Sq;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+    const int wm0 = (wave >> 2) * 32, wn0 = (wave & 3) * 48;
+    unsigned char* sA = smem_raw;
+    unsigned char* sB = sA + 2 * TileA::BYTES;
+    f32x4_t acc[2][3];
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 3; ++tb) acc[ta][tb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const __bf16* pa[TileA::PER_THREAD];
+    const __bf16* pb[TileB::PER_THREAD];
+    TileA::init(pa, a.X + (long)b * Sq * a.ldx, a.ldx, 0, 0, Sq, tid);
+#pragma unroll
+    for (int c = 0; c < TileB::PER_THREAD; ++c) {           // tile row r -> weight row (r / 64) * H * 64 + h * 64 + r % 64: the head's rows of W_q, W_k, W_v
+        int r, q;
+        TileB::coords(c, tid, r, q);
+        pb[c] = a.W + (long)((r >> 6) * HD3 + h * 64 + (r & 63)) * a.ldw + q * 8;
+    }
+    const int nfull = a.K / 64;
+    TileA::issue(pa, sA, tid);
+    TileB::issue(pb, sB, tid);
+    TileA::advance(pa, 64);
+    TileB::advance(pb, 64);
+    __syncthreads();
+    for (int t = 0; t < nfull; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nfull) {
+            TileA::issue(pa, sA + (cur ^ 1) * TileA::BYTES, tid);
+            TileB::issue(pb, sB + (cur ^ 1) * TileB::BYTES, tid);
+            TileA::advance(pa, 64);
+            TileB::advance(pb, 64);
+        }
+        tile_mma<__bf16, false, false, 2, 3, 2, TileA, TileB>(sA + cur * TileA::BYTES, sB + cur * TileB::BYTES, wm0, wn0, lane, acc);
+        __syncthreads();
+    }
+    // epilogue: + bias -> bf16 -> the qkv buffer (rows of the sequence) and the LDS images of the attention body (rows beyond it: zero)
+    const AttnFwdImages<__bf16> im(smem_raw, a.Sk_pad);
+    using C = AttnCfg<__bf16>;
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb) {
+        const int col = wn0 + 16 * tb + i, panel = col >> 6, c64 = col & 63;
+        const int gcol = panel * HD3 + h * 64 + c64;
+        const float bv = a.bias ? a.bias[gcol] : 0.0f;
+        __bf16* img = panel == 0 ? im.sQ : (panel == 1 ? im.sK : im.sV);
+        const int pitch = panel == 2 ? C::PT : C::PK;
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm0 + 16 * ta + 4 * g + r;
+                const __bf16 v = (__bf16)(acc[ta][tb][r] * 1.0f + bv);
+                if (row < Sq) a.qkv[((long)b * Sq + row) * a.ldqkv + gcol] = v;
+                if (row < a.Sk_pad || panel == 0) img[row * pitch + c64] = row < Sq ? v : (__bf16)0.0f;
+            }
+    }
+    attn_fwd_body<__bf16, 4, true>(a.at, a.Sk_pad, 0.125f, bh, 0, smem_raw);
+}
+
 // EXPERIMENTAL (UNIVL_ADAM_RIDE=1 with graphed.GraphedTrainStep(pipeline_optimizer=True)): a forward product and a range of BertAdam
 // chunks in ONE launch.  The fused update is one 0.8 ms HBM stream (30 B per parameter) at the end of a step whose forward is a chain
 // of latency-bound kernels on a third of the compute units; its only ordering constraints are "after the clip of its own backward"
@@ -1518,6 +1607,61 @@ extern "C" int univl_attention_bwd_fused(const UnivlAttention* at, const UnivlGe
     return UNIVL_OK;
 }
 
+// univl_attention_fwd with the q / k / v projection that produces its inputs computed inside the launch (attn_fwd_qkv_kernel above), and
+// optionally BertAdam chunks riding like in univl_gemm_rider.  bf16 self-attention over at most 64 positions; qkv: K-major x K-major,
+// [tokens, K] x [3 * H * 64, K] -> bf16 C16 with at->q / k / v = C16 + 0 / H * 64 / 2 * H * 64 and ldq = ldk = ldv = ldc, K a multiple
+// of 64, bias optional, no other epilogue.  Results (the qkv buffer, the attention output, the log-sum-exp) are bit-identical to
+// univl_gemm + univl_attention_fwd.  UNIVL_EUNSUPPORTED otherwise; adam may be NULL (chunk_count 0).
+static const size_t ATTN_FWD_FUSED_SMEM = 2 * (size_t)(64 + 192) * 64 * sizeof(__bf16);
+static void attn_fwd_fused_allow_lds() {
+    static bool done_nt[UNIVL_MAX_DEVICES] = {}, done_t[UNIVL_MAX_DEVICES] = {};
+    univl_allow_lds(attn_fwd_qkv_kernel<true>, ATTN_FWD_FUSED_SMEM, done_nt);
+    univl_allow_lds(attn_fwd_qkv_kernel<false>, ATTN_FWD_FUSED_SMEM, done_t);
+}
+
+extern "C" int univl_attention_fwd_fused(const UnivlAttention* at, const UnivlGemm* qkv, const UnivlAdam* adam, int32_t chunk_begin,
+                                         int32_t chunk_count, int32_t max_blocks, int32_t dry_run, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    UNIVL_CHECK_ARG(at != nullptr && qkv != nullptr, UNIVL_EINVAL, "univl_attention_fwd_fused: null descriptor");
+    UNIVL_CHECK_ARG(chunk_count == 0 || (adam != nullptr && adam->p && adam->g && adam->m && adam->v && adam->segs && adam->chunk_seg &&
+                                         adam->chunk_off && adam->chunk_len && adam->seg_scalars && chunk_begin >= 0 && chunk_count > 0 &&
+                                         chunk_begin + chunk_count <= adam->nchunk),
+                    UNIVL_EINVAL, "univl_attention_fwd_fused: chunks [%d, +%d)", chunk_begin, chunk_count);
+    int rc = attn_check(at, "univl_attention_fwd_fused", false);
+    if (rc) return rc;
+    const int Sk_pad = (at->Sk + 31) / 32 * 32;
+    const UnivlGemm* g = qkv;
+    const long hd = (long)at->H * 64;
+    const __bf16* c16 = reinterpret_cast<const __bf16*>(g->C16);
+    UNIVL_CHECK_ARG(at->dtype == UNIVL_DT_BF16 && at->Sq == at->Sk && Sk_pad <= 64 && !at->causal && at->bsk == 0 && at->bsv == 0 &&
+                        g->dtype == UNIVL_BF16 && !g->trans_a && !g->trans_b && g->M == at->B * at->Sq && g->N == 3 * hd && g->K % 64 == 0 &&
+                        g->K >= 64 && c16 != nullptr && !g->C32 && !g->R && !g->dbias && !g->sumsq && !g->aux && g->alpha == 1.0f &&
+                        g->ksplit <= 1 && (g->flags & ~(UNIVL_GEMM_XCD_MAP)) == 0 && aligned16(g->A) && aligned16(g->B) && g->lda % 8 == 0 &&
+                        g->ldb % 8 == 0 && at->q == (const void*)c16 && at->k == (const void*)(c16 + hd) && at->v == (const void*)(c16 + 2 * hd) &&
+                        at->ldq == g->ldc && at->ldk == g->ldc && at->ldv == g->ldc,
+                    UNIVL_EUNSUPPORTED, "univl_attention_fwd_fused: not a (q|k|v projection, self-attention) pair this launch carries");
+    if (dry_run) return UNIVL_OK;
+    AttnFwdFusedArgs a;
+    a.at = *at;
+    a.Sk_pad = Sk_pad;
+    a.X = reinterpret_cast<const __bf16*>(g->A); a.ldx = g->lda;
+    a.W = reinterpret_cast<const __bf16*>(g->B); a.ldw = g->ldb;
+    a.bias = g->bias;
+    a.qkv = reinterpret_cast<__bf16*>(g->C16); a.ldqkv = g->ldc;
+    a.K = g->K;
+    a.n_attn = at->B * at->H;
+    a.n_attn_pad = (a.n_attn + 7) / 8 * 8;
+    const int nb = chunk_count <= 0 ? 0 : ((max_blocks > 0 && max_blocks < chunk_count) ? max_blocks : chunk_count);
+    UnivlAdam none = {};
+    const UnivlAdam& ad = chunk_count > 0 ? *adam : none;
+    attn_fwd_fused_allow_lds();
+    const int cb = chunk_begin, ce = chunk_begin + (chunk_count > 0 ? chunk_count : 0);
+    if (univl_adam_nt()) hipLaunchKernelGGL(attn_fwd_qkv_kernel<true>, dim3(a.n_attn_pad + nb), dim3(512), ATTN_FWD_FUSED_SMEM, stream, a, ad, cb, ce);
+    else hipLaunchKernelGGL(attn_fwd_qkv_kernel<false>, dim3(a.n_attn_pad + nb), dim3(512), ATTN_FWD_FUSED_SMEM, stream, a, ad, cb, ce);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
 static const size_t RIDER_SMEM = 4 * (size_t)Tile<__bf16, false, 64, 128, 512>::BYTES;          // two stages of A and B
 static void rider_allow_lds() {
     static bool done_nt[UNIVL_MAX_DEVICES] = {}, done_t[UNIVL_MAX_DEVICES] = {};
@@ -1612,6 +1756,7 @@ extern "C" int univl_gemm_ln(const UnivlGemm* gemm, const UnivlLayerNorm* ln, in
 extern "C" int univl_gemm_rider_prime(hipStream_t stream) {
     UNIVL_ON_STREAM_DEVICE(stream);
     rider_allow_lds();
+    attn_fwd_fused_allow_lds();
     static bool done_nt[UNIVL_MAX_DEVICES] = {}, done_t[UNIVL_MAX_DEVICES] = {};
     univl_allow_lds(gemm_ln_kernel<true>, RIDER_SMEM, done_nt);
     univl_allow_lds(gemm_ln_kernel<false>, RIDER_SMEM, done_t);

@@ -355,6 +355,15 @@ class Plan:
         self.descs[len(self.ops)] = [dgrad, wgrad]
         self.ops.append(("pair", fn, arr, "univl_gemm_pair", stream))
 
+    def add_attn_fwd_fused(self, attn, qkv, key=None, slot=0, nslots=1, stream=0):
+        """The attention forward with the q | k | v projection computed inside the launch (univl_attention_fwd_fused); with `key` it
+        also carries optimizer chunks like add_gemm_rider."""
+        self.keep += [attn, qkv]
+        self.descs[len(self.ops)] = [qkv]
+        if key is not None:
+            self.rider_keys.add(key)
+        self.ops.append(("attn_fwd_fused", _lib.lib().univl_attention_fwd_fused, (attn, qkv, key, int(slot), int(nslots)), "univl_attention_fwd_fused", stream))
+
     def add_attn_bwd_fused(self, attn, odgrad, owgrad, stream=0):
         """The attention backward with the attention-output dgrad that feeds it computed inside the launch, the weight gradient of
         that projection riding as extra workgroups (univl_attention_bwd_fused; owgrad may be None)."""
@@ -497,6 +506,23 @@ class Plan:
                 rc = a(C.byref(b[0]), C.byref(b[1]), 0, h)
                 if rc != 0:
                     _lib.check(rc, name)
+            elif kind == "attn_fwd_fused":
+                h = handles.get(sidx)
+                if h is None:
+                    h = handles[sidx] = C.c_void_p(self._stream(sidx, cur).cuda_stream)
+                at, qd, key, slot, nslots = b
+                rd = self.riders
+                rng = rd["ranges"].get(key) if (rd and key is not None) else None
+                if rng is not None and (key, slot) in rd["used"]:
+                    rng = None
+                if rng is None:
+                    rc = a(C.byref(at), C.byref(qd), None, 0, 0, 0, 0, h)
+                else:
+                    rd["used"].add((key, slot))
+                    lo, hi = rng[0] + rng[1] * slot // nslots, rng[0] + rng[1] * (slot + 1) // nslots
+                    rc = a(C.byref(at), C.byref(qd), C.byref(rd["desc"]), lo, hi - lo, int(rd.get("max_blocks", 0)), 0, h)
+                if rc != 0:
+                    _lib.check(rc, name)
             elif kind == "attn_fused":
                 h = handles.get(sidx)
                 if h is None:
@@ -602,6 +628,8 @@ class Plan:
                 out.append((lambda h, d=arg[0]: _lib.lib().univl_gemm(C.byref(d), h), self.descs[i]))
             elif kind == "pair" and name.startswith(prefix):
                 out.append((lambda h, fn=fn, arg=arg: fn(C.byref(arg[0]), C.byref(arg[1]), 0, h), self.descs[i]))
+            elif kind == "attn_fwd_fused" and prefix == "univl_gemm":
+                out.append((lambda h, arg=arg: _lib.lib().univl_gemm(C.byref(arg[1]), h), self.descs[i]))
             elif kind == "attn_fused" and prefix == "univl_gemm":
                 # the dense contractions inside the fused launch, replayed the way they ran before it existed (the family's accounting)
                 if arg[2] is not None:
@@ -845,11 +873,21 @@ class EncoderStack:
                     plan.add("univl_gemm", desc, sm)
 
             wqkv, bqkv = fl.wop_fused(nm["qkv_w"]), fl.w32_fused(nm["qkv_b"])
-            gemm(_gemm_desc(dt, x16, H, wqkv, H, T, 3 * H, H, out16=ws["qkv"], ldc=3 * H, bias=bqkv))
             qkv = ws["qkv"]
-            plan.add("univl_attention_fwd", ops.attention_desc(
+            qkv_desc = _gemm_desc(dt, x16, H, wqkv, H, T, 3 * H, H, out16=qkv, ldc=3 * H, bias=bqkv)
+            attn_f = ops.attention_desc(
                 dt, B, self.NH, S, S, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx"], H, ws["lse"],
-                key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev), sm)
+                key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev)
+            # Round 5: the q | k | v projection computed INSIDE the attention forward (sequences of at most 64 positions, below 1536
+            # tokens): one launch less on the forward chain; the launch carries the optimizer chunks the projection's launch carried
+            if (self.bf and T < 1536 and bool(_ab.get("attn_fuse_fwd")) and
+                    _lib.lib().univl_attention_fwd_fused(C.byref(attn_f), C.byref(qkv_desc), None, 0, 0, 0, 1, None) == 0):
+                key = ("layer", self.prefix, l + 1) if (self.adam_ride and l + 1 < self.L) else None
+                plan.add_attn_fwd_fused(attn_f, qkv_desc, key, slot[0], 4, sm)
+                slot[0] += 1 if key is not None else 0
+            else:
+                gemm(qkv_desc)
+                plan.add("univl_attention_fwd", attn_f, sm)
             ln_fwd = (lambda d: None) if self.probe_no_ln in ("fwd", "both") else (lambda d: plan.add("univl_layernorm_fwd", d, sm))
 
             def gemm_ln(desc, lnd, site, _l=l, _slot=slot):

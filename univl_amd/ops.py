@@ -191,6 +191,16 @@ def attention_bwd_fused(attn, odgrad, owgrad=None, dry_run=False):
     return True
 
 
+def attention_fwd_fused(attn, qkv, dry_run=False):
+    """univl_attention_fwd with the q | k | v projection computed inside the launch (univl_attention_fwd_fused, no riding optimizer
+    chunks).  Returns False where the C side does not carry the pair."""
+    rc = _lib.lib().univl_attention_fwd_fused(_BYREF(attn), _BYREF(qkv), None, 0, 0, 0, int(bool(dry_run)), _stream())
+    if rc == _lib.EUNSUPPORTED:
+        return False
+    _lib.check(rc, "attention_fwd_fused")
+    return True
+
+
 def embed_text_desc(dtype, B, S, ids, word, pos, gamma, beta, *, type_ids=None, type_emb=None, eps=1e-12, y=None,
                     stats=None, out32=None, out16=None, p_post=0.0, seed=0, off_post=0, seed_dev=None, dout=None,
                     dword=None, dpos=None, dtype_emb=None, dgamma=None, dbeta=None, drows=None):
