@@ -537,7 +537,7 @@ def main():
             import glob
             import hashlib
             hs = hashlib.sha256()
-            for name in ("gemm.hip", "common.h"):
+            for name in ("gemm.hip", "gemm256.h", "attn_body.h", "common.h"):
                 hs.update(open(os.path.join(ROOT, "univl_amd", "csrc", name), "rb").read())
             for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_pmc.json")), reverse=True):
                 try:
@@ -551,7 +551,7 @@ def main():
                     continue
         step_bytes = int((8 + bpp) * n_params + 1.0e8)
         roofline = dict(
-            kernel="gemm_kernel / gemm_pair_kernel / gemm_group_kernel family (univl_amd/csrc/gemm.hip): every dense contraction of one step",
+            kernel="gemm_kernel / gemm_pair_kernel / gemm_group_kernel / gemm256 family (univl_amd/csrc/gemm.hip, gemm256.h): every dense contraction of one step",
             bound="hbm" if hbm_frac >= mfma_frac else "mfma",
             achieved=round(fam["algorithmic_bytes_per_step"] / fam_s / 1e9, 1) if hbm_frac >= mfma_frac
             else round(fam["flops_per_step"] / fam_s / 1e12, 1),

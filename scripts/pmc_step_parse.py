@@ -21,8 +21,10 @@ def rows(d):
 def family(name):
     # gemm_ln_kernel / the FOLD forms of gemm_pair_kernel (round 4) also finish a LayerNorm: its rows (~2.4 MB per launch at 192 tokens)
     # are counted with the family -- the reported traffic-over-algorithmic ratio is an upper bound
+    # round 5: the 256 x 256 body (gemm256_*) and the two attention launches that compute a projection inside (attn_fwd_qkv_kernel: the
+    # q | k | v product; attn_bwd_odgrad_kernel: the attention-output dgrad + its riding weight gradient) belong to the family as run
     if ("gemm_group_kernel" in name or "gemm_kernel" in name or "gemm_pair_kernel" in name or "gemm_ln_kernel" in name
-            or "gemm_adam_kernel" in name):
+            or "gemm_adam_kernel" in name or "gemm256" in name or "attn_fwd_qkv_kernel" in name or "attn_bwd_odgrad_kernel" in name):
         return "gemm"
     if "adam_apply" in name:
         return "adam"
@@ -73,7 +75,7 @@ def main(fetch_dir, write_dir, mfma_dir, elements, steps, out):
     import hashlib, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for name in ("gemm.hip", "common.h"):
+    for name in ("gemm.hip", "gemm256.h", "attn_body.h", "common.h"):
         h.update(open(os.path.join(root, "univl_amd", "csrc", name), "rb").read())
     res["kernel_source_sha16"] = h.hexdigest()[:16]
     json.dump(res, open(out, "w"), indent=1)
