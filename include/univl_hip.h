@@ -144,7 +144,10 @@ int univl_gemm_pair(const UnivlGemm* dgrad, const UnivlGemm* wgrad, int32_t dry_
  * what 0: plain-grid map, in out[0..2] = hardware block index, out = the tile that block computes;
  * what 1: out[0] <- position of linear workgroup out[0] in the XCD-grouped tile list of nx tiles;
  * what 2: out[0..2] <- tile number out[0] of an nx x ny x nz problem (a grouped launch's member);
- * what 3: out[0..2] <- the tile local workgroup out[0] of one half of a pair / rider launch computes. */
+ * what 3: out[0..2] <- the tile local workgroup out[0] of one half of a pair / rider launch computes;
+ * what 4: the rider launch of the 64 x 128 tile (round 5), whose update workgroups are spread through the grid in groups of 8: workgroup
+ *         out[0] of nx + ny (nx tile slots, ny update workgroups, both multiples of 8) -> out[1] = 1 and out[0] = its update index, or
+ *         out[1] = 0 and out[0] = its tile slot (congruent to the workgroup id modulo 8). */
 int univl_gemm_tile_map(int32_t what, int32_t nx, int32_t ny, int32_t nz, int32_t gm, int32_t* out);
 
 /* Host-side evaluation of the LDS maps of the 256 x 256 product body (csrc/gemm256.h; no device work -- lets a CPU test prove that the
@@ -413,6 +416,11 @@ int univl_bert_adam_range(const UnivlAdam* d, int32_t chunk_begin, int32_t chunk
  * the chunk range as its own launch -- same result.  max_blocks > 0 caps the workgroups given to the update. */
 int univl_gemm_rider(const UnivlGemm* gemm, const UnivlAdam* adam, int32_t chunk_begin, int32_t chunk_count, int32_t max_blocks,
                      hipStream_t stream);
+/* Round 5: the launch also carries products on the 64 x 128 tile (what univl_gemm picks from 1536 rows on).  Host-side question, no
+ * device work: 1 if univl_gemm_rider carries chunks INSIDE this product's launch, 0 if it would enqueue the update behind the product
+ * (the 128 x 128 and 256 x 256 tiles, transposed operands, fp32); negative: the descriptor's validation error.  A host spreads a
+ * layer's chunks over the products that answer 1 (engine.EncoderStack.build_forward). */
+int univl_gemm_rider_fits(const UnivlGemm* gemm);
 /* K8 / K10 of the survey (module_bert.py:207-211, 246-250: dense -> dropout -> + input -> LayerNorm; the copies in module_visual.py /
  * module_cross.py): a forward product whose fp32 output is the input x of a LayerNorm, with that LayerNorm finished INSIDE the product's
  * launch -- each 64-row block of the output is normalised by the last workgroups to contribute to it (agent-scope release / acquire around

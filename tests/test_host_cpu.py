@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _model(dt="bf16", **kw):
-    cfg = O.OracleConfig(batch_size=2, text_num_hidden_layers=2, visual_num_hidden_layers=1, max_words=16, max_frames=16, **kw)
+    cfg = O.OracleConfig(**dict(dict(batch_size=2, text_num_hidden_layers=2, visual_num_hidden_layers=1, max_words=16, max_frames=16), **kw))
     ns = argparse.Namespace(**cfg.to_dict(), local_rank=0, compute_dtype=dt)
     m = UniVL.from_pretrained("bert-base-uncased", "visual-base", "cross-base", "decoder-base", task_config=ns)
     return m, cfg
@@ -273,6 +273,51 @@ def test_adam_rider_plan_builds_on_cpu(ab):
     bw0 = [op[3] for op in build_step(m, "joint", 2, 16, 16, True).backward_plan(True).ops]
     ab(ln_fold_bwd=None)
     assert bw0.count("univl_gemm_pair_ln") == 0 and bw0.count("univl_layernorm_bwd") == bw.count("univl_layernorm_bwd") + bw.count("univl_gemm_pair_ln")
+
+
+def test_rect_rider_workgroup_roles_are_a_bijection():
+    """gemm_adam_rect_kernel spreads its update workgroups through the grid (groups of 8 ids, one per XCD): every tile slot and every
+    update index is taken exactly once, and a tile slot keeps its workgroup id modulo 8 (what the XCD-aware tile order is built on)."""
+    import ctypes as C
+    L = _lib.lib()
+    for nd_pad, nb in ((2304, 288), (576, 288), (8, 8), (16, 296), (1152, 8), (24, 1000), (4608, 224)):
+        tiles, upd = [], []
+        for w0 in range(nd_pad + nb):
+            out = (C.c_int32 * 3)(w0, 0, 0)
+            assert L.univl_gemm_tile_map(4, nd_pad, nb, 1, 0, out) == 0
+            (upd if out[1] else tiles).append(out[0])
+            assert out[1] or out[0] % 8 == w0 % 8
+        assert sorted(tiles) == list(range(nd_pad)) and sorted(upd) == list(range(nb)), (nd_pad, nb)
+        if nd_pad >= 8 * nb:           # spread: no stretch of tile slots longer than two periods without an update group
+            pos = [w0 for w0 in range(nd_pad + nb) if (lambda o: (L.univl_gemm_tile_map(4, nd_pad, nb, 1, 0, o), o[1])[1])((C.c_int32 * 3)(w0, 0, 0))]
+            gaps = [b - a for a, b in zip(pos[:-1], pos[1:])]
+            assert max(gaps) <= 2 * (nd_pad + nb) // (nb // 8) // 1, (nd_pad, nb, max(gaps))
+
+
+def test_adam_rider_slots_from_1536_tokens_follow_the_library(ab):
+    """From 1536 tokens on a layer's optimizer chunks are spread over the forward products univl_gemm_rider_fits says carry them
+    (round 5: the 64 x 128 tile has a rider kernel, the 128 x 128 and 256 x 256 tiles have none); every layer's range is covered once."""
+    import ctypes as C
+    from univl_amd.steps import build_step
+    m, cfg = _model("bf16", max_words=48, max_frames=48)
+    m._flat, m._seed_dev = FlatParams(list(m.named_parameters()), "cpu", torch.bfloat16), torch.zeros(1, dtype=torch.int64)
+    m.train()
+    m._flat.adam_ride = True
+    for B in (32, 128):
+        st = build_step(m, "joint", B, 48, 48, True)
+        riders = [op[2] for op in st.fwd.ops if op[0] == "rider"]
+        assert riders and all(_lib.lib().univl_gemm_rider_fits(C.byref(d)) == 1 for d, _, _, _ in riders)
+        plain = [st.fwd.descs[i][0] for i, op in enumerate(st.fwd.ops) if op[0] == "call" and op[3] == "univl_gemm"]
+        by_key = {}
+        for _, key, slot, n in riders:
+            by_key.setdefault(key, []).append((slot, n))
+        assert set(by_key) == {("layer", "bert", l) for l in range(1, cfg.text_num_hidden_layers)}      # (one video layer: nothing to carry)
+        for key, sl in by_key.items():
+            assert sorted(s_ for s_, _ in sl) == list(range(sl[0][1])), (B, key, sl)
+        # a product of a carrying layer that is NOT a rider launch is one the library does not carry
+        layer0 = [d for d in plain if d.M == B * 48 and d.K in (768, 3072) and d.N in (768, 2304, 3072)]
+        n_carry = len(by_key[("layer", "bert", 1)])
+        assert n_carry + sum(1 for d in layer0 if _lib.lib().univl_gemm_rider_fits(C.byref(d)) == 0) >= 4 or n_carry == 4, (B, n_carry)
 
 
 def test_stage_inputs_host_logic_on_cpu():

@@ -646,7 +646,7 @@ def test_dropout_training_runs_and_is_seeded():
             assert torch.isfinite(p.grad).all(), n
 
 
-def _train(kind, case, steps=5, lr=1e-5, dtype=torch.float32):
+def _train(kind, case, steps=5, lr=1e-5, dtype=torch.float32, spy=None):
     """`steps` optimizer steps on one fixed batch; returns the per-step losses, sampled final parameters and
     bookkeeping of the gradient exchange.  kind: eager | graph | graph_nopipe | loopback_eager | loopback_graph
     (graph / loopback_graph: BertAdam pipelined with the next forward, univl_amd.graphed)."""
@@ -685,6 +685,8 @@ def _train(kind, case, steps=5, lr=1e-5, dtype=torch.float32):
             losses.append(float(loss))
         mode = "eager"
         opt.flush()          # bf16: step() leaves its update to the next forward; the parameters are read below past the module API (flat.w32)
+    if spy is not None:
+        spy(model)
     used = model.used_parameter_names()
     final = {n: model.flat.w32(n).detach().float().cpu() for n in (used[0], used[3], used[len(used) // 2], used[-1])}
     red = model._reducer
@@ -954,6 +956,38 @@ def test_adam_update_riding_with_the_next_forward_matches_eager(case):
     ref_l, ref_p, _ = _train("eager", case, dtype=torch.bfloat16)
     l, p, info = _train("graph", case, dtype=torch.bfloat16)
     assert info["mode"] == "whole"
+    assert l == ref_l, (l, ref_l)
+    for n in ref_p:
+        assert torch.equal(p[n], ref_p[n]), (n, max_abs(p[n], ref_p[n]))
+
+
+def test_adam_update_riding_in_rectangular_tile_products_matches_the_plain_update(ab):
+    """From 1536 tokens on the forward products run on the 64 x 128 tile; round 5 gave that tile a rider kernel
+    (gemm_adam_rect_kernel, univl_gemm_rider) and lets the host spread a layer's chunks over the products the library says carry
+    (univl_gemm_rider_fits) -- before, product and update were enqueued one after the other.  joint_b32 (32 pairs, 1536 tokens per
+    stack), deterministic mode: losses and parameters BIT-IDENTICAL to the loop whose BertAdam.step() applies the update itself."""
+    import ctypes as C
+    from univl_amd import _lib
+    ab(adam_ride="0")
+    ref_l, ref_p, _ = _train("eager", "joint_b32", steps=3, dtype=torch.bfloat16)
+    ab(adam_ride=None)
+    _probe = {}
+
+    def spy(model):
+        st = next(iter(model._steps.values()))
+        riders = [op[2] for op in st.fwd.ops if op[0] == "rider"]
+        _probe["riders"] = [(key, slot, n) for _, key, slot, n in riders]
+        _probe["fits"] = [_lib.lib().univl_gemm_rider_fits(C.byref(d)) for d, _, _, _ in riders]
+    l, p, info = _train("graph", "joint_b32", steps=3, dtype=torch.bfloat16, spy=spy)
+    assert info["mode"] == "whole"
+    assert _probe["riders"] and all(f == 1 for f in _probe["fits"]), _probe
+    by_key = {}
+    for key, slot, n in _probe["riders"]:
+        by_key.setdefault(key, []).append((slot, n))
+    cfg = case_config("joint_b32")[0]
+    assert len(by_key) == (cfg.text_num_hidden_layers - 1) + (cfg.visual_num_hidden_layers - 1)
+    for key, sl in by_key.items():                      # every layer's chunk range is covered exactly once by the launches that carry
+        assert sorted(s_ for s_, _ in sl) == list(range(sl[0][1])) and 1 <= sl[0][1] <= 4, (key, sl)
     assert l == ref_l, (l, ref_l)
     for n in ref_p:
         assert torch.equal(p[n], ref_p[n]), (n, max_abs(p[n], ref_p[n]))

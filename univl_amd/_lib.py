@@ -100,6 +100,7 @@ def lib():
     L.univl_gemm_pair.argtypes = [vp, vp, i32, vp]
     L.univl_gemm_rider.argtypes = [vp, vp, i32, i32, i32, vp]
     L.univl_gemm_rider_prime.argtypes = [vp]
+    L.univl_gemm_rider_fits.argtypes = [vp]
     L.univl_gemm_ln.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.univl_gemm_ln.restype = i32
     L.univl_gemm_pair_ln.argtypes = [vp, vp, vp, vp, i32, vp]
@@ -164,7 +165,7 @@ def set_deterministic(on=True):
 
 
 EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_device_info", "univl_init", "univl_destroy",
-            "univl_allreduce_bucket", "univl_set_deterministic", "univl_get_deterministic", "univl_gemm", "univl_gemm_group_limited", "univl_gemm_group", "univl_gemm_tile_map", "univl_gemm256_layout", "univl_gemm_pair", "univl_gemm_rider", "univl_gemm_rider_prime", "univl_gemm_ln", "univl_gemm_pair_ln",
+            "univl_allreduce_bucket", "univl_set_deterministic", "univl_get_deterministic", "univl_gemm", "univl_gemm_group_limited", "univl_gemm_group", "univl_gemm_tile_map", "univl_gemm256_layout", "univl_gemm_pair", "univl_gemm_rider", "univl_gemm_rider_fits", "univl_gemm_rider_prime", "univl_gemm_ln", "univl_gemm_pair_ln",
             "univl_layernorm_fwd", "univl_layernorm_bwd", "univl_attention_fwd", "univl_attention_bwd", "univl_attention_bwd_fused", "univl_attention_fwd_fused",
             "univl_embed_text_fwd", "univl_embed_text_bwd", "univl_embed_scatter", "univl_rows_gather_sum", "univl_rows_zero", "univl_rows_append",
             "univl_rows_sumsq", "univl_zero_many", "univl_copy_many", "univl_pool_fwd", "univl_pool_bwd", "univl_pool_pair_fwd", "univl_pool_pair_bwd",

@@ -1117,6 +1117,36 @@ __global__ __launch_bounds__(512, 2) void gemm_adam_kernel(GemmArgs g, int nd, i
     }
 }
 
+// Round 5: the same for forward products on the 64 x 128 tile (what `choose` picks from 1536 tokens on).  There univl_gemm_rider used to
+// enqueue product and update one after the other -- 57 update launches, 0.7 - 1.1 ms of serial HBM time in an MFMA-bound step at 128
+// pairs (profiles/r05_final_bench_b128_kernel_stats.csv).  Three workgroups per compute unit like gemm_kernel's instantiation of the tile.
+// Here the product has several rounds of tiles (2304 at 6144 tokens against 768 resident slots), so update workgroups BEHIND the tiles
+// would only meet the last round: they are spread through the grid instead, in groups of 8 consecutive workgroup ids (one per XCD, so
+// that a tile's id modulo 8 -- what the tile order is built on -- stays what it was): group gi is an update group iff gi % pg == pg - 1
+// and gi / pg < nrg, with nrg = update groups, pg = groups per update group.
+// true: workgroup w0 of `total` is update workgroup idx of total - nd_pad; false: it is tile idx of nd_pad (total, nd_pad multiples of 8)
+__host__ __device__ __forceinline__ bool rect_rider_role(int w0, int total, int nd_pad, int& idx) {
+    const int gi = w0 >> 3, nrg = (total - nd_pad) >> 3, pg = (total >> 3) / nrg;
+    const int k = gi / pg;
+    if (gi - k * pg == pg - 1 && k < nrg) { idx = k * 8 + (w0 & 7); return true; }
+    idx = w0 - 8 * (k < nrg ? k : nrg);
+    return false;
+}
+
+template <bool NT>
+__global__ __launch_bounds__(512, 6) void gemm_adam_rect_kernel(GemmArgs g, int nd, int nd_pad, int nx, int ny, int nz, UnivlAdam a, int c0, int c1) {
+    int t;
+    if (rect_rider_role((int)blockIdx.x, (int)gridDim.x, nd_pad, t)) {
+        const int nb = (int)gridDim.x - nd_pad;
+        for (int c = c0 + t; c < c1; c += nb) adam_chunk<NT, 512>(a, c);
+    } else {
+        if (t >= nd) return;                                   // padding workgroup
+        int bx, by, bz;
+        pair_tile(t, nd, nx, ny, nz, g.flags, g.gm, bx, by, bz);
+        gemm_tile<__bf16, false, false, 64, 128, 2, 2, 4>(g, bx, by, bz, nz);
+    }
+}
+
 // K8 / K10 (module_bert.py:207-211, 246-250: dense -> dropout -> + input -> LayerNorm): the LayerNorm that consumes a product's fp32
 // output, finished INSIDE the product's launch.  The output rows of a 64-row block are complete when all nx * nz tiles of the block
 // (column tiles x split-K slices, meeting in fp32 atomics) have added to them; every tile workgroup announces itself
@@ -1365,12 +1395,19 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int 
 // one half of gemm_pair_kernel / gemm_adam_kernel.  tests/test_host_cpu.py proves the
 // maps are bijections for every grid shape the plans produce -- a map that is not one would silently skip tiles.
 extern "C" int univl_gemm_tile_map(int32_t what, int32_t nx, int32_t ny, int32_t nz, int32_t gm, int32_t* out) {
-    UNIVL_CHECK_ARG(out != nullptr && nx > 0 && ny > 0 && nz > 0 && what >= 0 && what <= 3, UNIVL_EINVAL,
+    UNIVL_CHECK_ARG(out != nullptr && nx > 0 && ny > 0 && nz > 0 && what >= 0 && what <= 4, UNIVL_EINVAL,
                     "univl_gemm_tile_map: what=%d grid=%dx%dx%d", what, nx, ny, nz);
     int bx = out[0], by = out[1], bz = out[2];
     if (what == 0) xcd_tile_grid(nx, ny, nz, gm, bx, by, bz);
     else if (what == 1) bx = xcd_run(out[0], nx);
     else if (what == 2) tile_of(out[0], nx, ny, nz, gm, bx, by, bz);
+    else if (what == 4) {                  // gemm_adam_rect_kernel: workgroup out[0] of nx + ny (nx tile slots, ny update workgroups)
+        UNIVL_CHECK_ARG(nx % 8 == 0 && ny % 8 == 0 && ny >= 8 && out[0] < nx + ny, UNIVL_EINVAL, "univl_gemm_tile_map: what=4 needs multiples of 8");
+        int idx;
+        out[1] = rect_rider_role(out[0], nx + ny, nx, idx) ? 1 : 0;
+        out[0] = idx;
+        return UNIVL_OK;
+    }
     else pair_tile(out[0], nx * ny * nz, nx, ny, nz, UNIVL_GEMM_XCD_MAP, gm, bx, by, bz);       // a half of gemm_pair_kernel / gemm_adam_kernel
     out[0] = bx; out[1] = by; out[2] = bz;
     return UNIVL_OK;
@@ -1669,6 +1706,40 @@ static void rider_allow_lds() {
     univl_allow_lds(gemm_adam_kernel<false>, RIDER_SMEM, done_t);
 }
 
+// 0: univl_gemm_rider enqueues product and update one after the other; 1: gemm_adam_kernel (64 x 64 tile); 2: gemm_adam_rect_kernel
+static int rider_form(const UnivlGemm* gemm, const Choice& c) {
+    if (gemm->dtype != UNIVL_BF16 || gemm->trans_a || gemm->trans_b || gemm->sumsq || gemm->dbias) return 0;
+    if (c.tile == 64 && c.nc == 4) return 1;
+    if (c.tile == 64128 && c.waves == 8) return 2;
+    return 0;
+}
+
+// The tile of a riding product: what the square-tile choice says where that is the 64 x 64 tile (a few hundred tokens: the forms rounds
+// 3 / 4 measured), else what univl_gemm itself would pick (rectangular tiles allowed).
+static int rider_prepare(const UnivlGemm* gemm, GemmArgs& a, int& ks, int& form) {
+    Choice c;
+    int rc = prepare(gemm, a, ks, c);
+    if (rc != UNIVL_OK) return rc;
+    form = rider_form(gemm, c);
+    if (form == 0) {
+        rc = prepare(gemm, a, ks, c, 0, 0, true);
+        if (rc != UNIVL_OK) return rc;
+        form = rider_form(gemm, c);
+    }
+    return UNIVL_OK;
+}
+
+// Host-side question (no device work): does univl_gemm_rider carry optimizer chunks INSIDE this product's launch (1) or would it enqueue
+// the update behind it (0)?  A host distributes a layer's chunks over the products that answer 1.
+extern "C" int univl_gemm_rider_fits(const UnivlGemm* gemm) {
+    UNIVL_CHECK_ARG(gemm != nullptr, UNIVL_EINVAL, "univl_gemm_rider_fits: null descriptor");
+    GemmArgs a;
+    int ks, form;
+    const int rc = rider_prepare(gemm, a, ks, form);
+    if (rc != UNIVL_OK) return rc;
+    return form != 0 ? 1 : 0;
+}
+
 extern "C" int univl_gemm_rider(const UnivlGemm* gemm, const UnivlAdam* adam, int32_t chunk_begin, int32_t chunk_count,
                                 int32_t max_blocks, hipStream_t stream) {
     UNIVL_ON_STREAM_DEVICE(stream);
@@ -1678,20 +1749,28 @@ extern "C" int univl_gemm_rider(const UnivlGemm* gemm, const UnivlAdam* adam, in
                         chunk_begin + chunk_count <= adam->nchunk,
                     UNIVL_EINVAL, "univl_gemm_rider: chunks [%d, +%d) of %d", chunk_begin, chunk_count, adam ? adam->nchunk : 0);
     GemmArgs a;
-    int ks;
-    Choice c;
-    const int rc = prepare(gemm, a, ks, c);
+    int ks, fits;
+    const int rc = rider_prepare(gemm, a, ks, fits);
     if (rc != UNIVL_OK) return rc;
-    const bool fits = gemm->dtype == UNIVL_BF16 && !gemm->trans_a && !gemm->trans_b && c.tile == 64 && c.nc == 4 && !gemm->sumsq && !gemm->dbias;
-    if (!fits || chunk_count == 0) {          // not a product this kernel carries: the two launches one after the other (same result)
+    if (!fits || chunk_count == 0) {          // not a product these kernels carry: the two launches one after the other (same result)
         const int r1 = univl_gemm(gemm, stream);
         if (r1 != UNIVL_OK || chunk_count == 0) return r1;
         return univl_bert_adam_range(adam, chunk_begin, chunk_count, 0, max_blocks, stream);
     }
-    const int nx = (gemm->N + 63) / 64, ny = (gemm->M + 63) / 64;
+    const int nx = (gemm->N + (fits == 2 ? 127 : 63)) / (fits == 2 ? 128 : 64), ny = (gemm->M + 63) / 64;
     const int nd = nx * ny * ks, nd_pad = (nd + 7) / 8 * 8;
     const int nb = (max_blocks > 0 && max_blocks < chunk_count) ? max_blocks : chunk_count;
     const bool nt = univl_adam_nt();              // optim.hip: the one switch of the update's cache policy (UNIVL_ADAM_NT)
+    if (fits == 2) {                              // the 64 x 128 tile: 48 KB of LDS, no opt-in
+        constexpr size_t smem = 2 * (size_t)(64 + 128) * 64 * sizeof(__bf16);
+        const int nb8 = (nb + 7) / 8 * 8;         // whole groups of 8 (the kernel's interleaving); surplus workgroups find no chunk
+        if (nt) hipLaunchKernelGGL(gemm_adam_rect_kernel<true>, dim3(nd_pad + nb8), dim3(512), smem, stream, a, nd, nd_pad, nx, ny, ks, *adam,
+                                   chunk_begin, chunk_begin + chunk_count);
+        else hipLaunchKernelGGL(gemm_adam_rect_kernel<false>, dim3(nd_pad + nb8), dim3(512), smem, stream, a, nd, nd_pad, nx, ny, ks, *adam,
+                                chunk_begin, chunk_begin + chunk_count);
+        UNIVL_LAUNCH_CHECK();
+        return UNIVL_OK;
+    }
     rider_allow_lds();
     if (nt) {
         hipLaunchKernelGGL(gemm_adam_kernel<true>, dim3(nd_pad + nb), dim3(512), RIDER_SMEM, stream, a, nd, nd_pad, nx, ny, ks, *adam,

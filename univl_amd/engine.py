@@ -857,8 +857,30 @@ class EncoderStack:
             nm = self._names(l)
             plan.wait_point(("layer", self.prefix, l), sm)
             slot = [0]
+            wqkv, bqkv = fl.wop_fused(nm["qkv_w"]), fl.w32_fused(nm["qkv_b"])
+            qkv = ws["qkv"]
+            qkv_desc = _gemm_desc(dt, x16, H, wqkv, H, T, 3 * H, H, out16=qkv, ldc=3 * H, bias=bqkv)
+            o_desc = _gemm_desc(dt, ws["ctx"], H, fl.wop(nm["o_w"]), H, T, H, H, out32=ws["y1"], ldc=H,
+                                bias=fl.w32(nm["o_b"]), ksplit=self.ksplit_for(H))
+            f1_desc = _gemm_desc(dt, ws["a16"], H, fl.wop(nm["w1"]), H, T, I, H, out16=ws["f"], ldc=I,
+                                 bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd", aux_f32=self.u_f32)
+            f2_desc = _gemm_desc(dt, ws["f"], I, fl.wop(nm["w2"]), I, T, H, I, out32=ws["y2"], ldc=H,
+                                 bias=fl.w32(nm["b2"]), ksplit=self.ksplit_for(I))
+            # Which of the four products carry the chunks of layer l + 1.  Below 1536 tokens all four (the 64 x 64 rider kernel, the
+            # fused attention forward, the LayerNorm folds -- rounds 3 - 5).  From 1536 tokens on the library answers per product
+            # (univl_gemm_rider_fits: the 64 x 128 tile carries, the 128 x 128 / 256 x 256 tiles do not) and the layer's chunks are
+            # spread over those that do: a product that does not carry is followed by its share as a launch of its own -- at 128 pairs
+            # that was ALL of them, 57 update launches and 0.7 - 1.1 ms of serial HBM time in a step whose products leave HBM idle
+            # (profiles/r05_final_bench_b128_kernel_stats.csv).
+            carriers, nslots = None, 4
+            if self.adam_ride and l + 1 < self.L and T >= 1536:
+                fits = [_lib.lib().univl_gemm_rider_fits(C.byref(d)) == 1 for d in (qkv_desc, o_desc, f1_desc, f2_desc)]
+                if not any(fits):
+                    fits[2] = True               # nothing carries: the FFN1 product is followed by the whole range
+                carriers = {id(d) for d, f in zip((qkv_desc, o_desc, f1_desc, f2_desc), fits) if f}
+                nslots = len(carriers)
 
-            def gemm(desc, _l=l, _slot=slot):
+            def gemm(desc, _l=l, _slot=slot, _car=carriers, _ns=nslots):
                 """a forward product of layer l; with self.adam_ride it can carry a quarter of layer l + 1's optimizer chunks.
                 (Equal quarters: with the LayerNorm folds two of the four carrying launches end in a latency-bound tail, but giving them
                 a larger share -- or a smaller one -- changes nothing: 2.26 - 2.29 vs 2.23 / 2.27 ms, profiles/r04u_ab_rider_shares.txt.)
@@ -866,15 +888,12 @@ class EncoderStack:
                 quarter k + 1 of its own layer, so that only the first quarter of a stack's first layer is left to the launches in
                 front of the forward: bit-identical, 2.405 / 2.436 / 2.406 vs 2.422 / 2.374 / 2.408 ms per step at 4 pairs,
                 profiles/r04h_ab_ride_ahead.txt -- the bytes cost the same wherever they ride.)"""
-                if self.adam_ride and _l + 1 < self.L:
-                    plan.add_gemm_rider(desc, ("layer", self.prefix, _l + 1), _slot[0], 4, sm)
+                if self.adam_ride and _l + 1 < self.L and (_car is None or id(desc) in _car):
+                    plan.add_gemm_rider(desc, ("layer", self.prefix, _l + 1), _slot[0], _ns, sm)
                     _slot[0] += 1
                 else:
                     plan.add("univl_gemm", desc, sm)
 
-            wqkv, bqkv = fl.wop_fused(nm["qkv_w"]), fl.w32_fused(nm["qkv_b"])
-            qkv = ws["qkv"]
-            qkv_desc = _gemm_desc(dt, x16, H, wqkv, H, T, 3 * H, H, out16=qkv, ldc=3 * H, bias=bqkv)
             attn_f = ops.attention_desc(
                 dt, B, self.NH, S, S, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx"], H, ws["lse"],
                 key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev)
@@ -902,16 +921,13 @@ class EncoderStack:
                     gemm(desc)
                     ln_fwd(lnd)
 
-            gemm_ln(_gemm_desc(dt, ws["ctx"], H, fl.wop(nm["o_w"]), H, T, H, H, out32=ws["y1"], ldc=H,
-                               bias=fl.w32(nm["o_b"]), ksplit=self.ksplit_for(H)),
+            gemm_ln(o_desc,
                     ops.layernorm_desc(
                         dt, T, H, x=ws["y1"], residual=x32, gamma=fl.w32(nm["ln1_g"]), beta=fl.w32(nm["ln1_b"]), y=ws["y1"],
                         stats=ws["st1"], out32=ws["a32"], out16=ws["a16"] if self.bf else None, p_pre=p, off_pre=ws["off"][1],
                         seed_dev=self.seed_dev), 0)
-            gemm(_gemm_desc(dt, ws["a16"], H, fl.wop(nm["w1"]), H, T, I, H, out16=ws["f"], ldc=I,
-                            bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd", aux_f32=self.u_f32))
-            gemm_ln(_gemm_desc(dt, ws["f"], I, fl.wop(nm["w2"]), I, T, H, I, out32=ws["y2"], ldc=H,
-                               bias=fl.w32(nm["b2"]), ksplit=self.ksplit_for(I)),
+            gemm(f1_desc)
+            gemm_ln(f2_desc,
                     ops.layernorm_desc(
                         dt, T, H, x=ws["y2"], residual=ws["a32"], gamma=fl.w32(nm["ln2_g"]), beta=fl.w32(nm["ln2_b"]), y=ws["y2"],
                         stats=ws["st2"], out32=ws["o32"], out16=ws["o16"] if self.bf else None, p_pre=p, off_pre=ws["off"][2],
