@@ -565,6 +565,8 @@ def main():
             how="the step's GEMM launches replayed alone (each product without the optimizer chunks / LayerNorm it carries in the step), "
                 "in plan order on one stream, as a hipGraph; HIP events; includes the dependent-launch gaps between them (the "
                 "rocprofv3 kernel-trace sum under profiles/ excludes them); `as_run`: the same with the folded LayerNorms",
+            traffic_how="FETCH_SIZE / WRITE_SIZE of the family's launches in a step enqueued kernel by kernel with the optimizer update "
+                        "as launches of its own (scripts/pmc_step.py), calibrated on cast_kernel; the products carry their folded LayerNorms",
             as_run=as_run,
             adam=adam,
             step=dict(flops_per_pair=gflop_row * 1e9, achieved_tflops=round(pairs_per_s * gflop_row * 1e9 / 1e12 / world, 2),
