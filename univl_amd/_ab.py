@@ -40,6 +40,7 @@ KEYS = {
     "dpos_gather_min": (32, "rows per position from which position-table gradients are gathered instead of scatter-added"),
     # ---- optimizer / step structure
     "adam_ride": ("1", "BertAdam chunks ride with the next forward's products; '0': side-stream form; 'force': one graph even with a captured exchange"),
+    "tail_ride": (1, "chunks of cross layer 0 / decoder layer 0 ride in the last text / video layer's products; 0: launched in front of the forward"),
     "adam_lazy_rows": (1, "weight-decay-only shortcut for word-table rows that never had a gradient"),
     "adam_blocks": (0, "grid cap of the overlapped (non-riding) update"),
     "pipeline_opt": (0, "experimental pipelined optimizer"),

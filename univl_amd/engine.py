@@ -735,6 +735,7 @@ class EncoderStack:
         # is complete before anybody reads the layer.
         self.adam_ride = (getattr(flat, "adam_ride", False)
                           and flat.compute_dtype == torch.bfloat16 and prefix in ("bert", "visual", "cross"))
+        self.tail_key = None         # chunk group carried by the products of the LAST layer (build_forward)
         # UNIVL_PROBE_SKIP=<prefix> (measurement only, scripts/probe_branches.py): this stack emits NO layer kernels, forward or
         # backward -- what the step costs without one of its two encoder branches (results are meaningless)
         self.probe_skip = _ab.get("probe_skip") == prefix
@@ -873,14 +874,18 @@ class EncoderStack:
             # that was ALL of them, 57 update launches and 0.7 - 1.1 ms of serial HBM time in a step whose products leave HBM idle
             # (profiles/r05_final_bench_b128_kernel_stats.csv).
             carriers, nslots = None, 4
-            if self.adam_ride and l + 1 < self.L and T >= 1536:
+            # what the products of layer l carry: the chunks of the stack's next layer; behind its LAST layer those of `tail_key` (steps.
+            # build_step: the first layer of the stack that runs after this one -- cross encoder / decoder -- instead of a launch in front
+            # of the whole forward)
+            nkey = (("layer", self.prefix, l + 1) if l + 1 < self.L else self.tail_key) if self.adam_ride else None
+            if nkey is not None and T >= 1536:
                 fits = [_lib.lib().univl_gemm_rider_fits(C.byref(d)) == 1 for d in (qkv_desc, o_desc, f1_desc, f2_desc)]
                 if not any(fits):
                     fits[2] = True               # nothing carries: the FFN1 product is followed by the whole range
                 carriers = {id(d) for d, f in zip((qkv_desc, o_desc, f1_desc, f2_desc), fits) if f}
                 nslots = len(carriers)
 
-            def gemm(desc, _l=l, _slot=slot, _car=carriers, _ns=nslots):
+            def gemm(desc, _l=l, _slot=slot, _car=carriers, _ns=nslots, _key=nkey):
                 """a forward product of layer l; with self.adam_ride it can carry a quarter of layer l + 1's optimizer chunks.
                 (Equal quarters: with the LayerNorm folds two of the four carrying launches end in a latency-bound tail, but giving them
                 a larger share -- or a smaller one -- changes nothing: 2.26 - 2.29 vs 2.23 / 2.27 ms, profiles/r04u_ab_rider_shares.txt.)
@@ -888,8 +893,8 @@ class EncoderStack:
                 quarter k + 1 of its own layer, so that only the first quarter of a stack's first layer is left to the launches in
                 front of the forward: bit-identical, 2.405 / 2.436 / 2.406 vs 2.422 / 2.374 / 2.408 ms per step at 4 pairs,
                 profiles/r04h_ab_ride_ahead.txt -- the bytes cost the same wherever they ride.)"""
-                if self.adam_ride and _l + 1 < self.L and (_car is None or id(desc) in _car):
-                    plan.add_gemm_rider(desc, ("layer", self.prefix, _l + 1), _slot[0], _ns, sm)
+                if _key is not None and (_car is None or id(desc) in _car):
+                    plan.add_gemm_rider(desc, _key, _slot[0], _ns, sm)
                     _slot[0] += 1
                 else:
                     plan.add("univl_gemm", desc, sm)
@@ -901,7 +906,7 @@ class EncoderStack:
             # tokens): one launch less on the forward chain; the launch carries the optimizer chunks the projection's launch carried
             if (self.bf and T < 1536 and bool(_ab.get("attn_fuse_fwd")) and
                     _lib.lib().univl_attention_fwd_fused(C.byref(attn_f), C.byref(qkv_desc), None, 0, 0, 0, 1, None) == 0):
-                key = ("layer", self.prefix, l + 1) if (self.adam_ride and l + 1 < self.L) else None
+                key = nkey
                 plan.add_attn_fwd_fused(attn_f, qkv_desc, key, slot[0], 4, sm)
                 slot[0] += 1 if key is not None else 0
             else:
@@ -909,12 +914,12 @@ class EncoderStack:
                 plan.add("univl_attention_fwd", attn_f, sm)
             ln_fwd = (lambda d: None) if self.probe_no_ln in ("fwd", "both") else (lambda d: plan.add("univl_layernorm_fwd", d, sm))
 
-            def gemm_ln(desc, lnd, site, _l=l, _slot=slot):
+            def gemm_ln(desc, lnd, site, _l=l, _slot=slot, _key=nkey):
                 """a forward product and the LayerNorm behind it: one launch where the library carries the pair (ln_fold), else two"""
                 ctr = self.ln_ctr[_l, site] if self.ln_fold else None
                 if (ctr is not None and not self.probe_no_ln and
                         _lib.lib().univl_gemm_ln(C.byref(desc), C.byref(lnd), C.c_void_p(ctr.data_ptr()), None, 0, 0, 0, 1, None) == 0):
-                    key = ("layer", self.prefix, _l + 1) if (self.adam_ride and _l + 1 < self.L) else None
+                    key = _key
                     plan.add_gemm_ln(desc, lnd, ctr, key, _slot[0], 4, sm)
                     _slot[0] += 1 if key is not None else 0
                 else:

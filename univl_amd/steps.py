@@ -720,6 +720,13 @@ def build_step(model, kind, B, W, F, training):
     if cx.p > 0:
         fwd.add_callable(lambda: ops.bump_counter(cx.seed_dev))
     st.enc = enc = EncoderPass(cx, B, W, F, normalized_input=(kind == "features_shaped"))
+    # Round 5: the first layer of the cross encoder / the decoder is read after both encoder stacks; while an update rides, its chunks go
+    # with the products of the text / video stack's LAST layer (which carry nothing otherwise) instead of a launch in front of the forward
+    if _ab.get("tail_ride"):
+        if kind in ("align", "caption", "pretrain", "pretrain_nocap") and model.cross is not None:
+            enc.text.tail_key = ("layer", "cross", 0)
+        if kind in ("caption", "pretrain") and model.decoder is not None:
+            enc.vis.tail_key = ("layer", "decoder", 0)
     enc.build_forward(fwd)
     st.fwd_encoders_len = len(fwd)
     stage_two = bool(model._stage_two)
