@@ -438,7 +438,7 @@ int univl_gemm_ln(const UnivlGemm* gemm, const UnivlLayerNorm* ln, int32_t* coun
 /* The backward twin: univl_gemm_pair whose dgrad product's fp32 output is the upstream gradient of a LayerNorm backward (ln->dout ==
  * dgrad->C32, e.g. the FFN1 dgrad in front of BertSelfOutput's LayerNorm, module_bert.py:207-211 differentiated), with that LayerNorm
  * backward (dx32 / dxd16 rows, dgamma / dbeta / dbias column sums) finished inside the launch by the dgrad's last workgroups per 64-row
- * block.  Square dgrad body only (below 384 rows), N = 768, C32 pre-zeroed (the dgrad's contributions become fp32 atomics), no position
+ * block.  At most 1024 rows (the rectangular dgrad body of 384+ rows only beside a 128 x 64 weight-gradient body), N = 768, C32 pre-zeroed (the dgrad's contributions become fp32 atomics), no position
  * rows (ln->dpos NULL); counters as for univl_gemm_ln; UNIVL_EUNSUPPORTED otherwise and in deterministic mode. */
 int univl_gemm_pair_ln(const UnivlGemm* dgrad, const UnivlGemm* wgrad, const UnivlLayerNorm* ln, int32_t* counters, int32_t dry_run,
                        hipStream_t stream);

@@ -643,7 +643,9 @@ def test_gemm_ln_fold_matches_the_two_launches(M, K, ksplit, p_drop):
         univl_amd.set_deterministic(was)
 
 
-@pytest.mark.parametrize("T,K_out,ks,p_drop", [(192, 3072, 8, 0.1), (192, 2304, 6, 0.0), (100, 3072, 8, 0.1), (320, 768, 2, 0.1), (64, 2304, 6, 0.0)])
+@pytest.mark.parametrize("T,K_out,ks,p_drop", [(192, 3072, 8, 0.1), (192, 2304, 6, 0.0), (100, 3072, 8, 0.1), (320, 768, 2, 0.1), (64, 2304, 6, 0.0),
+                                               # round 5: the rectangular dgrad body (384+ tokens, slices up to 1536 deep)
+                                               (384, 3072, 2, 0.1), (512, 2304, 2, 0.0), (448, 3072, 8, 0.1), (512, 3072, 4, 0.1), (1024, 2304, 3, 0.0)])
 def test_gemm_pair_ln_fold_matches_the_two_launches(T, K_out, ks, p_drop):
     """univl_gemm_pair_ln (gemm.hip: ln_fold_bwd): the LayerNorm BACKWARD fed by a pair launch's dgrad product, finished by the dgrad's
     last workgroups per 64-row block -- dx32 / dxd16 rows and the dgamma / dbeta / dbias column sums against univl_gemm_pair +

@@ -28,7 +28,8 @@ KEYS = {
     "splitk_mid": (1, "three-slice split of the deep (K >= 2304) N = 768 products at 128 .. 255 tiles"),
     "splitk_mid_tiles": (256, "upper tile bound of that regime"),
     "ln_fold": (1, "LayerNorm forward finished inside its product's launch (univl_gemm_ln) up to 512 tokens"),
-    "ln_fold_bwd": (1, "LayerNorm backward finished inside the dgrad pair launch (univl_gemm_pair_ln) below 384 tokens"),
+    "ln_fold_bwd": (1, "LayerNorm backward finished inside the dgrad pair launch (univl_gemm_pair_ln)"),
+    "ln_fold_bwd_max": (512, "... up to this many tokens (383: round 4's range, the square pair form only)"),
     "wgrad_big_min": (0, "token count from which a layer's grouped weight gradients take the big tile (0: where every dgrad does)"),
     "attn_fuse_fwd": (1, "the q | k | v projection computed inside the attention forward launch (univl_attention_fwd_fused); 0: two launches"),
     "attn_fuse_bwd": (1, "the attention-output dgrad computed inside the attention backward launch (univl_attention_bwd_fused); 0: two launches"),

@@ -871,7 +871,7 @@ __host__ __device__ __forceinline__ void pair_tile(int t, int total, int nx, int
 //     (profiles/r04g_trace_gemm_phases.txt) the square weight-gradient tiles of the FFN1 / QKV pairs end 3 - 4 us after the dgrad
 //     chain they ride with (17.6 / 15.9 us per launch against 14.8 for the dgrad-bound FFN2 pair).
 template <bool DR, int WF, bool FOLD = false>
-__global__ __launch_bounds__(512, (DR && WF == 2) ? 6 : 4) void gemm_pair_kernel(PairArgs a, LnFold f) {      // 4 waves per SIMD = two workgroups per compute unit
+__global__ __launch_bounds__(512, (DR && WF == 2 && !FOLD) ? 6 : 4) void gemm_pair_kernel(PairArgs a, LnFold f) {      // 4 waves per SIMD = two workgroups per compute unit (the fold's LayerNorm rows need the registers)
     const int w0 = blockIdx.x;
     int bx, by, bz;
     if (w0 < a.nd_pad) {
@@ -1544,8 +1544,9 @@ static int pair_impl(const UnivlGemm* dgrad, const UnivlGemm* wgrad, const Univl
     }
     if (ln != nullptr) {
         // the LayerNorm backward whose upstream gradient this dgrad produces, finished by the dgrad's last workgroups per 64-row block
-        // (ln_fold_bwd): square dgrad body only (below 384 tokens), fp32 output over N = 768 columns, pre-zeroed (atomics)
-        UNIVL_CHECK_ARG(!univl_deterministic() && !drect && counters != nullptr && dgrad->C32 && !dgrad->C16 && dgrad->N == 768 &&
+        // (ln_fold_bwd): fp32 output over N = 768 columns, pre-zeroed (atomics); the rectangular dgrad body (384+ tokens) only together
+        // with the 128 x 64 weight-gradient body (round 5: gemm_pair_kernel<true, 2, true>, two workgroups per compute unit)
+        UNIVL_CHECK_ARG(!univl_deterministic() && (!drect || (wrect && !wone)) && counters != nullptr && dgrad->C32 && !dgrad->C16 && dgrad->N == 768 &&
                             dgrad->ldc == 768 && !(dgrad->flags & (UNIVL_GEMM_GELU_FWD | UNIVL_GEMM_GELU_BWD | UNIVL_GEMM_ACCUM)) &&
                             a.dnx * a.dnz >= LN_SHARE && a.dny <= LN_FOLD_MAX_BLOCKS && ln->dtype == UNIVL_BF16 && ln->N == 768 && ln->rows == dgrad->M &&
                             ln->dout == (const float*)dgrad->C32 && ln->gamma && ln->y && ln->stats && !ln->dpos &&
@@ -1558,6 +1559,7 @@ static int pair_impl(const UnivlGemm* dgrad, const UnivlGemm* wgrad, const Univl
         LnFold f;
         f.ln = *ln;
         f.counters = counters;
+        if (drect) return launch_pair<true, 2, true>(a, stream, &f);
         if (wrect) return wone ? launch_pair<false, 3, true>(a, stream, &f) : launch_pair<false, 2, true>(a, stream, &f);
         return wone ? launch_pair<false, 1, true>(a, stream, &f) : launch_pair<false, 0, true>(a, stream, &f);
     }

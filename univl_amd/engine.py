@@ -772,7 +772,10 @@ class EncoderStack:
         # ... and the backward twin (Plan.add_gemm_pair_ln: the LayerNorm backward behind the FFN1 / QKV dgrad, square pair form: < 384 tokens).
         # Measured (profiles/r04r_ab_ln_fold_bwd.txt, three interleaved pairs at 4 pairs): 2.231 vs 2.260 ms per step (-1.3 %; no fold at
         # all: 2.357), 288 tokens 2.656 vs 2.665, FT-Align 3.144 vs 3.184, pretrain 9.66 vs 9.75.  UNIVL_LN_FOLD_BWD=0: two launches (A/B).
-        self.ln_fold_bwd = self.ln_fold and T < 384 and bool(_ab.get("ln_fold_bwd"))
+        # Round 5: the rectangular pair form (384+ tokens) carries it too (gemm_pair_kernel<true, 2, true>), up to 512 tokens where the
+        # forward folds stop as well: 384 tokens 2.66 / 2.64 vs 2.69 / 2.68 ms per step (-1.3 %), 480 tokens 2.88 / 2.91 vs 2.93 / 2.93,
+        # caption 5.164 / 5.168 vs 5.167 / 5.218, pretrain 9.31 / 9.31 vs 9.28 / 9.25 (profiles/r05x_ab_fold_bwd_rect.txt).
+        self.ln_fold_bwd = self.ln_fold and T <= int(_ab.get("ln_fold_bwd_max")) and bool(_ab.get("ln_fold_bwd"))
         self.ln_ctr_b = torch.zeros(n_layers, 2, 2 * ((T + 63) // 64), dtype=torch.int32, device=dev) if self.ln_fold_bwd else None
         for l in range(n_layers):
             ws = dict(qkv=e(T, 3 * H, dtype=ct), lse=e(B, self.NH, S), ctx=e(T, H, dtype=ct),
