@@ -445,8 +445,7 @@ def test_deep_weight_gradients_take_the_big_tile_without_fused_bias_gradients(ab
 def test_layernorm_fold_entry_points_validate_on_the_host():
     """univl_gemm_ln / univl_gemm_pair_ln with dry_run: which (product, LayerNorm) pairs the launches carry is decided on the host from the
     two descriptors alone (no device work) -- the plans ask exactly this question at build time.  Refused: a LayerNorm that does not read
-    the product's output, other widths, a product with a bf16 output, too few tiles per row block, the rectangular pair form (>= 384
-    rows) for the backward twin.  (Deterministic mode refuses everything: covered on the GPU, test_gemm_ln_fold_* -- switching the mode
+    the product's output, other widths, a product with a bf16 output, too few tiles per row block, more than 16 row blocks.  (Deterministic mode refuses everything: covered on the GPU, test_gemm_ln_fold_* -- switching the mode
     allocates device scratch.)"""
     import ctypes as C
     import univl_amd
@@ -495,7 +494,15 @@ def test_layernorm_fold_entry_points_validate_on_the_host():
         wg2 = _gemm_desc(dt, dY2, I, X2, H, I, H, T2, trans_a=1, trans_b=1, out32=dW, ldc=H)
         lb2 = ops.layernorm_desc(dt, T2, H, gamma=gm, y=torch.zeros(T2, H), stats=torch.zeros(T2, 2), dout=da2, dx32=torch.zeros(T2, H),
                                  dxd16=torch.zeros(T2, H, dtype=bf))
-        assert L.univl_gemm_pair(C.byref(dg2), C.byref(wg2), 1, None) == 0 and bwd(dg2, wg2, lb2) == _lib.EUNSUPPORTED
+        # round 5: carried on the rectangular form too (beside the 128 x 64 weight-gradient body), up to 1024 rows
+        assert L.univl_gemm_pair(C.byref(dg2), C.byref(wg2), 1, None) == 0 and bwd(dg2, wg2, lb2) == 0
+        T3 = 1088
+        dY3, X3, da3 = torch.zeros(T3, I, dtype=bf), torch.zeros(T3, H, dtype=bf), torch.zeros(T3, H)
+        dg3 = _gemm_desc(dt, dY3, I, W1, H, T3, H, I, trans_b=1, out32=da3, ldc=H, ksplit=2)
+        wg3 = _gemm_desc(dt, dY3, I, X3, H, I, H, T3, trans_a=1, trans_b=1, out32=dW, ldc=H)
+        lb3 = ops.layernorm_desc(dt, T3, H, gamma=gm, y=torch.zeros(T3, H), stats=torch.zeros(T3, 2), dout=da3, dx32=torch.zeros(T3, H),
+                                 dxd16=torch.zeros(T3, H, dtype=bf))
+        assert L.univl_gemm_pair(C.byref(dg3), C.byref(wg3), 1, None) == 0 and bwd(dg3, wg3, lb3) == _lib.EUNSUPPORTED      # 17 row blocks
 
 
 @pytest.mark.parametrize("trans", [0, 1])
