@@ -24,7 +24,7 @@ def family(name):
     # round 5: the 256 x 256 body (gemm256_*) and the two attention launches that compute a projection inside (attn_fwd_qkv_kernel: the
     # q | k | v product; attn_bwd_odgrad_kernel: the attention-output dgrad + its riding weight gradient) belong to the family as run
     if ("gemm_group_kernel" in name or "gemm_kernel" in name or "gemm_pair_kernel" in name or "gemm_ln_kernel" in name
-            or "gemm_adam_kernel" in name or "gemm256" in name or "attn_fwd_qkv_kernel" in name or "attn_bwd_odgrad_kernel" in name):
+            or "gemm_adam_kernel" in name or "gemm_adam_rect_kernel" in name or "gemm256" in name or "attn_fwd_qkv_kernel" in name or "attn_bwd_odgrad_kernel" in name):
         return "gemm"
     if "adam_apply" in name:
         return "adam"

@@ -12,7 +12,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libunivl_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-         "-Wno-unused-result", "-ffast-math" if os.environ.get("UNIVL_FAST_MATH") else "-fno-fast-math"]
+         "-Wno-unused-result", "-fno-fast-math"]
 
 
 def _stale(out, deps):
