@@ -311,6 +311,9 @@ def test_adam_rider_slots_from_1536_tokens_follow_the_library(ab):
         by_key = {}
         for _, key, slot, n in riders:
             by_key.setdefault(key, []).append((slot, n))
+        for op in st.fwd.ops:        # at 1536 tokens the fused attention forward still runs and carries its share (slot 0)
+            if op[0] == "attn_fwd_fused" and op[2][2] is not None:
+                by_key.setdefault(op[2][2], []).append((op[2][3], op[2][4]))
         assert set(by_key) == {("layer", "bert", l) for l in range(1, cfg.text_num_hidden_layers)}      # (one video layer: nothing to carry)
         for key, sl in by_key.items():
             assert sorted(s_ for s_, _ in sl) == list(range(sl[0][1])), (B, key, sl)

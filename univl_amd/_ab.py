@@ -33,6 +33,8 @@ KEYS = {
     "wgrad_big_min": (0, "token count from which a layer's grouped weight gradients take the big tile (0: where every dgrad does)"),
     "attn_fuse_fwd": (1, "the q | k | v projection computed inside the attention forward launch (univl_attention_fwd_fused); 0: two launches"),
     "attn_fuse_bwd": (1, "the attention-output dgrad computed inside the attention backward launch (univl_attention_bwd_fused); 0: two launches"),
+    "attn_fuse_fwd_max_rows": (1536, "token count up to which the fused attention FORWARD launch is used (1536: -1.9 %, 3072: +0.7 %, profiles/r05ae)"),
+    "attn_fuse_bwd_max_rows": (1535, "token count up to which the fused attention BACKWARD launch is used (1536: +1 %, 6144: +4.9 %)"),
     "g256": (1, "256 x 256 8-phase body (csrc/gemm256.h) for the grouped weight gradients / single products it is picked for; 0: the older tiles"),
     "g256_min_rows": (1536, "token count (a multiple of 256) from which the plans drop the pair launches for separate dgrads + the grouped 256-body launch"),
     "gelu_pre_f32": (0, "A/B measurement: the FFN1 pre-activation saved for GELU' in fp32 instead of the compute type (encoder stacks)"),

@@ -870,6 +870,9 @@ class EncoderStack:
                                  bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd", aux_f32=self.u_f32)
             f2_desc = _gemm_desc(dt, ws["f"], I, fl.wop(nm["w2"]), I, T, H, I, out32=ws["y2"], ldc=H,
                                  bias=fl.w32(nm["b2"]), ksplit=self.ksplit_for(I))
+            attn_f = ops.attention_desc(
+                dt, B, self.NH, S, S, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx"], H, ws["lse"],
+                key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev)
             # Which of the four products carry the chunks of layer l + 1.  Below 1536 tokens all four (the 64 x 64 rider kernel, the
             # fused attention forward, the LayerNorm folds -- rounds 3 - 5).  From 1536 tokens on the library answers per product
             # (univl_gemm_rider_fits: the 64 x 128 tile carries, the 128 x 128 / 256 x 256 tiles do not) and the layer's chunks are
@@ -877,12 +880,15 @@ class EncoderStack:
             # that was ALL of them, 57 update launches and 0.7 - 1.1 ms of serial HBM time in a step whose products leave HBM idle
             # (profiles/r05_final_bench_b128_kernel_stats.csv).
             carriers, nslots = None, 4
+            fused_fwd = (self.bf and T <= int(_ab.get("attn_fuse_fwd_max_rows")) and bool(_ab.get("attn_fuse_fwd")) and
+                         _lib.lib().univl_attention_fwd_fused(C.byref(attn_f), C.byref(qkv_desc), None, 0, 0, 0, 1, None) == 0)
             # what the products of layer l carry: the chunks of the stack's next layer; behind its LAST layer those of `tail_key` (steps.
             # build_step: the first layer of the stack that runs after this one -- cross encoder / decoder -- instead of a launch in front
             # of the whole forward)
             nkey = (("layer", self.prefix, l + 1) if l + 1 < self.L else self.tail_key) if self.adam_ride else None
             if nkey is not None and T >= 1536:
                 fits = [_lib.lib().univl_gemm_rider_fits(C.byref(d)) == 1 for d in (qkv_desc, o_desc, f1_desc, f2_desc)]
+                fits[0] = fits[0] or fused_fwd           # the fused attention forward carries chunks whatever tile the projection would take
                 if not any(fits):
                     fits[2] = True               # nothing carries: the FFN1 product is followed by the whole range
                 carriers = {id(d) for d, f in zip((qkv_desc, o_desc, f1_desc, f2_desc), fits) if f}
@@ -902,15 +908,11 @@ class EncoderStack:
                 else:
                     plan.add("univl_gemm", desc, sm)
 
-            attn_f = ops.attention_desc(
-                dt, B, self.NH, S, S, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx"], H, ws["lse"],
-                key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev)
-            # Round 5: the q | k | v projection computed INSIDE the attention forward (sequences of at most 64 positions, below 1536
+            # Round 5: the q | k | v projection computed INSIDE the attention forward (sequences of at most 64 positions, up to 1536
             # tokens): one launch less on the forward chain; the launch carries the optimizer chunks the projection's launch carried
-            if (self.bf and T < 1536 and bool(_ab.get("attn_fuse_fwd")) and
-                    _lib.lib().univl_attention_fwd_fused(C.byref(attn_f), C.byref(qkv_desc), None, 0, 0, 0, 1, None) == 0):
+            if fused_fwd:
                 key = nkey
-                plan.add_attn_fwd_fused(attn_f, qkv_desc, key, slot[0], 4, sm)
+                plan.add_attn_fwd_fused(attn_f, qkv_desc, key, slot[0], nslots, sm)
                 slot[0] += 1 if key is not None else 0
             else:
                 gemm(qkv_desc)
@@ -1053,7 +1055,7 @@ class EncoderStack:
             # (below 1536 tokens: at 6144 every one of the 3072 role workgroups walks a K loop of its own in front of the attention body --
             #  11.87 vs 11.32 ms per step at 128 pairs; 2.26 vs 2.31 at 4 pairs, 3.37 vs 3.43 at 16: profiles/r05p_ab_attn_fuse_bwd.txt)
             w_ride = w_o if self.ride else None
-            if (self.bf and T < 1536 and bool(_ab.get("attn_fuse_bwd")) and
+            if (self.bf and T <= int(_ab.get("attn_fuse_bwd_max_rows")) and bool(_ab.get("attn_fuse_bwd")) and
                     _lib.lib().univl_attention_bwd_fused(C.byref(attn_b), C.byref(o_dgrad), C.byref(w_ride) if w_ride is not None else None, 1, None) == 0):
                 plan.add_attn_bwd_fused(attn_b, o_dgrad, w_ride, sm)
                 if w_ride is None:
