@@ -119,12 +119,27 @@ def make_optimizer(model, BertAdam, lr=3e-5, coef_lr=0.1):
 
 
 def cpu_baseline(batch_rows, budget_s=20.0):
-    """The oracle's training step (oracle/cpu_step.py: forward, backward, clip, BertAdam -- a CPU port of the reference's
-    loop body) on the host cores of this box.  /root/reference does not exist here; tests/golden/cpu_port_ratio.json holds
-    the port/reference time ratio measured in the build container, where both run side by side."""
+    """The CPU leg, on the host cores of this box.  Where the reference exists (UNIVL_REFERENCE_ROOT, default /root/reference: the
+    build container, or a box a maintainer copied microsoft/UniVL to) the REAL reference loop is timed -- modules.modeling.UniVL +
+    modules.optimization.BertAdam through oracle/time_reference.py, `kind: "reference"`.  Otherwise (the GPU boxes of this pool have
+    no reference) the oracle's training step (oracle/cpu_step.py: forward, backward, clip, BertAdam -- a CPU port of the reference's
+    loop body), `kind: "port"`, with the port/reference time ratio measured in the build container where both run side by side
+    (tests/golden/cpu_port_ratio.json)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import cpu_step
-    step = cpu_step.make_step(batch_rows)
+    import _ref_harness
+    kind, why_port = "port", None
+    if _ref_harness.reference_available():
+        try:
+            import time_reference
+            step = time_reference.reference_step_fn(batch_rows)
+            kind = "reference"
+        except Exception as ex:      # noqa: BLE001 -- a reference checkout that does not import here: say so, time the port
+            why_port = "reference at %s did not load (%s: %s)" % (_ref_harness.REFERENCE_ROOT, type(ex).__name__, str(ex)[:160])
+    else:
+        why_port = "no reference checkout at %s on this box (UNIVL_REFERENCE_ROOT)" % _ref_harness.REFERENCE_ROOT
+    if kind == "port":
+        import cpu_step
+        step = cpu_step.make_step(batch_rows)
     # pick the OpenMP thread count that runs the step fastest on this host (more threads than ~64 hurt at bs=4:
     # the GEMMs are [192,768]x[768,3072]); every candidate costs one step
     host = os.cpu_count()
@@ -153,17 +168,21 @@ def cpu_baseline(batch_rows, budget_s=20.0):
         phys = psutil.cpu_count(logical=False)
     except Exception:   # noqa: BLE001
         phys = None
-    out = dict(value=round(batch_rows / med, 3), unit="pairs/s", cores=best, host_logical_cpus=host, host_physical_cores=phys, kind="port",
+    what = ("microsoft/UniVL itself (modules.modeling.UniVL + modules.optimization.BertAdam imported from %s)" % _ref_harness.REFERENCE_ROOT
+            if kind == "reference" else "oracle/cpu_step.py (CPU port of the reference's loop body)")
+    out = dict(value=round(batch_rows / med, 3), unit="pairs/s", cores=best, host_logical_cpus=host, host_physical_cores=phys, kind=kind,
                sample="%d full training steps (fwd+bwd+clip+BertAdam, bs=%d, 48x48, 12+6 layers, fp32, dropout 0.1) "
-                      "of oracle/cpu_step.py on %d OpenMP threads (best of 8/16/32/64; host has %d logical CPUs), "
-                      "median step %.3f s" % (len(times), batch_rows, best, host, med))
-    ratio = os.path.join(ROOT, "tests", "golden", "cpu_port_ratio.json")
-    if os.path.exists(ratio):
-        r = json.load(open(ratio))
-        out["port_over_reference_time"] = r["port_over_reference_time"]
-        out["reference_equivalent"] = round(out["value"] * r["port_over_reference_time"], 3)
-        out["ratio_source"] = "tests/golden/cpu_port_ratio.json: real reference %.3f s/step vs port %.3f s/step on %d threads " \
-                              "in the build container" % (r["reference_s_per_step"], r["port_s_per_step"], r["threads"])
+                      "of %s on %d OpenMP threads (best of 8/16/32/64; host has %d logical CPUs), "
+                      "median step %.3f s" % (len(times), batch_rows, what, best, host, med))
+    if kind == "port":
+        out["why_port"] = why_port
+        ratio = os.path.join(ROOT, "tests", "golden", "cpu_port_ratio.json")
+        if os.path.exists(ratio):
+            r = json.load(open(ratio))
+            out["port_over_reference_time"] = r["port_over_reference_time"]
+            out["reference_equivalent"] = round(out["value"] * r["port_over_reference_time"], 3)
+            out["ratio_source"] = "tests/golden/cpu_port_ratio.json: real reference %.3f s/step vs port %.3f s/step on %d threads " \
+                                  "in the build container" % (r["reference_s_per_step"], r["port_s_per_step"], r["threads"])
     return out
 
 
@@ -339,139 +358,151 @@ def main():
     used = set(model.used_parameter_names(model.step_kind(args.kind in ("caption", "pretrain"))))      # parameters that receive a gradient
     n_params = sum(p.numel() for n, p in model.named_parameters() if n in used)
 
-    B, (W, F, _, gflop_row) = args.batch, KINDS[args.kind]
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    ids = torch.randint(1000, 30522, (B, 1, W), generator=g)
-    ids[..., 0] = 101
-    host_inputs = dict(input_ids=ids, token_type_ids=torch.zeros(B, 1, W, dtype=torch.int64),
-                       attention_mask=torch.ones(B, 1, W, dtype=torch.int64),
-                       video=torch.randn(B, 1, F, 1024, generator=g, dtype=torch.float64),
-                       video_mask=torch.ones(B, 1, F, dtype=torch.int64))
-    if args.kind == "pretrain":      # masked-token / masked-frame labels (15 %), as the pretrain loader builds them
-        host_inputs["pairs_token_labels"] = torch.where(torch.rand(B, 1, W, generator=g) < 0.15, ids, torch.full_like(ids, -1))
-        host_inputs["video_labels_index"] = torch.where(torch.rand(B, 1, F, generator=g) < 0.15, torch.zeros(B, 1, F, dtype=torch.int64),
-                                                        torch.full((B, 1, F), -1, dtype=torch.int64))
-    if args.kind in ("caption", "pretrain"):
-        cap = torch.randint(1000, 30522, (B, 1, W), generator=g)
-        host_inputs.update(input_caption_ids=cap, decoder_mask=torch.ones_like(cap), output_caption_ids=cap.clone())
-    inputs = {k: v.to(dev) for k, v in host_inputs.items()}
+    W, F, _, gflop_row = KINDS[args.kind]
     params = list(model.parameters())
+    import types
 
-    def call_args(src):
-        kw = dict(pairs_masked_text=src["input_ids"], pairs_token_labels=src.get("pairs_token_labels"), masked_video=src["video"],
-                  video_labels_index=src.get("video_labels_index"))
-        if "input_caption_ids" in src:
-            kw.update(input_caption_ids=src["input_caption_ids"], decoder_mask=src["decoder_mask"], output_caption_ids=src["output_caption_ids"])
-        return ((src["input_ids"], src["token_type_ids"], src["attention_mask"], src["video"], src["video_mask"]), kw)
+    def build_runner(B):
+        """Everything that depends on the per-GPU batch: synthetic inputs resident in HBM (+ their pageable host twins), the eager loop
+        body, the captured step, and the timing helpers.  The headline uses one runner; at N > 1 a second one (cfg3's share of the
+        global batch of 128) is measured in the same N-rank run."""
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        ids = torch.randint(1000, 30522, (B, 1, W), generator=g)
+        ids[..., 0] = 101
+        host_inputs = dict(input_ids=ids, token_type_ids=torch.zeros(B, 1, W, dtype=torch.int64),
+                           attention_mask=torch.ones(B, 1, W, dtype=torch.int64),
+                           video=torch.randn(B, 1, F, 1024, generator=g, dtype=torch.float64),
+                           video_mask=torch.ones(B, 1, F, dtype=torch.int64))
+        if args.kind == "pretrain":      # masked-token / masked-frame labels (15 %), as the pretrain loader builds them
+            host_inputs["pairs_token_labels"] = torch.where(torch.rand(B, 1, W, generator=g) < 0.15, ids, torch.full_like(ids, -1))
+            host_inputs["video_labels_index"] = torch.where(torch.rand(B, 1, F, generator=g) < 0.15, torch.zeros(B, 1, F, dtype=torch.int64),
+                                                            torch.full((B, 1, F), -1, dtype=torch.int64))
+        if args.kind in ("caption", "pretrain"):
+            cap = torch.randint(1000, 30522, (B, 1, W), generator=g)
+            host_inputs.update(input_caption_ids=cap, decoder_mask=torch.ones_like(cap), output_caption_ids=cap.clone())
+        inputs = {k: v.to(dev) for k, v in host_inputs.items()}
 
-    def step_body():
-        a, kw = call_args(inputs)
-        loss = model(*a, **kw)
-        loss.backward()
-        clip_grad_norm_(params, 1.0)
-        opt.step()
-        opt.zero_grad()
-        return loss
+        def call_args(src):
+            kw = dict(pairs_masked_text=src["input_ids"], pairs_token_labels=src.get("pairs_token_labels"), masked_video=src["video"],
+                      video_labels_index=src.get("video_labels_index"))
+            if "input_caption_ids" in src:
+                kw.update(input_caption_ids=src["input_caption_ids"], decoder_mask=src["decoder_mask"], output_caption_ids=src["output_caption_ids"])
+            return ((src["input_ids"], src["token_type_ids"], src["attention_mask"], src["video"], src["video_mask"]), kw)
 
-    # eager warm-up (builds plans / tables), then hipGraph replay of the whole step (univl_amd.graphed): one graph on a
-    # single GPU; with a gradient exchange the collectives stay on the host between captured segments
-    for _ in range(3):
-        float(step_body())
-    torch.cuda.synchronize()
-    gstep, mode = None, ("per-plan graphs (UniVL._run_plan)" if model.auto_graph else "eager")
-    if not args.no_graph:
-        from univl_amd.graphed import GraphedTrainStep
-        # one process, bf16: the BertAdam update of iteration t rides with the forward of iteration t + 1 (default; --no-pipeline)
-        # ... and, with a captured gradient exchange, as two graphs (forward with riders | backward with collectives + clip)
-        pipe = args.pipeline or (not args.no_pipeline and args.dtype == "bf16" and not args.shard_optimizer
-                                 and (model._reducer is None or model._reducer.capturable))
-        gstep = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=0, pipeline_optimizer=pipe,
-                                 persistent_inputs=True)     # the bench contract: the batch is resident in HBM, refilled in place
-        ok = 1
-        try:
+        def step_body():
             a, kw = call_args(inputs)
-            float(gstep(*a, **kw))
-            torch.cuda.synchronize()
-        except Exception as ex:      # noqa: BLE001
-            print("[bench] rank %d: hipGraph capture failed (%s: %s); running eagerly" % (rank, type(ex).__name__, ex),
-                  file=sys.stderr)
-            ok = 0
-        if dist is not None:         # every rank must take the same path
-            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag)
-        if ok:
-            mode = "hipGraph"
-        else:
-            gstep = None
-            model.graph_backward = False
-            torch.cuda.synchronize()
+            loss = model(*a, **kw)
+            loss.backward()
+            clip_grad_norm_(params, 1.0)
+            opt.step()
+            opt.zero_grad()
+            return loss
 
-    def one_step(src):
-        a, kw = call_args(src)
-        if gstep is not None:
-            return float(gstep(*a, **kw))     # D2H sync every step, as main_task_retrieval.py:344
-        if src is not inputs:
-            for k in inputs:
-                inputs[k].copy_(src[k], non_blocking=True)
-        return float(step_body())
-
-    def timed(src, steps, warmup):
-        last = None
-        for _ in range(warmup):
-            last = one_step(src)
-        if dist is not None:
-            dist.barrier()
+        # eager warm-up (builds plans / tables), then hipGraph replay of the whole step (univl_amd.graphed): one graph on a
+        # single GPU; with a gradient exchange the collectives stay on the host between captured segments
+        for _ in range(3):
+            float(step_body())
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            last = one_step(src)
-        if gstep is not None:
-            gstep.flush()            # a riding optimizer update is still pending: it belongs to the timed steps (conservative: the region
-                                     # then holds steps + 1 updates, the first one left over by the warm-up)
-        else:
-            opt.flush()              # the unchanged loop (--no-graph): BertAdam.step() left its update to the next forward, same accounting
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        el = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t)
-        return el, last
+        gstep, mode = None, ("per-plan graphs (UniVL._run_plan)" if model.auto_graph else "eager")
+        if not args.no_graph:
+            from univl_amd.graphed import GraphedTrainStep
+            # one process, bf16: the BertAdam update of iteration t rides with the forward of iteration t + 1 (default; --no-pipeline)
+            # ... and, with a captured gradient exchange, as two graphs (forward with riders | backward with collectives + clip)
+            pipe = args.pipeline or (not args.no_pipeline and args.dtype == "bf16" and not args.shard_optimizer
+                                     and (model._reducer is None or model._reducer.capturable))
+            gstep = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=0, pipeline_optimizer=pipe,
+                                     persistent_inputs=True)     # the bench contract: the batch is resident in HBM, refilled in place
+            ok = 1
+            try:
+                a, kw = call_args(inputs)
+                float(gstep(*a, **kw))
+                torch.cuda.synchronize()
+            except Exception as ex:      # noqa: BLE001
+                print("[bench] rank %d: hipGraph capture failed (%s: %s); running eagerly" % (rank, type(ex).__name__, ex),
+                      file=sys.stderr)
+                ok = 0
+            if dist is not None:         # every rank must take the same path
+                flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag)
+            if ok:
+                mode = "hipGraph"
+            else:
+                gstep = None
+                model.graph_backward = False
+                torch.cuda.synchronize()
 
-    def preheat(src, block, tol=0.01, need=3):
-        """DECLARED, UNTIMED pre-heat in front of the timed steps.  Measured at the driver in round 3 (BENCH_r03.json): the first 25
-        replays after the ~25 s CPU leg + 3 eager steps + capture ran 9 % slower than every later block of the same graph (2.72 ms vs
-        2.49-2.51; the PCIe-inclusive block that followed was FASTER than the headline) -- clock / power ramp of a GPU that sat idle,
-        first touch of the graph's memory pool.  So: replay blocks of `block` steps until `need` consecutive blocks agree within `tol`
-        (or --preheat-max-s is spent), report every block's ms/step, and only then run the W untimed + K timed steps of the contract."""
-        blocks, t_begin = [], time.perf_counter()
-        stable = False
-        while True:
+        def one_step(src):
+            a, kw = call_args(src)
+            if gstep is not None:
+                return float(gstep(*a, **kw))     # D2H sync every step, as main_task_retrieval.py:344
+            if src is not inputs:
+                for k in inputs:
+                    inputs[k].copy_(src[k], non_blocking=True)
+            return float(step_body())
+
+        def timed(src, steps, warmup):
+            last = None
+            for _ in range(warmup):
+                last = one_step(src)
             if dist is not None:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(block):
-                one_step(src)
+            for _ in range(steps):
+                last = one_step(src)
+            if gstep is not None:
+                gstep.flush()            # a riding optimizer update is still pending: it belongs to the timed steps (conservative: the region
+                                         # then holds steps + 1 updates, the first one left over by the warm-up)
+            else:
+                opt.flush()              # the unchanged loop (--no-graph): BertAdam.step() left its update to the next forward, same accounting
             torch.cuda.synchronize()
-            blocks.append((time.perf_counter() - t0) / block * 1e3)
-            last_n = blocks[-need:]
-            stable = len(last_n) == need and max(last_n) <= min(last_n) * (1.0 + tol)
-            spent = time.perf_counter() - t_begin
-            if dist is not None:       # every rank must leave the loop in the same iteration
-                f = torch.tensor([1 if (stable or spent > args.preheat_max_s) else 0], device=dev, dtype=torch.int32)
-                dist.all_reduce(f, op=dist.ReduceOp.MAX)
-                if int(f):
-                    break
-            elif stable or spent > args.preheat_max_s:
-                break
-        return dict(seconds=round(time.perf_counter() - t_begin, 3), block_steps=block, block_ms=[round(b, 4) for b in blocks],
-                    stable=bool(stable), rule="blocks of %d untimed steps until %d consecutive blocks agree within %.0f %% (cap %.0f s)"
-                                              % (block, need, tol * 100, args.preheat_max_s))
+            if dist is not None:
+                dist.barrier()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t)
+            return el, last
 
+        def preheat(src, block, tol=0.01, need=3):
+            """DECLARED, UNTIMED pre-heat in front of the timed steps.  Measured at the driver in round 3 (BENCH_r03.json): the first 25
+            replays after the ~25 s CPU leg + 3 eager steps + capture ran 9 % slower than every later block of the same graph (2.72 ms vs
+            2.49-2.51; the PCIe-inclusive block that followed was FASTER than the headline) -- clock / power ramp of a GPU that sat idle,
+            first touch of the graph's memory pool.  So: replay blocks of `block` steps until `need` consecutive blocks agree within `tol`
+            (or --preheat-max-s is spent), report every block's ms/step, and only then run the W untimed + K timed steps of the contract."""
+            blocks, t_begin = [], time.perf_counter()
+            stable = False
+            while True:
+                if dist is not None:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(block):
+                    one_step(src)
+                torch.cuda.synchronize()
+                blocks.append((time.perf_counter() - t0) / block * 1e3)
+                last_n = blocks[-need:]
+                stable = len(last_n) == need and max(last_n) <= min(last_n) * (1.0 + tol)
+                spent = time.perf_counter() - t_begin
+                if dist is not None:       # every rank must leave the loop in the same iteration
+                    f = torch.tensor([1 if (stable or spent > args.preheat_max_s) else 0], device=dev, dtype=torch.int32)
+                    dist.all_reduce(f, op=dist.ReduceOp.MAX)
+                    if int(f):
+                        break
+                elif stable or spent > args.preheat_max_s:
+                    break
+            return dict(seconds=round(time.perf_counter() - t_begin, 3), block_steps=block, block_ms=[round(b, 4) for b in blocks],
+                        stable=bool(stable), rule="blocks of %d untimed steps until %d consecutive blocks agree within %.0f %% (cap %.0f s)"
+                                                  % (block, need, tol * 100, args.preheat_max_s))
+
+        return types.SimpleNamespace(B=B, inputs=inputs, host_inputs=host_inputs, call_args=call_args, step_body=step_body, gstep=gstep, mode=mode,
+                                     one_step=one_step, timed=timed, preheat=preheat)
+
+    R = build_runner(args.batch)
+    inputs, host_inputs, call_args, step_body, gstep, mode, timed, preheat = (R.inputs, R.host_inputs, R.call_args, R.step_body, R.gstep, R.mode,
+                                                                              R.timed, R.preheat)
     main_src = host_inputs if args.host_inputs else inputs
     pre = None if args.no_preheat else preheat(main_src, max(5, min(args.steps, 50)))
     elapsed, last = timed(main_src, args.steps, args.warmup)

@@ -406,6 +406,58 @@ def test_gemm256_epilogues_split_k_and_fallbacks():
             assert torch.equal(o1, o2)
 
 
+def test_gemm256_gelu_and_gelu_grad_against_exact_erf_over_every_bf16_input():
+    """gemm256.h evaluates erf by a branch-free Abramowitz-Stegun 7.1.26 form (__expf, rcp) instead of erff, so GELU / GELU'
+    depend on which tile a shape selects.  Pin that form directly: the 256 body's GELU epilogues on EVERY bf16 pre-activation with
+    |x| <= 8 (33 282 values, an identity product puts them into the accumulators exactly), and on fp32 pre-activations (the same grid plus
+    an fp32 bias), against the exact erf in fp64 -- the bf16 result must be the correctly rounded one up to ONE bf16 ulp on a small
+    fraction of inputs (an absolute error of the erf form <= 1.5e-7 can only move a result across a rounding boundary)."""
+    dtype = torch.bfloat16
+    M = N = K = 256
+    pos = torch.arange(0, 0x4100 + 1, dtype=torch.int32)                              # +0 .. 8.0 as bf16 bit patterns
+    bits = torch.cat([pos, pos | 0x8000]).to(torch.int16)
+    grid = torch.zeros(M * N, dtype=torch.int16)
+    grid[:bits.numel()] = bits
+    G = grid.view(torch.bfloat16).view(N, M).to(DEV)                                  # W[n, m]
+    X = torch.eye(M, K, dtype=torch.float32).to(DEV, dtype)
+    sqrt2 = math.sqrt(2.0)
+
+    def exact(u):
+        u = u.double().cpu()
+        return u * 0.5 * (1.0 + torch.erf(u / sqrt2)), 0.5 * (1.0 + torch.erf(u / sqrt2)) + u * torch.exp(-0.5 * u * u) / math.sqrt(2.0 * math.pi)
+
+    def ulps_off(out, ref64):
+        want = ref64.to(torch.float32).to(torch.bfloat16)
+        a = out.cpu().view(torch.int16).to(torch.int32)
+        b = want.view(torch.int16).to(torch.int32)
+        a = torch.where(a < 0, -(a & 0x7fff), a)                                       # sign-magnitude -> ordered integers
+        b = torch.where(b < 0, -(b & 0x7fff), b)
+        return (a - b).abs()
+
+    for bias in (None, (torch.rand(N, generator=torch.Generator().manual_seed(5)) * 2 - 1).to(DEV)):
+        f = torch.empty(M, N, device=DEV, dtype=dtype)
+        u = torch.empty(M, N, device=DEV, dtype=dtype)
+        ops.gemm(X, G, M, N, K, out16=f, aux=u, bias=bias, gelu="fwd", tile=256)
+        pre = G.float().T + (bias if bias is not None else 0.0)                       # pre[m, n] = W[n, m] (+ bias[n]): exact in fp32
+        gel, _ = exact(pre)
+        d = ulps_off(f, gel)
+        # results below 2^-100 are denormal territory of the tiny inputs: flushed or not, they are zero to any gate
+        big = gel.abs() > 2.0 ** -100
+        assert int(d[big].max()) <= 1, int(d[big].max())
+        assert float((d[big] > 0).float().mean()) < 5e-3
+        assert torch.equal(u.float().cpu(), pre.to(torch.bfloat16).float().cpu())     # the saved pre-activation: correctly rounded
+        # GELU' of the SAVED (bf16) pre-activation times an upstream gradient of exactly 1
+        W2 = torch.ones(K, N, dtype=torch.float32).to(DEV, dtype)                     # one-hot rows of dY against an all-ones W2: every product 1
+        dY = torch.zeros(M, K, device=DEV, dtype=dtype)
+        dY[:, 0] = 1.0
+        du = torch.empty(M, N, device=DEV, dtype=dtype)
+        ops.gemm(dY, W2, M, N, K, trans_b=True, out16=du, aux=u, gelu="bwd", tile=256)
+        _, gp = exact(u.float())
+        d = ulps_off(du, gp)
+        assert int(d.max()) <= 1, int(d.max())
+        assert float((d > 0).float().mean()) < 5e-3
+
+
 @pytest.mark.parametrize("T", [1536, 6144])
 def test_gemm256_weight_gradient_group_with_bias_gradients_and_norms(T):
     """A layer's four weight gradients as ONE grouped launch on the 256 tile (what the backward plan issues at thousands of tokens):

@@ -41,12 +41,14 @@ GATES = {
                         gp95=1e-3, gglobal=1e-3, gcos=1e-5),
     # round 4: tightened to ~1.3 x the worst measured value of the cases that use them (cfg1-3, cfg4): gnorm 3.2e-3, gtop 1.3e-2,
     # gmedian 1.0e-2, gp95 1.5e-2, gglobal 1.2e-2, gcos 7.1e-5 -- and see check_against_reference_bf16 for the yardstick.
-    # round 5: gnorm 6e-3 -> 8.5e-3: the worst per-tensor norm error of joint_b128 measures 6.6e-3 with the grouped weight gradients on the
-    # 256 x 256 body (32x32x16 MFMA chunks: another fp32 summation order over 6144 tokens; 4.6e-3 on the 128 tile) -- 0.47 x the
-    # reference's own bf16 autocast run on that case (1.41e-2, tests/golden/bf16_autocast_noise.json), which stays the binding gate
-    torch.bfloat16: dict(hidden=5e-2, sim=1e-2, logits=1e-2, loss=1e-2, gnorm=8.5e-3, gsample=4e-2, gtop=2e-2, gmedian=1.5e-2,
+    # round 6: gnorm is back at 6e-3 for every case; the one case whose grouped weight gradients sum 6144 tokens on the
+    # 256 x 256 body (32x32x16 MFMA chunks: another fp32 summation order) has its own entry in BF16_CASE_GATES below
+    torch.bfloat16: dict(hidden=5e-2, sim=1e-2, logits=1e-2, loss=1e-2, gnorm=6e-3, gsample=4e-2, gtop=2e-2, gmedian=1.5e-2,
                          gp95=2e-2, gglobal=1.3e-2, gcos=1.5e-4),
 }
+# per-case bf16 gates: joint_b128 measures gnorm 6.6e-3 with the 256 body (4.6e-3 on the 128 tile), 0.47 x the reference's own bf16
+# autocast run on that case (1.41e-2, tests/golden/bf16_autocast_noise.json) -- which stays the binding gate
+BF16_CASE_GATES = {"joint_b128": dict(gnorm=8.5e-3)}
 # Branch-specific bf16 GRADIENT gates.
 #  * caption: the 30522-way softmax gradient through the tied table leaves a few small tensors at 3e-2 (measured 3.0-3.4e-2).
 #  * align / pretrain THROUGH THE LOSS: the hinge / CrossEn over B x B nearly equal cross-encoder scores makes the gradient a
@@ -75,6 +77,8 @@ def gates_for(name, dtype):
     branch = name.split("_")[0]
     if dtype == torch.bfloat16 and branch in BF16_GRAD_GATES:
         g.update(BF16_GRAD_GATES[branch])
+    if dtype == torch.bfloat16 and name in BF16_CASE_GATES:
+        g.update(BF16_CASE_GATES[name])
     return g
 
 
@@ -745,14 +749,13 @@ def test_unchanged_training_loop_switches_to_graph_replay(dtype):
         model, P = build(cfg, dtype)
         model.auto_graph, model.auto_ride = auto_graph, ride
         model.train()
-        params = list(model.parameters())
-        opt = BertAdam(params, lr=1e-4, warmup=-1, t_total=-1, weight_decay=0.01, max_grad_norm=1.0)
+        opt = BertAdam(model.parameters(), lr=1e-4, warmup=-1, t_total=-1, weight_decay=0.01, max_grad_norm=1.0)
         batch = O.synthetic_batch(cfg, rows, seed=dseed)
         losses = []
         for _ in range(7):
             loss = call(model, batch)
             loss.backward()
-            clip_grad_norm_(params, 1.0)
+            clip_grad_norm_(model.parameters(), 1.0)     # the reference's own call (main_task_retrieval.py:347): in-loop parameters()
             opt.step()
             opt.zero_grad()
             losses.append(float(loss))
@@ -773,6 +776,127 @@ def test_unchanged_training_loop_switches_to_graph_replay(dtype):
     else:
         assert not pend and rides == 0             # fp32 compute: the update is applied by step() itself
         np.testing.assert_allclose(l_graph, l_eager, rtol=2e-4, atol=2e-5)
+
+
+def _loop_model(dtype=torch.bfloat16, lr=1e-3):
+    cfg, rows, dseed = case_config("joint_small")
+    model, P = build(cfg, dtype)
+    model.train()
+    opt = BertAdam(model.parameters(), lr=lr, warmup=-1, t_total=-1, weight_decay=0.01, max_grad_norm=1.0)
+    return cfg, model, opt, O.synthetic_batch(cfg, rows, seed=dseed)
+
+
+def _one_iteration(model, opt, batch):
+    loss = call(model, batch)
+    loss.backward()
+    clip_grad_norm_(model.parameters(), 1.0)
+    opt.step()
+    opt.zero_grad()
+    return float(loss)
+
+
+def test_forward_that_fails_after_adopting_the_pending_update_hands_it_back():
+    """optimizer.step() left its update to the next forward; that forward raises (here: a batch the step cannot load) before any
+    launch of the update went out.  The update must be pending again -- applied exactly once by the next forward, never twice, never
+    dropped -- so a loop that skips the bad batch ends bit-identical to the loop that never saw it."""
+    def run(with_bad_batch):
+        cfg, model, opt, batch = _loop_model()
+        losses = []
+        for it in range(6):
+            if with_bad_batch and it == 3:
+                assert opt.has_pending and opt._auto_deferred
+                bad = dict(batch)
+                bad["video"] = batch["video"][:, :, :, :17]          # wrong feature width: steps.*.load refuses it
+                with pytest.raises(Exception):
+                    call(model, bad)
+                assert opt.has_pending and opt._auto_deferred and model._rider_update is None
+            losses.append(_one_iteration(model, opt, batch))
+        final = {n: p.detach().clone() for n, p in model.named_parameters()}
+        return losses, final, getattr(model, "auto_ride_count", 0)
+    l_bad, p_bad, rides_bad = run(True)
+    l_ok, p_ok, rides_ok = run(False)
+    assert rides_bad == rides_ok == 5
+    assert l_bad == l_ok
+    assert all(torch.equal(p_bad[n], p_ok[n]) for n in p_ok), [n for n in p_ok if not torch.equal(p_bad[n], p_ok[n])][:5]
+
+
+def test_load_state_dict_and_dirty_marks_with_an_update_pending():
+    """with optimizer.step()'s update still pending, (1) model.load_state_dict() must end with exactly the loaded weights in the
+    fp32 master AND in the bf16 shadow the next forward reads (the pending update belongs to the old weights: it is applied first and then
+    overwritten), (2) optimizer.load_state_dict() must not replace the moments under a pending update, (3) a shadow marked dirty stays
+    dirty through a flush / an adoption: tensors outside the update are refreshed from the fp32 master."""
+    cfg, model, opt, batch = _loop_model()
+    for _ in range(4):
+        _one_iteration(model, opt, batch)
+    assert opt.has_pending
+    P = O.procedural_params(cfg, 3)
+    sd = dict(P)
+    for alias, owner in O.tied_aliases(cfg).items():
+        sd[alias] = P[owner]
+    model.load_state_dict(sd, strict=True)
+    assert not opt.has_pending and model.flat.shadow_valid is False
+    loss = call(model, batch)
+    fl = model.flat
+    assert torch.equal(fl.p16.float(), fl.p32.to(torch.bfloat16).float())                  # shadow == rounded master, every tensor
+    for n, p in model.named_parameters():
+        assert torch.equal(p.detach().cpu(), P[n]), n
+    # the same model loaded into a FRESH instance gives the same loss, bit for bit (deterministic mode)
+    cfg2, model2, opt2, _ = _loop_model()
+    model2.load_state_dict(sd, strict=True)
+    assert float(call(model2, batch)) == float(loss)
+    # (2): the optimizer's own load with an update pending -- the update lands first (with the moments it was prepared for), then the
+    # loaded moments replace them
+    loss.backward()
+    clip_grad_norm_(model.parameters(), 1.0)
+    opt.step()
+    assert opt.has_pending
+    before = {n: p.detach().clone() for n, p in torch.nn.Module.named_parameters(model)}      # base-class walk: flushes nothing
+    _one_iteration(model2, opt2, batch)
+    sd2 = opt2.state_dict()
+    opt.load_state_dict(sd2)
+    assert not opt.has_pending
+    after = {n: p.detach().clone() for n, p in torch.nn.Module.named_parameters(model)}
+    assert any(not torch.equal(before[n], after[n]) for n in after)                            # the pending update was applied, once
+    m2 = {i: st["next_m"] for i, st in sd2["state"].items()}
+    for i, st in opt.state_dict()["state"].items():
+        assert torch.equal(st["next_m"].cpu(), m2[i].cpu())
+    # (3): dirty shadow + pending update -> the next forward refreshes every tensor, also those the update does not touch
+    loss = call(model, batch)
+    loss.backward()
+    opt.step()
+    with torch.no_grad():
+        fl.p32[fl.index["bert.pooler.dense.weight"][0]] += 1.0          # a tensor without gradient on this path: outside the update
+    model._flat.shadow_valid = False                                      # what mark_params_dirty records (without its flush)
+    call(model, batch)
+    assert torch.equal(fl.p16.float(), fl.p32.to(torch.bfloat16).float())
+
+
+def test_gradient_accumulation_replays_both_forward_graphs_without_recapture():
+    """with gradient_accumulation_steps > 1 on one GPU (README pretrain commands: 16 / 60) the forward after step() carries the
+    riding update and the following ones do not.  Both variants of the forward plan are captured ONCE and replayed: no capture after
+    warm-up, and the result equals the loop that applies every update immediately."""
+    def run(ride):
+        cfg, model, opt, batch = _loop_model()
+        model.auto_ride = ride
+        caps, losses = [], []
+        for it in range(12):
+            loss = call(model, batch)
+            (loss / 2).backward()
+            if it % 2 == 1:
+                clip_grad_norm_(model.parameters(), 1.0)
+                opt.step()
+                opt.zero_grad()
+            losses.append(float(loss))
+            caps.append(getattr(model, "graph_captures", 0))
+        return losses, caps, {n: p.detach().clone() for n, p in model.named_parameters()}, model
+    l_r, caps, p_r, model = run(True)
+    l_e, _, p_e, _ = run(False)
+    st = next(iter(model._steps.values()))
+    assert st.fwd._segments is not None and len(st.fwd.__dict__.get("_seg_cache", {})) >= 1     # both signatures alive
+    assert caps[-1] == caps[7], caps              # warm-up: 3 eager calls + the first capture of either variant; nothing after it
+    assert model.auto_ride_count == 5
+    assert l_r == l_e
+    assert all(torch.equal(p_r[n], p_e[n]) for n in p_e), [n for n in p_e if not torch.equal(p_r[n], p_e[n])][:5]
 
 
 def test_bert_adam_checkpoint_resume_and_state_dict_layout(tmp_path):

@@ -66,6 +66,28 @@ KEYS = {
 
 _allowed = False
 _parsed = None
+_legacy_checked = False
+
+# Operational switches (not measurements): a training process sets them on the model -- `model.auto_graph`, `model.auto_dp`,
+# `model.dp_capture`, `model.auto_ride` (univl_amd.UniVL attributes, all default True) -- UNIVL_AB stays the harness-only override.
+OPERATIONAL = {"auto_graph": "model.auto_graph = False", "auto_dp": "model.auto_dp = False", "dp_capture": "model.dp_capture = False",
+               "adam_ride": "model.auto_ride = False"}
+
+
+def _check_legacy():
+    """Rounds 1-4 read one environment variable per switch (UNIVL_AUTO_DP, UNIVL_DP_CAPTURE, UNIVL_ADAM_RIDE, UNIVL_LN_FOLD, ...).  They
+    are gone; a process that still sets one would silently run the default -- the failure this module exists to refuse -- so it is an
+    error that names the replacement."""
+    global _legacy_checked
+    if _legacy_checked:
+        return
+    _legacy_checked = True
+    for k in KEYS:
+        name = "UNIVL_" + k.upper()
+        if name in os.environ:
+            how = ("set `%s` on the model (or UNIVL_AB=%s=... in a measurement harness)" % (OPERATIONAL[k], k)) if k in OPERATIONAL \
+                else ("use UNIVL_AB=%s=... (measurement / test harnesses only)" % k)
+            raise RuntimeError("%s is set but no longer read (it would be silently ignored): %s" % (name, how))
 
 
 def allow():
@@ -76,6 +98,7 @@ def allow():
 
 def _parse():
     global _parsed
+    _check_legacy()
     raw = os.environ.get("UNIVL_AB", "")
     if _parsed is not None and _parsed[0] == raw:
         return _parsed[1]

@@ -396,7 +396,11 @@ class UniVL(UniVLPreTrainedModel):
             bert_config.intermediate_size == 3072, "kernels are specialised for H=768, 12 heads, I=3072"
 
         self.graph_backward = False
-        self.auto_graph = bool(_ab.get("auto_graph"))
+        # operational switches a training process may turn off on the model (UNIVL_AB is refused outside measurement harnesses)
+        self.auto_graph = bool(_ab.get("auto_graph"))      # the unchanged loop switches to graph replay on its own
+        self.auto_dp = bool(_ab.get("auto_dp"))            # built-in gradient exchange inside an initialised process group
+        self.dp_capture = bool(_ab.get("dp_capture"))      # RCCL exchange captured into the step graph (False: host-issued collectives)
+        self.auto_ride = _ab.get("adam_ride") != "0"       # optimizer.step() leaves its launch to the next forward (bf16, one process)
         self._stage_one, self._stage_two = True, False
         if _check_attr("stage_two", tc):
             self._stage_one, self._stage_two = False, tc.stage_two
@@ -466,7 +470,7 @@ class UniVL(UniVLPreTrainedModel):
         loss.backward() through autograd so that DDP's bookkeeping for the anchor parameter stays consistent."""
         self._dp_checked = True
         import torch.distributed as dist
-        if not _ab.get("auto_dp") or not (dist.is_available() and dist.is_initialized()):
+        if not self.auto_dp or not (dist.is_available() and dist.is_initialized()):
             return
         if dist.get_world_size() > 1:
             self.enable_data_parallel()
@@ -484,6 +488,8 @@ class UniVL(UniVLPreTrainedModel):
             module.bias.data.zero_()
 
     def _apply(self, fn, *a, **kw):
+        if self.__dict__.get("_pending_update") is not None:
+            self._flush_pending()           # .to() / .float() re-allocate the parameters a pending update still points at
         r = super()._apply(fn, *a, **kw)
         self._flat, self._steps = None, {}      # parameters were re-allocated (e.g. .to(device)): re-flatten lazily
         return r
@@ -521,10 +527,13 @@ class UniVL(UniVLPreTrainedModel):
     def mark_params_dirty(self):
         """Tell the model its fp32 parameters were modified outside univl_amd.optimization.BertAdam (the bf16
         shadow the GEMMs read is refreshed before the next forward)."""
+        self._flush_pending()               # nothing stays pending across an outside edit (the edit itself should come after a flush:
+                                            # INTEGRATION.md, "what a deferred update can and cannot hide")
         if self._flat is not None:
             self._flat.shadow_valid = False
 
     def load_state_dict(self, *a, **kw):
+        self._flush_pending()               # (ADVICE r5) never on top of the loaded weights
         r = super().load_state_dict(*a, **kw)
         self.mark_params_dirty()
         return r
@@ -580,7 +589,7 @@ class UniVL(UniVLPreTrainedModel):
         self._reducer = BucketReducer(fl.g32, process_group, loopback=loopback, force=force)
         if not self._reducer.active:
             self._reducer = None
-        elif _ab.get("dp_capture") and not loopback and fl.device.type == "cuda":
+        elif self.dp_capture and not loopback and fl.device.type == "cuda":
             # RCCL: a communicator of our own, so that the exchange is captured into the step's hipGraph (univl_amd.rccl)
             try:
                 with torch.cuda.device(fl.device):
@@ -658,6 +667,7 @@ class UniVL(UniVLPreTrainedModel):
         return st
 
     AUTO_GRAPH_AFTER = 2
+    GRAPH_SIGS = 4
 
     def _run_plan(self, plan, st):
         """Enqueue a forward / backward plan.  Launched kernel by kernel from Python the host is the bottleneck at small
@@ -673,8 +683,18 @@ class UniVL(UniVLPreTrainedModel):
                 # (steady state of a training loop: same optimizer tables, same buffers), else capture again
                 rd = plan.riders
                 sig = None if rd is None else (bytes(rd["desc"]), tuple(sorted(rd["ranges"].items())), int(rd.get("max_blocks", 0)))
-                if plan._segments is not None and getattr(plan, "_rider_sig", None) != sig:
-                    plan._segments = None
+                if getattr(plan, "_rider_sig", None) != sig:
+                    # captured segments are kept PER signature: under gradient accumulation the forward after step() carries
+                    # riders and the following ones do not -- both graphs are captured once and replayed, not re-captured at every
+                    # transition.  At most GRAPH_SIGS signatures are kept (steady state: "no riders" + one update descriptor).
+                    cache = plan.__dict__.setdefault("_seg_cache", {})
+                    if plan._segments is not None:
+                        cache[getattr(plan, "_rider_sig", None)] = plan._segments
+                        while len(cache) > self.GRAPH_SIGS:
+                            cache.pop(next(iter(cache)))
+                    plan._segments = cache.pop(sig, None)
+                    if plan._segments is None:
+                        self.graph_captures = getattr(self, "graph_captures", 0) + 1
                 if plan._segments is None and sig is not None:
                     import ctypes as C                  # the rider kernels' large-LDS opt-in must not happen inside the capture
                     _lib.check(_lib.lib().univl_gemm_rider_prime(C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm_rider_prime")
@@ -727,36 +747,78 @@ class UniVL(UniVLPreTrainedModel):
             raise RuntimeError("UniVL.forward: the caption path needs input_caption_ids / decoder_mask / output_caption_ids")
         if not self._dp_checked:
             self._auto_data_parallel()
-        adopted = self._adopt_pending_update()
-        if not adopted:
-            self._flush_pending()
-        fl = self.flat
-        if getattr(fl, "shard_reducer", None) is not None:
-            fl.shard_reducer.join()            # the all-gather of the updated shadow must have landed
-        fl.refresh_shadow()
-        st = self._get_step(kind, B, W, F)
-        st.enc.load(input_ids, token_type_ids, attention_mask, video, video_mask)
-        if kind in ("pretrain", "pretrain_nocap"):
-            st.enc_m.load(pairs_masked_text, token_type_ids, attention_mask, masked_video, video_mask)
-            st.heads.load(pairs_token_labels, video_labels_index)
-        if st.decoder is not None:
-            st.decoder.load(input_caption_ids, decoder_mask, output_caption_ids)
-        anchor = fl.params[self.ANCHOR]
-        st.calls += 1
-        ru = self._rider_update
-        if ru is not None:
-            self._start_riding_update(st, ru)
+        adopted, riding = False, False
         try:
-            if torch.is_grad_enabled() and anchor.requires_grad:
-                out = _StepLossFn.apply(anchor, self, st).as_subclass(_LossTensor)
-                out._univl = (self, st)
-                return out
-            self._run_plan(st.fwd, st)
-            return _loss_out(st)
+            adopted = self._adopt_pending_update()
+            if not adopted:
+                self._flush_pending()
+            fl = self.flat
+            if getattr(fl, "shard_reducer", None) is not None:
+                fl.shard_reducer.join()            # the all-gather of the updated shadow must have landed
+            fl.refresh_shadow()
+            st = self._get_step(kind, B, W, F)
+            st.enc.load(input_ids, token_type_ids, attention_mask, video, video_mask)
+            if kind in ("pretrain", "pretrain_nocap"):
+                st.enc_m.load(pairs_masked_text, token_type_ids, attention_mask, masked_video, video_mask)
+                st.heads.load(pairs_token_labels, video_labels_index)
+            if st.decoder is not None:
+                st.decoder.load(input_caption_ids, decoder_mask, output_caption_ids)
+            anchor = fl.params[self.ANCHOR]
+            st.calls += 1
+            ru = self._rider_update
+            if ru is not None:
+                riding = True
+                self._start_riding_update(st, ru)
+            try:
+                if torch.is_grad_enabled() and anchor.requires_grad:
+                    out = _StepLossFn.apply(anchor, self, st).as_subclass(_LossTensor)
+                    out._univl = (self, st)
+                    return out
+                self._run_plan(st.fwd, st)
+                return _loss_out(st)
+            finally:
+                st.fwd.riders = None
+        except BaseException:
+            if adopted:
+                self._unadopt_pending_update(riding)
+            raise
         finally:
-            st.fwd.riders = None
+            # an update this forward adopted is never left behind: either it went out with the plan, or the except branch
+            # above handed it back to the optimizer; graphed.GraphedTrainStep sets and clears its own descriptor around its calls
             if adopted:
                 self._rider_update = None
+
+    def _unadopt_pending_update(self, riding):
+        """forward() adopted the optimizer's pending update and failed.  Before any launch of the update went out (bad batch shape, out of
+        memory while a new step was built, a failing join): hand it back -- it is pending again and the next forward (or any flush) applies
+        it exactly once.  After _start_riding_update began enqueueing it cannot be taken back (some chunk ranges are applied, the ones
+        riding in the failed plan are not): apply the whole set of ranges that have not gone out as plain launches, so that every
+        parameter sees the update exactly once, and leave nothing pending."""
+        o, ru = self._pending_update, self._rider_update
+        self._rider_update = None
+        if o is None or ru is None:
+            return
+        if not riding:
+            o._deferred, o._auto_deferred = True, True
+            self.auto_ride_count = getattr(self, "auto_ride_count", 1) - 1
+            return
+        import ctypes as C
+        for st in self._steps.values():
+            rd = getattr(getattr(st, "fwd", None), "riders", None)
+            if rd is None or rd.get("desc") is not ru["desc"]:
+                continue
+            h = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            done = {}
+            for key, slot in rd["used"]:
+                done.setdefault(key, set()).add(slot)
+            for key, (c0, n) in rd["ranges"].items():
+                if key in done:
+                    # a stack whose first products already carried a part: the slots are fractions of the range only the plan knows;
+                    # nothing here can tell which chunks went out -- refuse to guess
+                    raise RuntimeError("univl_amd.UniVL.forward failed after a part of the riding BertAdam update was enqueued; the "
+                                       "parameters hold a partial update (model.auto_ride = False avoids riding updates)")
+                _lib.check(_lib.lib().univl_bert_adam_range(C.byref(rd["desc"]), c0, n, 0, 0, h), "bert_adam_range")
+            st.fwd.riders = None
 
     def _adopt_pending_update(self):
         """The unchanged training loop (main_task_retrieval.py:333-353): optimizer.step() left its BertAdam update pending
@@ -773,7 +835,8 @@ class UniVL(UniVLPreTrainedModel):
         self._rider_update = dict(desc=o._last_desc, groups=o.chunk_groups(), max_blocks=0)
         o._deferred = False                   # from here on the update counts as applied (launch_deferred's bookkeeping)
         o._auto_deferred = False
-        fl.shadow_valid = True
+        # fl.shadow_valid is left as it is: the update rewrites the bf16 shadow of the tensors it updates, and a shadow that was marked
+        # dirty (mark_params_dirty, a broadcast) is still refreshed from the fp32 master by this forward, in front of the riders
         self.auto_ride_count = getattr(self, "auto_ride_count", 0) + 1
         return True
 

@@ -367,6 +367,7 @@ class BertAdam(Optimizer):
         """optimizer.load_state_dict(checkpoint['last_optimizer_state']) of main_pretrain.py:389: torch installs fresh
         tensors under state[p]; they are copied into the flat moment buffers, the device step counters are set from
         state['step'], and the entries are re-pointed at the flat views the kernel updates."""
+        self.flush()                        # a pending update reads the moments this call replaces (ADVICE r5)
         super().load_state_dict(state_dict)
         try:
             fl = _find_flat(self.param_groups[0]['params'][0])
@@ -432,7 +433,8 @@ class BertAdam(Optimizer):
                 if on_group is not None and (i + 1 == len(groups) or groups[i + 1][0] != key):
                     on_group(key)
         self._deferred = False
-        self._fl.shadow_valid = True
+        # (the update rewrites the bf16 shadow of the tensors it updates: a valid shadow stays valid, and one that was marked dirty --
+        # tensors outside this update may be stale -- stays dirty until refresh_shadow)
         self._after_update(self._fl)
 
     def _after_update(self, fl):
@@ -536,8 +538,7 @@ class BertAdam(Optimizer):
             self._deferred = True
         else:
             _lib.check(_lib.lib().univl_bert_adam(C.byref(d), _stream()), "bert_adam")
-            fl.shadow_valid = True      # the step rewrote the bf16 shadow
-            self._after_update(fl)
+            self._after_update(fl)      # (the step rewrote the bf16 shadow of what it updated; a dirty shadow stays dirty)
         for n in cfg:
             p = fl.params[n]
             st = self.state[p]
