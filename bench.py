@@ -71,6 +71,17 @@ def get_args():
                     help="skip `other_configs` (the other BASELINE.json configurations, each measured by a child process of this run "
                          "after the headline: 16 / 128 pairs, FT-Align, cfg4, cfg5, the data-parallel schedule on one GPU)")
     ap.add_argument("--others-budget", type=float, default=300.0, help="wall-clock budget (s) for all `other_configs` children together")
+    ap.add_argument("--measure", default="", choices=["", "eval_joint", "eval_align", "decode"],
+                    help="internal (children of the default run): time a CALLER of the hot path instead of the training step -- retrieval "
+                         "evaluation FT-Joint / FT-Align (univl_amd.eval.eval_retrieval, main_task_retrieval.py:383-450) or beam-5 caption "
+                         "decoding (univl_amd.decode.CaptionBeamSearch, main_task_caption.py:434-522); prints one JSON line")
+    ap.add_argument("--eval-items", type=int, default=0, help="--measure eval_*: number of (text, video) items (default 1024 joint / 128 align)")
+    ap.add_argument("--cfg3-row", action="store_true",
+                    help="also time BASELINE cfg3's share of the global batch of 128 (128 / world pairs per GPU) in THIS run (default at N > 1)")
+    ap.add_argument("--watchdog-s", type=float, default=240.0,
+                    help="N > 1 / --force-dp: bound (s) on every phase that can hang on a collective (process-group init, communicator "
+                         "construction + captured self-test, first captured step, each timed region); on expiry every rank prints a JSON "
+                         "error line and exits with status 3 instead of hanging to the driver's timeout")
     ap.add_argument("--child", action="store_true", help="internal: one `other_configs` measurement (no CPU leg, no PCIe leg, no children)")
     ap.add_argument("--no-preheat", action="store_true", help="skip the declared, untimed pre-heat in front of the timed steps")
     ap.add_argument("--preheat-max-s", type=float, default=6.0)
@@ -200,6 +211,12 @@ OTHER_CONFIGS = [
     ("ft_align_48x48", ["--kind", "align"], {}, "align_full, align_full_cot"),
     ("cfg4_caption_128x96", ["--kind", "caption"], {}, "caption_full"),
     ("cfg5_pretrain_48x64_6_rows", ["--kind", "pretrain", "--batch", "6"], {}, "pretrain_full, pretrain_full_cot"),
+    # the reference's own arithmetic (modules/modeling.py is fp32 end to end): exact-fp32 MFMA products, same plans
+    ("fp32_mode_4_pairs", ["--dtype", "fp32"], {}, "joint_full[float32]"),
+    # callers either side of the path, timed: retrieval evaluation and beam-search caption decoding
+    ("eval_retrieval_ft_joint_1024_items", ["--measure", "eval_joint"], {}, "tests/test_eval_gpu.py"),
+    ("eval_retrieval_ft_align_128_items", ["--measure", "eval_align"], {}, "tests/test_eval_gpu.py"),
+    ("caption_beam5_decode_16x32", ["--measure", "decode"], {}, "tests/test_decode_gpu.py"),
     ("dp_schedule_dry_run_4_pairs", ["--force-dp"], {"UNIVL_AB": "dp_dryrun=1"}, "test_graphed_and_data_parallel_schedules_match_eager[joint_small]"),
     ("dp_schedule_dry_run_16_pairs", ["--force-dp", "--batch", "16"], {"UNIVL_AB": "dp_dryrun=1"}, "test_graphed_and_data_parallel_schedules_match_eager[joint_small]"),
 ]
@@ -229,11 +246,15 @@ def other_configs(args):
         except Exception as ex:      # noqa: BLE001
             rows.append(dict(name=name, error="%s: %s" % (type(ex).__name__, str(ex)[-300:])))
             continue
+        if "--measure" in extra:     # a caller of the path, not the training step: the child's own line is the row
+            j.update(name=name, args=" ".join(extra), child_wall_s=round(time.time() - t0, 1))
+            rows.append(j)
+            continue
         rf = j.get("roofline") or {}
         rows.append(dict(
             name=name, args=" ".join(extra), env=env_extra or None, ms_per_step=j["ms_per_step"], value=j["value"], unit=j["unit"],
             steps=j["steps"], warmup=j["warmup"], preheat_block_ms=(j.get("preheat") or {}).get("block_ms"),
-            graph_mode=j["config"].get("graph_mode"), optimizer_riding=j["config"].get("optimizer_riding"),
+            graph_mode=j["config"].get("graph_mode"), optimizer_riding=j["config"].get("optimizer_riding"), dtype=j.get("dtype"),
             roofline=dict(gemm_family_ms=rf.get("family_ms_per_step"), gemm_hbm_frac=(rf.get("hbm") or {}).get("frac"),
                           gemm_mfma_frac=(rf.get("mfma") or {}).get("frac"), step_hbm_frac=(rf.get("step") or {}).get("hbm_frac"),
                           step_mfma_frac=(rf.get("step") or {}).get("mfma_frac"), adam_frac=(rf.get("adam") or {}).get("frac"))
@@ -311,8 +332,186 @@ def gemm_family(model, dev, reps=10, carried=False):
                 algorithmic_bytes_per_step=int(nbytes), weight_bytes_per_step=int(wbytes), flops_per_step=flops)
 
 
+
+def parity_leg(batch, kind, dtype):
+    """The parity statistic of the BENCHED configuration, measured in this run: tests/test_model_gpu.py's golden test
+    of the library's default mode for the case that covers it (fixtures of the real reference under tests/golden/) runs as a child
+    process -- the test module is the checker, this file only reads the numbers it recorded."""
+    case = {("joint", 4): "joint_full", ("joint", 16): "joint_b16", ("joint", 32): "joint_b32", ("joint", 64): "joint_b64",
+            ("joint", 128): "joint_b128", ("caption", 4): "caption_full", ("pretrain", 6): "pretrain_full", ("align", 4): "align_full"}.get((kind, batch))
+    if case is None or dtype != "bf16":
+        return None
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), "univl_parity_%d.json" % os.getpid())
+    env = dict(os.environ, UNIVL_PARITY_OUT=path)
+    env.pop("UNIVL_AB", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_model_gpu.py"), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "test_forward_backward_vs_reference_golden_default_mode and %s" % case], env=env, capture_output=True, text=True,
+                       timeout=240, cwd=ROOT)
+    out = dict(case=case + "@default", test="tests/test_model_gpu.py::test_forward_backward_vs_reference_golden_default_mode[%s]" % case,
+               passed=r.returncode == 0, seconds=round(time.time() - t0, 1), north_star_tolerance=1e-2,
+               against="gradients / loss / similarity of the real reference in fp32 (tests/golden/%s.npz, oracle/make_golden.py)" % case)
+    try:
+        e = json.load(open(path))[case + "@default"]["bfloat16"]
+        out.update(gglobal=e.get("gglobal"), gate=1.3e-2 * 1.1, gnorm=e.get("gnorm"), gmedian=e.get("gmedian"), loss=e.get("loss"), sim=e.get("sim"),
+                   note="gglobal = ||all gradient samples - reference|| / ||reference||; loss / sim relative output errors (gate 1e-2); the "
+                        "gradient statistic sits at the north-star tolerance, not under it: profiles/r06_emul_bf16_roundings.txt says which "
+                        "operand roundings own it")
+        os.remove(path)
+    except Exception as ex:      # noqa: BLE001
+        out["error"] = "%s: %s | %s" % (type(ex).__name__, ex, (r.stdout or r.stderr)[-200:])
+    return out
+
+
+class Watchdog:
+    """A phase that can hang on a collective must not cost the whole scaling record: arm(label, seconds) starts a timer thread; if the
+    phase is still running when it fires, this rank prints ONE JSON line naming the phase (rank 0: stdout, so the driver's record holds
+    it; others: stderr) and leaves with os._exit(3) -- torch.distributed.run then tears the other ranks down."""
+
+    def __init__(self, rank, world, enabled):
+        import threading
+        self._threading, self.rank, self.world, self.enabled = threading, rank, world, enabled
+        self._timer, self.label = None, None
+
+    def arm(self, label, seconds):
+        self.disarm()
+        if not self.enabled or seconds <= 0:
+            return
+        self.label = label
+        self._timer = self._threading.Timer(seconds, self._fire, args=(label, seconds))
+        self._timer.daemon = True
+        self._timer.start()
+
+    def disarm(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+    def _fire(self, label, seconds):
+        line = json.dumps(dict(metric="video-text pairs/sec (retrieval finetune, 48x48)", value=None, error="watchdog",
+                               phase=label, bound_s=seconds, rank=self.rank, n_gpus=self.world,
+                               what="this phase did not return within its bound; the run was aborted instead of hanging"))
+        try:
+            print(line, file=(sys.stdout if self.rank == 0 else sys.stderr), flush=True)
+        finally:
+            os._exit(3)
+
+
+def _eval_model(args, dev, kind):
+    from univl_amd import UniVL
+    a2 = argparse.Namespace(**vars(args))
+    a2.kind, a2.dropout = kind, 0.0
+    tc = task_config(a2, 1)
+    model = UniVL.from_pretrained("bert-base-uncased", "visual-base", "cross-base", "decoder-base", task_config=tc)
+    model.to(dev).eval()
+    return model, tc
+
+
+def measure_caller(args):
+    """`--measure`: the callers either side of the hot path that rounds 1-5 only parity-tested, timed on
+    synthetic data of the reference's shapes with the inputs resident in HBM.  One JSON line."""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from univl_amd import _ab as _uab
+    _uab.allow()
+    torch.manual_seed(0)
+    g = torch.Generator(device="cpu").manual_seed(99)
+    out = dict(measure=args.measure, dtype=args.dtype, data="synthetic", n_gpus=1)
+    if args.measure in ("eval_joint", "eval_align"):
+        from univl_amd.eval import eval_retrieval
+        align = args.measure == "eval_align"
+        model, tc = _eval_model(args, dev, "align" if align else "joint")
+        W, F = tc.max_words, tc.max_frames
+        n = args.eval_items or (128 if align else 1024)
+        bs = 64                                      # --batch_size_val 64 of the README's retrieval commands: 64 x 64 similarity blocks
+        batches = []
+        for lo in range(0, n, bs):
+            b = min(bs, n - lo)
+            ids = torch.randint(1000, 30522, (b, 1, W), generator=g)
+            ids[..., 0] = 101
+            batches.append(tuple(t.to(dev) for t in (ids, torch.ones(b, 1, W, dtype=torch.int64), torch.zeros(b, 1, W, dtype=torch.int64),
+                                                     torch.randn(b, 1, F, 1024, generator=g, dtype=torch.float64),
+                                                     torch.ones(b, 1, F, dtype=torch.int64))))
+        eval_retrieval(model, batches)              # builds the plans
+        torch.cuda.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            metrics, sim = eval_retrieval(model, batches)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / reps
+        # algorithmic forward work: both encoders once per item (12.436 GFLOP: SURVEY section 8a, FlopCounterMode on the reference);
+        # FT-Align adds every (text, video) pair through the 2-layer cross encoder over 96 tokens + pooler + similarity_dense
+        enc = 12.436e9 * n
+        cross_pair = 2 * (W + F) * 14.16e6 + 2 * 4 * (W + F) ** 2 * 768 + 2 * 768 * 768
+        flops = enc + (cross_pair * n * n if align else 2.0 * n * n * 768)
+        out.update(metric="retrieval evaluation, %s (items/s)" % ("FT-Align: N^2 pairs through the cross encoder" if align else "FT-Joint"),
+                   value=round(n / el, 1), unit="items/s", seconds_per_eval=round(el, 4), items=n, block=bs,
+                   similarity_pairs_per_s=round(n * n / el, 1),
+                   roofline=dict(bound="mfma", flops=flops, achieved_tflops=round(flops / el / 1e12, 2), peak=2500.0,
+                                 frac=round(flops / el / 2.5e15, 4)),
+                   parity_test="tests/test_eval_gpu.py::test_eval_retrieval_and_replicas[%s]" % ("align_small" if align else "joint_small"),
+                   reference="main_task_retrieval.py:383-450 (eval_epoch, _run_on_single_gpu), metrics.py:8-20",
+                   R1=float(metrics["R1"]))
+    else:
+        from univl_amd.decode import CaptionBeamSearch
+        model, tc = _eval_model(args, dev, "caption")
+        W, F = tc.max_words, tc.max_frames
+        n, nb, T = 16, 5, 32
+        ids = torch.randint(1000, 30522, (n, 1, W), generator=g)
+        ids[..., 0] = 101
+        b = [t.to(dev) for t in (ids, torch.zeros(n, 1, W, dtype=torch.int64), torch.ones(n, 1, W, dtype=torch.int64),
+                                 torch.randn(n, 1, F, 1024, generator=g, dtype=torch.float64), torch.ones(n, 1, F, dtype=torch.int64))]
+        with torch.no_grad():
+            so, vo = model.get_sequence_visual_output(*b)
+        am, vm = b[2].view(n, -1), b[4].view(n, -1)
+        bsr = CaptionBeamSearch(model, n, W, F, n_bm=nb, max_len=T)
+        hyp, _ = bsr(so, vo, am, vm, bos=101, eos=-1)                 # captures one graph per position; eos -1: every instance runs T steps
+        torch.cuda.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            hyp, _ = bsr(so, vo, am, vm, bos=101, eos=-1)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / reps
+        # the reference's procedure (main_task_caption.py:441-452): decoder_caption on the COMPLETE prefixes of all n x 5 beams, once per token
+        R = n * nb
+        so5, vo5 = so.repeat_interleave(nb, 0), vo.repeat_interleave(nb, 0)
+        am5, vm5 = am.repeat_interleave(nb, 0), vm.repeat_interleave(nb, 0)
+        cap = torch.randint(1000, 30522, (R, T), generator=g).to(dev)
+
+        def no_cache():
+            with torch.no_grad():
+                for t in range(1, T + 1):
+                    model.decoder_caption(so5, vo5, None, am5, vm5, cap[:, :t], torch.ones(R, t, dtype=torch.int64, device=dev),
+                                          shaped=True, get_logits=True)
+        no_cache()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        no_cache()
+        torch.cuda.synchronize()
+        el_nc = time.perf_counter() - t0
+        # bytes one cached step has to read: the decoder stack's bf16 weights + the tied vocabulary table (the step is HBM / latency bound)
+        esz = 2 if args.dtype == "bf16" else 4
+        dec_params = sum(p.numel() for k, p in model.named_parameters() if k.startswith("decoder.decoder.layer"))
+        step_bytes = (dec_params + 30522 * 768) * esz
+        out.update(metric="beam-%d caption decoding (hypothesis tokens/s)" % nb, value=round(n * T / el, 1), unit="tokens/s",
+                   instances=n, beams=nb, max_len=T, ms_per_position=round(el / T * 1e3, 4), seconds_per_batch=round(el, 4),
+                   no_cache=dict(value=round(n * T / el_nc, 1), unit="tokens/s", seconds_per_batch=round(el_nc, 4),
+                                 what="model.decoder_caption() on the complete prefixes of all %d beams once per position (the reference's loop)" % R),
+                   speedup_over_no_cache=round(el_nc / el, 2),
+                   roofline=dict(bound="hbm", algorithmic_bytes_per_position=step_bytes, achieved_gbs=round(step_bytes / (el / T) / 1e9, 1),
+                                 peak=8000.0, frac=round(step_bytes / (el / T) / 8.0e12, 4)),
+                   parity_test="tests/test_decode_gpu.py::test_beam_search_matches_reference_golden",
+                   reference="main_task_caption.py:434-522, modules/beam.py", tokens_generated=sum(len(h) for h in hyp))
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = get_args()
+    if args.measure:
+        return measure_caller(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         respawn_under_launcher(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -321,7 +520,9 @@ def main():
     if world != args.gpus and rank == 0:
         print("[bench] --gpus %d but the launcher started %d rank(s); using %d" % (args.gpus, world, world), file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
+    wd = Watchdog(rank, world, enabled=(world > 1 or args.force_dp))
     if world > 1 or args.force_dp:
+        wd.arm("torch.distributed.init_process_group(nccl)", args.watchdog_s)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
@@ -331,6 +532,7 @@ def main():
         assert torch.cuda.device_count() > local_rank, "rank %d has no GPU %d" % (rank, local_rank)
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        wd.disarm()
     else:
         dist = None
     dev = torch.device("cuda", local_rank)
@@ -351,7 +553,9 @@ def main():
     if args.grad_exchange:
         os.environ["UNIVL_GRAD_EXCHANGE"] = args.grad_exchange
     if world > 1 or args.force_dp:
+        wd.arm("enable_data_parallel: parameter broadcast, ncclCommInitRank of the library's communicator, captured self-test", args.watchdog_s)
         model.enable_data_parallel(force=args.force_dp, shard_optimizer=args.shard_optimizer)
+        wd.disarm()
     elif args.loopback:
         model.enable_data_parallel(loopback=True)
     opt = make_optimizer(model, BertAdam)
@@ -400,9 +604,11 @@ def main():
 
         # eager warm-up (builds plans / tables), then hipGraph replay of the whole step (univl_amd.graphed): one graph on a
         # single GPU; with a gradient exchange the collectives stay on the host between captured segments
+        wd.arm("first eager training steps at %d pairs per GPU (first collectives of the gradient exchange)" % B, args.watchdog_s)
         for _ in range(3):
             float(step_body())
         torch.cuda.synchronize()
+        wd.arm("capture + first replay of the step graph at %d pairs per GPU" % B, args.watchdog_s)
         gstep, mode = None, ("per-plan graphs (UniVL._run_plan)" if model.auto_graph else "eager")
         if not args.no_graph:
             from univl_amd.graphed import GraphedTrainStep
@@ -432,6 +638,8 @@ def main():
                 model.graph_backward = False
                 torch.cuda.synchronize()
 
+        wd.disarm()
+
         def one_step(src):
             a, kw = call_args(src)
             if gstep is not None:
@@ -443,6 +651,7 @@ def main():
 
         def timed(src, steps, warmup):
             last = None
+            wd.arm("timed region: %d warm-up + %d steps at %d pairs per GPU" % (warmup, steps, B), args.watchdog_s)
             for _ in range(warmup):
                 last = one_step(src)
             if dist is not None:
@@ -464,6 +673,7 @@ def main():
                 t = torch.tensor([el], device=dev, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 el = float(t)
+            wd.disarm()
             return el, last
 
         def preheat(src, block, tol=0.01, need=3):
@@ -474,6 +684,7 @@ def main():
             (or --preheat-max-s is spent), report every block's ms/step, and only then run the W untimed + K timed steps of the contract."""
             blocks, t_begin = [], time.perf_counter()
             stable = False
+            wd.arm("pre-heat blocks at %d pairs per GPU" % B, args.watchdog_s + args.preheat_max_s)
             while True:
                 if dist is not None:
                     dist.barrier()
@@ -493,6 +704,7 @@ def main():
                         break
                 elif stable or spent > args.preheat_max_s:
                     break
+            wd.disarm()
             return dict(seconds=round(time.perf_counter() - t_begin, 3), block_steps=block, block_ms=[round(b, 4) for b in blocks],
                         stable=bool(stable), rule="blocks of %d untimed steps until %d consecutive blocks agree within %.0f %% (cap %.0f s)"
                                                   % (block, need, tol * 100, args.preheat_max_s))
@@ -612,53 +824,83 @@ def main():
     except Exception as ex:      # noqa: BLE001 -- a failing side measurement must never cost the headline line
         print("[bench] rank %d: roofline side measurements failed (%s: %s)" % (rank, type(ex).__name__, ex), file=sys.stderr)
         roofline = dict(error="%s: %s" % (type(ex).__name__, ex))
-    exchange = None
-    if model._reducer is not None:
-        stp = [v for v in model._steps.values() if hasattr(v, "exchange_points")]
-        if stp:
-            pts = stp[0].exchange_points
-            red = model._reducer
-            exchange = dict(points=len(pts), dense_mb=round(sum(e - s for c in pts for s, e in c) * 4 / 2 ** 20, 1),
-                            sparse_word_embedding=getattr(stp[0], "sparse_exchange", None),
-                            backend="loopback" if red.loopback else "rccl", wire_dtype="bf16" if red.bf16 else "fp32",
-                            graphs_per_iteration=(2 if (gstep is not None and gstep._g_rest is not None) else 1) if gstep is not None and gstep.mode == "whole" else None,
-                            captured_in_step_graph=bool(red.capturable and gstep is not None and gstep.mode == "whole"))
-            if red.capturable:
-                # Where the step's time goes once gradients cross xGMI: a few EAGER iterations (events cannot be timed inside a
-                # graph) with HIP events around every collective on the communication stream and around the join that precedes the
-                # clip.  exposed_ms = what the compute stream waits for after its last backward kernel; algbw_gbs = exchanged
-                # bytes / time the collectives themselves took (the all-reduce algorithm bandwidth the ring delivers at this size).
-                try:
-                    from univl_amd.parallel import collect_timings
-                    if gstep is not None:
-                        gstep.flush()
-                    auto, model.auto_graph, model.graph_backward = model.auto_graph, False, False
-                    red.measure = True
-                    for _ in range(5):
-                        float(step_body())
-                    tm = collect_timings(red)
-                    red.measure, model.auto_graph = False, auto
-                    n = max(1, tm["steps"])
-                    exchange.update(exposed_ms=round(tm["exposed_ms"] / n, 4), collective_ms=round(tm["collective_ms"] / n, 4),
-                                    algbw_gbs=round(tm["bytes"] / max(tm["collective_ms"], 1e-9) / 1e6, 1),
-                                    measured_on="5 eager iterations after the timed region (HIP events; eager launches are host-bound, so "
-                                                "the backward these collectives hide behind is LONGER than in the graph replay: exposed_ms "
-                                                "is a lower bound for the replayed step)")
-                except Exception as ex:      # noqa: BLE001
-                    exchange["timing_error"] = "%s: %s" % (type(ex).__name__, ex)
-            if dist is not None and world > 1:
-                # first contact with N > 1: EVERY rank's view of the exchange in the one line rank 0 prints (a slow link or a rank
-                # that fell back shows up here, not in a log nobody collects)
-                mine = dict(rank=rank, backend=exchange["backend"], wire_dtype=exchange["wire_dtype"], captured=exchange["captured_in_step_graph"],
-                            exposed_ms=exchange.get("exposed_ms"), collective_ms=exchange.get("collective_ms"), algbw_gbs=exchange.get("algbw_gbs"),
-                            timing_error=exchange.get("timing_error"))
-                per_rank = [None] * world
-                dist.all_gather_object(per_rank, mine)
-                exchange["per_rank"] = per_rank
-                ex_ms = [r["exposed_ms"] for r in per_rank if r and r.get("exposed_ms") is not None]
-                if ex_ms:
-                    exchange["exposed_ms_max_over_ranks"] = max(ex_ms)
-                    exchange["exposed_fraction_of_step"] = round(max(ex_ms) / ms_per_step, 4)
+    def exchange_report(R_, ms_step):
+        gstep, step_body = R_.gstep, R_.step_body
+        exchange = None
+        if model._reducer is not None:
+            stp = [v for k_, v in model._steps.items() if hasattr(v, "exchange_points") and isinstance(k_, tuple) and len(k_) > 1 and k_[1] == R_.B] \
+                or [v for v in model._steps.values() if hasattr(v, "exchange_points")]
+            if stp:
+                pts = stp[0].exchange_points
+                red = model._reducer
+                exchange = dict(points=len(pts), dense_mb=round(sum(e - s for c in pts for s, e in c) * 4 / 2 ** 20, 1),
+                                sparse_word_embedding=getattr(stp[0], "sparse_exchange", None),
+                                backend="loopback" if red.loopback else "rccl", wire_dtype="bf16" if red.bf16 else "fp32",
+                                graphs_per_iteration=(2 if (gstep is not None and gstep._g_rest is not None) else 1) if gstep is not None and gstep.mode == "whole" else None,
+                                captured_in_step_graph=bool(red.capturable and gstep is not None and gstep.mode == "whole"))
+                if red.capturable:
+                    # Where the step's time goes once gradients cross xGMI: a few EAGER iterations (events cannot be timed inside a
+                    # graph) with HIP events around every collective on the communication stream and around the join that precedes the
+                    # clip.  exposed_ms = what the compute stream waits for after its last backward kernel; algbw_gbs = exchanged
+                    # bytes / time the collectives themselves took (the all-reduce algorithm bandwidth the ring delivers at this size).
+                    try:
+                        from univl_amd.parallel import collect_timings
+                        if gstep is not None:
+                            gstep.flush()
+                        auto, model.auto_graph, model.graph_backward = model.auto_graph, False, False
+                        red.measure = True
+                        for _ in range(5):
+                            float(step_body())
+                        tm = collect_timings(red)
+                        red.measure, model.auto_graph = False, auto
+                        n = max(1, tm["steps"])
+                        exchange.update(exposed_ms=round(tm["exposed_ms"] / n, 4), collective_ms=round(tm["collective_ms"] / n, 4),
+                                        algbw_gbs=round(tm["bytes"] / max(tm["collective_ms"], 1e-9) / 1e6, 1),
+                                        measured_on="5 eager iterations after the timed region (HIP events; eager launches are host-bound, so "
+                                                    "the backward these collectives hide behind is LONGER than in the graph replay: exposed_ms "
+                                                    "is a lower bound for the replayed step)")
+                    except Exception as ex:      # noqa: BLE001
+                        exchange["timing_error"] = "%s: %s" % (type(ex).__name__, ex)
+                if dist is not None and world > 1:
+                    # first contact with N > 1: EVERY rank's view of the exchange in the one line rank 0 prints (a slow link or a rank
+                    # that fell back shows up here, not in a log nobody collects)
+                    mine = dict(rank=rank, backend=exchange["backend"], wire_dtype=exchange["wire_dtype"], captured=exchange["captured_in_step_graph"],
+                                exposed_ms=exchange.get("exposed_ms"), collective_ms=exchange.get("collective_ms"), algbw_gbs=exchange.get("algbw_gbs"),
+                                timing_error=exchange.get("timing_error"))
+                    per_rank = [None] * world
+                    dist.all_gather_object(per_rank, mine)
+                    exchange["per_rank"] = per_rank
+                    ex_ms = [r["exposed_ms"] for r in per_rank if r and r.get("exposed_ms") is not None]
+                    if ex_ms:
+                        exchange["exposed_ms_max_over_ranks"] = max(ex_ms)
+                        exchange["exposed_fraction_of_step"] = round(max(ex_ms) / ms_step, 4)
+        return exchange
+
+    exchange = exchange_report(R, ms_per_step)
+
+    # BASELINE cfg3 (MSRVTT retrieval, GLOBAL batch 128 => 128 / N pairs per GPU) in the SAME N-rank run, with its own exchange report:
+    # the 4-pair headline is exchange-bound by construction (521 MB of gradients against a 2.2 ms step), cfg3 is the configuration the
+    # reference trains at.  `--cfg3-row` forces it on one rank (with --force-dp: the N > 1 code path on world-size-1 RCCL).
+    cfg3 = None
+    if (world > 1 or args.cfg3_row) and args.kind == "joint" and 128 // world != args.batch and 128 % world == 0:
+        b3 = 128 // world
+        try:
+            if gstep is not None:
+                gstep.flush()
+            R3 = build_runner(b3)
+            k3, w3 = min(args.steps, 10), min(args.warmup, 3)
+            pre3 = None if args.no_preheat else R3.preheat(R3.inputs, 5)
+            el3, last3 = R3.timed(R3.inputs, k3, w3)
+            ms3 = el3 / k3 * 1e3
+            if R3.gstep is not None:
+                R3.gstep.flush()
+            cfg3 = dict(name="cfg3_global_batch_128_in_this_run", per_gpu_batch=b3, global_batch=b3 * world, n_gpus=world,
+                        ms_per_step=round(ms3, 4), value=round(b3 * world / (el3 / k3), 2), unit="pairs/s", steps=k3, warmup=w3,
+                        preheat_block_ms=(pre3 or {}).get("block_ms"), graph_mode=(R3.gstep.mode if R3.gstep is not None else R3.mode),
+                        step_mfma_frac=round(b3 * gflop_row * 1e9 / (ms3 * 1e-3) / 2.5e15, 4), last_loss=round(last3, 6),
+                        exchange=exchange_report(R3, ms3), parity_case=("joint_b%d" % b3) if b3 in (16, 32, 64, 128) else "joint_b16")
+        except Exception as ex:      # noqa: BLE001 -- never at the price of the headline line (a rank that hangs here meets the watchdog)
+            cfg3 = dict(name="cfg3_global_batch_128_in_this_run", per_gpu_batch=b3, error="%s: %s" % (type(ex).__name__, str(ex)[-300:]))
     if rank == 0:
         names = dict(joint=("video-text pairs/sec (retrieval finetune, 48x48)", "YouCookII-shape retrieval finetune (FT-Joint) training step: BERT-base text "
                             "encoder (12 L) + 6-layer visual encoder"),
@@ -681,13 +923,21 @@ def main():
                                host_inputs=bool(args.host_inputs), exchange=exchange, params=n_params,
                                last_loss=round(last, 6), ab_overrides=_uab.overrides()),
                    preheat=pre, pcie_inclusive=pcie, roofline=roofline, cpu_baseline=None)
+    if rank == 0 and cfg3 is not None:
+        out["other_configs"] = [cfg3]
+    wd.disarm()
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0 and world == 1 and not args.child and not args.no_others and args.kind == "joint" and not args.force_dp:
         try:
-            out["other_configs"] = other_configs(args)
+            out["other_configs"] = out.get("other_configs", []) + other_configs(args)
         except Exception as ex:      # noqa: BLE001 -- never at the price of the headline line
-            out["other_configs"] = dict(error="%s: %s" % (type(ex).__name__, ex))
+            out["other_configs"] = out.get("other_configs", []) + [dict(error="%s: %s" % (type(ex).__name__, ex))]
+    if rank == 0 and world == 1 and not args.child and not args.no_extras and not args.force_dp:
+        try:
+            out["parity"] = parity_leg(args.batch, args.kind, args.dtype)
+        except Exception as ex:      # noqa: BLE001
+            out["parity"] = dict(error="%s: %s" % (type(ex).__name__, ex))
     if rank == 0 and world == 1 and not args.child and not args.no_cpu_baseline and args.kind == "joint":
         # after every GPU measurement (round 3 ran it first: ~25 s of idle GPU in front of the timed steps)
         try:

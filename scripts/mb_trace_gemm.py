@@ -101,6 +101,10 @@ def run(name, launch, split=0, reps=12, rot=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", default="192,768")
+    ap.add_argument("--warm", action="store_true",
+                    help="ONE copy of every weight operand instead of > 256 MB of rotating copies: each replay finds the weights where the "
+                         "previous replay left them (L2 / Infinity Cache) -- the upper bound of what prefetching the next launch's weights "
+                         "across the dependency edge can buy")
     a = ap.parse_args()
     H, I = 768, 3072
     print("device:", torch.cuda.get_device_name(0), " lib:", os.environ["UNIVL_LIB"])
@@ -118,7 +122,7 @@ def main():
         print("---- rows M = %d (split-K of the N = 768 products: %s)" % (M, splitk))
         # rotating weights: > 256 MB per family so that each replay reads them from HBM
         def pool(n, k):
-            cnt = max(2, int(300e6 // (n * k * 2)) + 1)
+            cnt = 1 if a.warm else max(2, int(300e6 // (n * k * 2)) + 1)
             return [torch.randn(n, k, device=DEV).to(bf) * 0.02 for _ in range(cnt)]
         x = torch.randn(M, H, device=DEV).to(bf)
         f = torch.randn(M, I, device=DEV).to(bf)
