@@ -37,7 +37,7 @@ typedef struct ihipStream_t* hipStream_t;
 
 const char* univl_last_error(void);
 int univl_version(void);
-/* sizeof of ABI struct #which (0 Gemm, 1 LayerNorm, 2 Attention, 3 EmbedText, 4 Pool, 5 Seg, 6 Adam) -- lets a
+/* sizeof of ABI struct #which (0 Gemm, 1 LayerNorm, 2 Attention, 3 EmbedText, 4 Pool, 5 Seg, 6 Adam, 7 VocabCE) -- lets a
  * foreign-language binding verify its struct mirrors at load time */
 int univl_struct_size(int which);
 /* number of CUs / name of the current device, for host-side launch heuristics; returns 0 or hipError_t */
@@ -361,6 +361,35 @@ int univl_simdense_bwd(const float* ds, const float* x, const float* w, int32_t 
  * label != ignore_index; dlogits (compute type, [rows, lddl]) = (softmax - onehot) / n_valid.  scratch2: 2 floats. */
 int univl_ce_loss(int32_t dtype, const float* logits, int64_t ld, const int64_t* labels, int32_t rows, int32_t V,
                   int32_t ignore_index, float* scratch2, float* loss, void* dlogits, int64_t lddl, hipStream_t stream);
+/* K16: the tied vocabulary classifier fused with an ONLINE log-softmax cross entropy -- BertLMPredictionHead.forward's last line
+ * (module_bert.py:327-330: h . E_word^T + bias; decoder copy module_decoder.py:180-183) and CrossEntropyLoss(ignore_index) on it
+ * (modeling.py:253, 275) without the [rows, V] logits ever existing in memory.
+ *   univl_vocab_ce_fwd: walks the product in 128 x 128 tiles; a tile's epilogue leaves one (max, sum exp(logit - max)) pair per row in
+ *     partial[row][column tile] and the label's logit in label_logit[row]; two small kernels fold them (fixed order: bit-reproducible)
+ *     into lse[rows], rowloss[rows], scratch2[0] = number of rows whose label != ignore_index, loss = mean over those rows (NaN if none).
+ *   univl_vocab_ce_bwd: the same product again; the epilogue stores dlogits[row, col] = (exp(logit - lse[row]) - [col == label]) *
+ *     gout / n_valid in the compute type (0 on ignored rows) -- the operand of the two backward products (dh = dlogits . E,
+ *     dE += dlogits^T . h), which are ordinary univl_gemm calls.  Call after univl_vocab_ce_fwd with the same descriptor.
+ * x [rows, K] and table [V, K] in the compute type, K-major, K a multiple of 64 (bf16) / 32 (fp32); slots >= ceil(V / 128);
+ * partial holds rows * slots * 2 floats; dlogits rows are lddl >= V elements apart (columns >= V are left untouched). */
+typedef struct UnivlVocabCE {
+    int32_t dtype, rows, V, K;
+    const void* x; int64_t ldx;
+    const void* table; int64_t ldt;
+    const float* bias;             /* [V] or null */
+    const int64_t* labels;         /* [rows] */
+    int32_t ignore_index, slots;
+    float* partial;                /* [rows, slots, 2] */
+    float* label_logit;            /* [rows] */
+    float* lse;                    /* [rows] */
+    float* rowloss;                /* [rows] */
+    float* scratch2;               /* [0] n_valid, [1] sum of the row losses */
+    float* loss;                   /* [1] */
+    const float* gout;             /* backward: upstream gradient of the loss, one float on the device; null = 1 */
+    void* dlogits; int64_t lddl;   /* backward output */
+} UnivlVocabCE;
+int univl_vocab_ce_fwd(const UnivlVocabCE* desc, hipStream_t stream);
+int univl_vocab_ce_bwd(const UnivlVocabCE* desc, hipStream_t stream);
 /* masked-frame NCE of UniVL._calculate_mfm_loss (modeling.py:285-297) on the [n,n] logits matrix */
 int univl_mfm_nce_loss(const float* logits, int64_t ld, const int64_t* vmask, const int64_t* labels, int32_t n,
                        float* scratch2, float* loss, float* dlogits, int64_t lddl, hipStream_t stream);

@@ -35,7 +35,11 @@ int main(int argc, char** argv) {
     // forward: a chain of small kernels, each third one followed by a streaming slice of the update (what rides in the forward products)
     for (int i = 0; i < nk; ++i) {
         hipLaunchKernelGGL(small_chain, dim3(64), dim3(256), 0, a, x, 1 << 14);
-        if (i % 3 == 0) { size_t lo = (NP / nk) * i; hipLaunchKernelGGL(stream_update, dim3(1024), dim3(256), 0, a, p + lo, g + lo, NP / nk * 3); }
+        if (i % 3 == 0) {
+            size_t lo = (NP / nk) * i, len = NP / nk * 3;
+            if (lo + len > NP) len = NP - lo;
+            hipLaunchKernelGGL(stream_update, dim3(1024), dim3(256), 0, a, p + lo, g + lo, len);
+        }
     }
     // backward: the chain again, with an exchange point every nk / nb kernels on the communication stream
     for (int i = 0, b = 0; i < nk; ++i) {

@@ -1351,6 +1351,63 @@ def test_ce_loss_with_ignore_index(dtype, V):
     assert math.isnan(float(loss))
 
 
+@pytest.mark.parametrize("rows,V", [(50, 1000), (192, 1002), (288, 30522)])       # 30522 = 238 full column tiles + 58 columns
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_vocab_ce_online_log_softmax_matches_the_materialised_path(dtype, rows, V):
+    """K16 (univl_vocab_ce_fwd / _bwd): h . E^T + bias -> CrossEntropyLoss(ignore_index=-1) (module_bert.py:327-330 + modeling.py:253)
+    with the statistics taken in the product's epilogue.  Against fp64 on the SAME (rounded) operands: loss, n_valid, every row's
+    log-sum-exp, dlogits = (softmax - onehot) * gout / n_valid, zero rows where the label is ignored, untouched padding columns, NaN when
+    no row counts; and against the two-step path (univl_gemm -> univl_ce_loss -> scale) of the same library."""
+    K = 768
+    ldv = (V + 7) // 8 * 8
+    x = gen(rows, K, seed=1).to(DEV, dtype)
+    table = (gen(V, K, seed=2, scale=0.06)).to(DEV, dtype)
+    bias = gen(V, seed=3, scale=0.5).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    labels = torch.randint(0, V, (rows,), generator=g)
+    labels[::5] = -1
+    labels[1], labels[2] = 0, V - 1
+    labels_d = labels.to(DEV)
+    dl = torch.full((rows, ldv), 7.0, device=DEV, dtype=dtype)
+    d, buf = ops.vocab_ce_desc(x, table, bias, labels_d, dl, V)
+    gout = torch.tensor([0.37], device=DEV)
+    ops.vocab_ce_fwd(d)
+    d.gout = gout.data_ptr()
+    ops.vocab_ce_bwd(d)
+    lr = (x.double().cpu() @ table.double().cpu().T + bias.double().cpu()).requires_grad_(True)
+    ref = O.cross_entropy_ignore(lr, labels)
+    (ref * 0.37).backward()
+    ot = 2e-6 if dtype == torch.float32 else 2e-6             # same operands, fp32 accumulation on both sides
+    assert abs(float(buf["loss"]) - float(ref)) < max(ot, 3e-6) * max(1.0, abs(float(ref))), (float(buf["loss"]), float(ref))
+    assert float(buf["scratch"][0]) == float((labels != -1).sum())
+    assert rel_err(buf["lse"], torch.logsumexp(lr.detach(), 1)) < 1e-6
+    assert rel_err(dl[:, :V].float(), lr.grad) < tol(dtype)
+    assert float(dl[::5, :V].float().abs().max()) == 0.0
+    if ldv > V:
+        assert float((dl[:, V:].float() - 7.0).abs().max()) == 0.0
+    # the two-step path of the same library on the same operands
+    logits = torch.zeros(rows, ldv, device=DEV)
+    ops.gemm(x, table, rows, V, K, out32=logits, bias=bias)
+    dl2 = torch.zeros(rows, ldv, device=DEV, dtype=dtype)
+    loss2, scr2 = torch.zeros(1, device=DEV), torch.zeros(2, device=DEV)
+    ops.ce_loss(logits, labels_d, V, scr2, loss2, dl2)
+    ops.scale_ct(dl2, gout)
+    assert abs(float(buf["loss"]) - float(loss2)) < 3e-6 * max(1.0, abs(float(loss2)))
+    # (bf16: the two-step path rounds twice -- after the 1 / n_valid of the loss kernel and after the scale pass -- K16 once)
+    assert rel_err(dl[:, :V].float(), dl2[:, :V].float().double().cpu()) < (2e-5 if dtype == torch.float32 else 1e-2)
+    # bit-reproducible: fixed-order folds everywhere
+    first = (buf["loss"].clone(), buf["lse"].clone(), dl.clone())
+    d.gout = None
+    ops.vocab_ce_fwd(d)
+    d.gout = gout.data_ptr()
+    ops.vocab_ce_bwd(d)
+    assert torch.equal(buf["loss"], first[0]) and torch.equal(buf["lse"], first[1]) and torch.equal(dl, first[2])
+    labels_d.fill_(-1)                                    # nothing to average over: NaN, like torch; dlogits all zero
+    ops.vocab_ce_fwd(d)
+    ops.vocab_ce_bwd(d)
+    assert math.isnan(float(buf["loss"])) and float(dl[:, :V].float().abs().max()) == 0.0
+
+
 def test_mfm_nce_loss():
     """_calculate_mfm_loss tail (modeling.py:285-297): pair mask * -1e8, diagonal log-softmax, masked-position mean."""
     B, F = 3, 8

@@ -38,6 +38,7 @@ KEYS = {
     "g256": (1, "256 x 256 8-phase body (csrc/gemm256.h) for the grouped weight gradients / single products it is picked for; 0: the older tiles"),
     "g256_min_rows": (1536, "token count (a multiple of 256) from which the plans drop the pair launches for separate dgrads + the grouped 256-body launch"),
     "gelu_pre_f32": (0, "A/B measurement: the FFN1 pre-activation saved for GELU' in fp32 instead of the compute type (encoder stacks)"),
+    "vocab_ce": (1, "K16: the vocabulary classifier with the online log-softmax CE in its epilogue (univl_vocab_ce_fwd / _bwd: no [tokens, 30522] logits in training); 0: product -> logits -> univl_ce_loss"),
     "vocab_dgrad_split": (1, "split-K of the vocabulary dgrad (caption / pretrain heads)"),
     "fused_sim": (1, "pooling + similarity + loss heads as fused launches up to 256 rows"),
     "dpos_gather_min": (32, "rows per position from which position-table gradients are gathered instead of scatter-added"),

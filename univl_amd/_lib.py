@@ -64,7 +64,13 @@ class Adam(C.Structure):
                 ("t_total", i32), ("seg_scalars", vp), ("schedule", i32), ("row_flags", vp), ("flag_seg", i32), ("row_len", i32)]
 
 
-_STRUCTS = [Gemm, LayerNorm, Attention, EmbedText, Pool, Seg, Adam]
+class VocabCE(C.Structure):
+    _fields_ = [("dtype", i32), ("rows", i32), ("V", i32), ("K", i32), ("x", vp), ("ldx", i64), ("table", vp), ("ldt", i64), ("bias", vp),
+                ("labels", vp), ("ignore_index", i32), ("slots", i32), ("partial", vp), ("label_logit", vp), ("lse", vp), ("rowloss", vp),
+                ("scratch2", vp), ("loss", vp), ("gout", vp), ("dlogits", vp), ("lddl", i64)]
+
+
+_STRUCTS = [Gemm, LayerNorm, Attention, EmbedText, Pool, Seg, Adam, VocabCE]
 _lib = None
 
 
@@ -87,7 +93,7 @@ def lib():
         n = L.univl_struct_size(k)
         if n != C.sizeof(st):
             raise RuntimeError("ABI mismatch for %s: library %d bytes, ctypes %d" % (st.__name__, n, C.sizeof(st)))
-    for name in ("univl_gemm", "univl_layernorm_fwd", "univl_layernorm_bwd", "univl_attention_fwd",
+    for name in ("univl_vocab_ce_fwd", "univl_vocab_ce_bwd", "univl_gemm", "univl_layernorm_fwd", "univl_layernorm_bwd", "univl_attention_fwd",
                  "univl_attention_bwd", "univl_embed_text_fwd", "univl_embed_text_bwd", "univl_pool_fwd",
                  "univl_pool_bwd", "univl_bert_adam"):
         getattr(L, name).argtypes = [vp, vp]
@@ -170,7 +176,7 @@ EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_dev
             "univl_embed_text_fwd", "univl_embed_text_bwd", "univl_embed_scatter", "univl_rows_gather_sum", "univl_rows_zero", "univl_rows_append",
             "univl_rows_sumsq", "univl_zero_many", "univl_copy_many", "univl_pool_fwd", "univl_pool_bwd", "univl_pool_pair_fwd", "univl_pool_pair_bwd",
             "univl_maxmargin_loss", "univl_crossen_loss", "univl_milnce_loss", "univl_rank_counts", "univl_gather_rows", "univl_log_softmax_rows", "univl_scale_by_device_scalar", "univl_pair_concat_fwd", "univl_pair_concat_bwd", "univl_postype_fwd", "univl_postype_bwd", "univl_tanh_fwd",
-            "univl_tanh_bwd", "univl_gelu_bwd", "univl_colsum", "univl_scale_ct_by_device_scalar", "univl_simdense_fwd", "univl_simdense_bwd", "univl_ce_loss", "univl_mfm_nce_loss", "univl_grad_sumsq", "univl_sumsq_finish",
+            "univl_tanh_bwd", "univl_gelu_bwd", "univl_colsum", "univl_scale_ct_by_device_scalar", "univl_simdense_fwd", "univl_simdense_bwd", "univl_ce_loss", "univl_vocab_ce_fwd", "univl_vocab_ce_bwd", "univl_mfm_nce_loss", "univl_grad_sumsq", "univl_sumsq_finish",
             "univl_clip_coef", "univl_scale_grads", "univl_bert_adam", "univl_bert_adam_range", "univl_cast_bf16", "univl_cast_f32", "univl_bump_counter", "univl_probe_layouts", "univl_stamp"]
 
 

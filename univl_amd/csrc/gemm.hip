@@ -959,6 +959,7 @@ __device__ __forceinline__ void gemm_acc_only(const T* A, long lda, const T* B, 
     }
 }
 
+#include "vocab_ce.h"
 #include "attn_body.h"
 
 struct AttnFusedArgs {
@@ -1842,6 +1843,51 @@ extern "C" int univl_gemm_rider_prime(hipStream_t stream) {
     univl_allow_lds(gemm_ln_kernel<true>, RIDER_SMEM, done_nt);
     univl_allow_lds(gemm_ln_kernel<false>, RIDER_SMEM, done_t);
     return UNIVL_OK;
+}
+
+static int vocab_ce_prepare(const UnivlVocabCE* d, VocabCeArgs& a, const char* who, bool bwd) {
+    UNIVL_CHECK_ARG(d != nullptr, UNIVL_EINVAL, "%s: null descriptor", who);
+    UNIVL_CHECK_ARG(d->dtype == UNIVL_F32 || d->dtype == UNIVL_BF16, UNIVL_EUNSUPPORTED, "%s: dtype %d", who, d->dtype);
+    const int bk = d->dtype == UNIVL_BF16 ? 64 : 32;
+    UNIVL_CHECK_ARG(d->rows > 0 && d->V > 0 && d->K > 0 && d->K % bk == 0, UNIVL_EINVAL, "%s: rows %d V %d K %d (K must be a multiple of %d)", who,
+                    d->rows, d->V, d->K, bk);
+    UNIVL_CHECK_ARG(d->x && d->table && d->labels && d->partial && d->label_logit && d->lse && d->rowloss && d->scratch2 && d->loss, UNIVL_EINVAL,
+                    "%s: null buffer", who);
+    UNIVL_CHECK_ARG(d->ldx >= d->K && d->ldt >= d->K && d->slots >= (d->V + 127) / 128, UNIVL_EINVAL, "%s: ldx %ld ldt %ld slots %d", who, (long)d->ldx,
+                    (long)d->ldt, d->slots);
+    const int al = d->dtype == UNIVL_BF16 ? 8 : 4;      // 16-byte rows for the LDS-DMA
+    UNIVL_CHECK_ARG(d->ldx % al == 0 && d->ldt % al == 0 && ((uintptr_t)d->x & 15) == 0 && ((uintptr_t)d->table & 15) == 0, UNIVL_EINVAL,
+                    "%s: operands must be 16-byte aligned with 16-byte row pitches", who);
+    if (bwd) UNIVL_CHECK_ARG(d->dlogits && d->lddl >= d->V, UNIVL_EINVAL, "%s: dlogits %p lddl %ld", who, d->dlogits, (long)d->lddl);
+    a.X = d->x; a.ldx = d->ldx; a.E = d->table; a.lde = d->ldt; a.bias = d->bias;
+    a.rows = d->rows; a.V = d->V; a.K = d->K;
+    a.labels = d->labels; a.ignore = d->ignore_index;
+    a.partial = d->partial; a.slots = d->slots; a.label_logit = d->label_logit;
+    a.lse = d->lse; a.scal = d->scratch2; a.gout = d->gout; a.dl = d->dlogits; a.lddl = d->lddl;
+    a.nx = (d->V + 127) / 128; a.ny = (d->rows + 127) / 128;
+    return UNIVL_OK;
+}
+
+extern "C" int univl_vocab_ce_fwd(const UnivlVocabCE* d, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    VocabCeArgs a;
+    const int rc = vocab_ce_prepare(d, a, "univl_vocab_ce_fwd", false);
+    if (rc != UNIVL_OK) return rc;
+    const int r2 = d->dtype == UNIVL_BF16 ? vocab_ce_launch<__bf16, 4>(a, false, stream) : vocab_ce_launch<float, 2>(a, false, stream);
+    if (r2 != UNIVL_OK) return r2;
+    hipLaunchKernelGGL(vocab_ce_rows_kernel, dim3((d->rows + 3) / 4), dim3(256), 0, stream, d->partial, d->slots, a.nx, d->label_logit, d->labels,
+                       d->ignore_index, d->rows, d->lse, d->rowloss);
+    hipLaunchKernelGGL(vocab_ce_loss_kernel, dim3(1), dim3(256), 0, stream, d->rowloss, d->labels, d->ignore_index, d->rows, d->scratch2, d->loss);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+extern "C" int univl_vocab_ce_bwd(const UnivlVocabCE* d, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    VocabCeArgs a;
+    const int rc = vocab_ce_prepare(d, a, "univl_vocab_ce_bwd", true);
+    if (rc != UNIVL_OK) return rc;
+    return d->dtype == UNIVL_BF16 ? vocab_ce_launch<__bf16, 4>(a, true, stream) : vocab_ce_launch<float, 2>(a, true, stream);
 }
 
 extern "C" int univl_gemm_group(const UnivlGemm* d, int n, hipStream_t stream) {

@@ -30,6 +30,7 @@ extern "C" int univl_struct_size(int which) {
         case 4: return (int)sizeof(UnivlPool);
         case 5: return (int)sizeof(UnivlSeg);
         case 6: return (int)sizeof(UnivlAdam);
+        case 7: return (int)sizeof(UnivlVocabCE);
         default: return -1;
     }
 }

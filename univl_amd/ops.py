@@ -415,6 +415,33 @@ def ce_loss(logits, labels, V, scratch2, loss, dlogits, ignore_index=-1):
                                         ignore_index, _p(scratch2), _p(loss), _p(dlogits), dlogits.stride(0), _stream()), "ce_loss")
 
 
+def vocab_ce_desc(x, table, bias, labels, dlogits, V, ignore_index=-1):
+    """K16 descriptor (include/univl_hip.h: UnivlVocabCE) + the buffers it owns: x [rows, K], table [V(+pad), K] in the compute type,
+    dlogits [rows, lddl] in the compute type.  Returns (desc, buffers) -- keep `buffers` alive as long as the descriptor is used."""
+    rows, K = x.shape
+    slots = (V + 127) // 128
+    dev = x.device
+    b = dict(partial=torch.empty(rows, slots, 2, device=dev), label_logit=torch.zeros(rows, device=dev), lse=torch.empty(rows, device=dev),
+             rowloss=torch.empty(rows, device=dev), scratch=torch.zeros(2, device=dev), loss=torch.zeros(1, device=dev),
+             keep=(x, table, bias, labels, dlogits))
+    d = _lib.VocabCE()
+    d.dtype, d.rows, d.V, d.K = dtype_code(x.dtype), rows, V, K
+    d.x, d.ldx, d.table, d.ldt = _p(x), x.stride(0), _p(table), table.stride(0)
+    d.bias, d.labels, d.ignore_index, d.slots = (_p(bias) if bias is not None else None), _p(labels), ignore_index, slots
+    d.partial, d.label_logit, d.lse, d.rowloss = _p(b["partial"]), _p(b["label_logit"]), _p(b["lse"]), _p(b["rowloss"])
+    d.scratch2, d.loss, d.gout = _p(b["scratch"]), _p(b["loss"]), None
+    d.dlogits, d.lddl = _p(dlogits), dlogits.stride(0)
+    return d, b
+
+
+def vocab_ce_fwd(desc):
+    _lib.check(_lib.lib().univl_vocab_ce_fwd(C.byref(desc), _stream()), "vocab_ce_fwd")
+
+
+def vocab_ce_bwd(desc):
+    _lib.check(_lib.lib().univl_vocab_ce_bwd(C.byref(desc), _stream()), "vocab_ce_bwd")
+
+
 def mfm_nce_loss(logits, vmask, labels, scratch2, loss, dlogits):
     n = logits.shape[0]
     _lib.check(_lib.lib().univl_mfm_nce_loss(_p(logits), logits.stride(0), _p(vmask), _p(labels), n, _p(scratch2), _p(loss),

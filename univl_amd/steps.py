@@ -438,11 +438,36 @@ class VocabHead:
         self.u, self.hy, self.hst = e(T, H, dtype=ct), e(T, H), e(T, 2)
         self.h32 = e(T, H)
         self.h16 = e(T, H, dtype=ct) if bf else self.h32
-        self.logits = e(T, self.ldv)
+        self._logits = None                      # materialised only where somebody reads them (evaluation / decoding, vocab_ce=0)
         self.dlogits = e(T, self.ldv, dtype=ct)
         self.labels = e(T, dtype=torch.int64)
         self.loss, self.scratch = e(1), e(2)
         self.dh, self.dg, self.du = e(T, H), e(T, H), e(T, H, dtype=ct)
+        # K16 (univl_vocab_ce_fwd / _bwd): per-row (max, sum exp) pairs of the 128-column tiles, the label's logit, the row's log-sum-exp
+        self.k16 = None
+        self.slots = (V + 127) // 128
+
+    @property
+    def logits(self):
+        if self._logits is None:
+            self._logits = self.cx.e(self.T, self.ldv)
+        return self._logits
+
+    def _k16_desc(self, x16, bias, table):
+        cx, T = self.cx, self.T
+        e = cx.e
+        self.k16 = k = dict(partial=e(T, self.slots, 2), label_logit=e(T), lse=e(T), rowloss=e(T))
+        d = _lib.VocabCE()
+        d.dtype, d.rows, d.V, d.K = cx.dt, T, self.V, H
+        d.x, d.ldx, d.table, d.ldt, d.bias = x16.data_ptr(), H, table.data_ptr(), H, bias.data_ptr()
+        d.labels, d.ignore_index, d.slots = self.labels.data_ptr(), -1, self.slots
+        d.partial, d.label_logit, d.lse, d.rowloss = (k["partial"].data_ptr(), k["label_logit"].data_ptr(), k["lse"].data_ptr(),
+                                                      k["rowloss"].data_ptr())
+        d.scratch2, d.loss = self.scratch.data_ptr(), self.loss.data_ptr()
+        d.gout, d.dlogits, d.lddl = None, self.dlogits.data_ptr(), self.ldv
+        k["desc"] = d
+        k["keep"] = (x16, bias, table)
+        return d
 
     def names(self):
         p = self.prefix
@@ -456,6 +481,11 @@ class VocabHead:
                                          aux=self.u, ldaux=H, gelu="fwd"), sm)
         fwd.add("univl_layernorm_fwd", ops.layernorm_desc(dt, T, H, x=self.hy, gamma=W32(n["lg"]), beta=W32(n["lb"]), y=self.hy,
                                                           stats=self.hst, out32=self.h32, out16=self.h16 if cx.bf else None), sm)
+        if with_loss and _ab.get("vocab_ce"):
+            # K16: the product's epilogue keeps the online log-softmax statistics; the [T, 30522] logits never exist (module_bert.py:327-330 +
+            # modeling.py:253 / 275 in one entry point); the backward recomputes the product into dlogits
+            fwd.add("univl_vocab_ce_fwd", self._k16_desc(self.h16, W32(n["bias"]), fl.wop(n["emb"])), sm)
+            return
         fwd.add("univl_gemm", _gemm_desc(dt, self.h16, H, fl.wop(n["emb"]), H, T, self.V, H, out32=self.logits, ldc=self.ldv,
                                          bias=W32(n["bias"])), sm)
         if with_loss:
@@ -465,7 +495,13 @@ class VocabHead:
         """dx32 receives the gradient wrt the head input (accumulated if accumulate_dx)."""
         cx, fl, dt, n, T, sm = self.cx, self.cx.fl, self.cx.dt, self.names(), self.T, self.sm
         W32, G = fl.w32, fl.g
-        bwd.add_callable(lambda: ops.scale_ct(self.dlogits, gout), sm)
+        if self.k16 is not None:
+            db = _lib.VocabCE.from_buffer_copy(self.k16["desc"])      # the forward's descriptor + the upstream gradient of this loss term
+            db.gout = gout.data_ptr()
+            self.k16["gout"] = gout
+            bwd.add("univl_vocab_ce_bwd", db, sm)
+        else:
+            bwd.add_callable(lambda: ops.scale_ct(self.dlogits, gout), sm)
         # dh = dlogits . E contracts over the 30522-word vocabulary with only (T / 64) x 12 output tiles: unsplit, each workgroup
         # walks 239 K steps alone (a ~240 us latency chain at T = 512).  Split over the vocabulary so that ~512 workgroups share it
         # (fp32 atomics into the pre-zeroed dh; one slice in deterministic mode).  UNIVL_VOCAB_DGRAD_SPLIT=0: unsplit.
