@@ -25,6 +25,11 @@ KEYS = {
     "splitk_tiles": (128, "split the contraction of the N = 768 products while the 64 x 64 output grid has fewer tiles than this"),
     "splitk_len": (384, "target slice depth of that split"),
     "splitk_maxwg": (512, "cap on tiles x slices of that split"),
+    "splitk_dgrad_maxwg": (0, "cap on tiles x slices of the dgrad half of a pair launch (0: splitk_maxwg) -- so that dgrad + weight-gradient tiles fit one round of resident slots"),
+    "splitk_target_wg": (180, "up to 48 output tiles (256 tokens): split the N = 768 products into round(target / tiles) slices of at least 256 (0: the splitk_len / splitk_maxwg policy of rounds 1-5)"),
+    "splitk_target_wg_big": (264, "the same from 49 tiles up to splitk_tiles"),
+    "ks_o_fwd": (0, "A/B: slices of the attention-output product (0: policy)"), "ks_ffn2_fwd": (0, "A/B: slices of the FFN2 forward product"),
+    "ks_ffn1_dgrad": (0, "A/B: slices of the FFN1 dgrad"), "ks_qkv_dgrad": (0, "A/B: slices of the QKV dgrad"),
     "splitk_mid": (1, "three-slice split of the deep (K >= 2304) N = 768 products at 128 .. 255 tiles"),
     "splitk_mid_tiles": (256, "upper tile bound of that regime"),
     "ln_fold": (1, "LayerNorm forward finished inside its product's launch (univl_gemm_ln) up to 512 tokens"),

@@ -813,14 +813,28 @@ class EncoderStack:
         self.zero_y = self.any_split or self.ln_fold
         self.zero_g = self.any_split or self.ln_fold_bwd
 
-    def ksplit_for(self, K):
+    def ksplit_for(self, K, dgrad=False, site=None):
         if self.splitk_mid:
             return 3 if K >= 2304 else 1
         if not self.splitk:
             return 1
+        if site is not None and _ab.get("ks_" + site):       # A/B: explicit slice count of one product of the layer
+            return int(_ab.get("ks_" + site))
+        tgt = _ab.get("splitk_target_wg") if self.tiles <= 48 else _ab.get("splitk_target_wg_big")
+        if tgt:
+            # Round 6: as many slices as bring tiles x slices to ~`tgt` workgroups, each at least 256 deep.  The rule of rounds 1-5
+            # (384-deep slices, tiles x slices <= 512) dates from before the pair launches and the folds: at 192 tokens it made 288
+            # workgroups of every K = 3072 product -- with its 288 weight-gradient tiles and 8 column-sum roles the FFN1 pair launch then
+            # needs 584 resident slots of 512, i.e. a second round (phase trace, profiles/r06c_trace_gemm_192_weights_cold.txt: the
+            # dgrad half is done after 11.6 us, the launch after 17.9).  Measured per step, alternating on one box
+            # (profiles/r06h_ab_target_wg.txt, r06i_ab_target_wg2.txt): 4 pairs 2.210 -> 2.144 ms (-3.0 %) at 180; 8 pairs 2.652 -> 2.575
+            # (-2.9 %) at 252 - 288; 10 pairs -1.6 %; FT-Align -2.6 %; pretrain 9.37 -> 9.03 (-3.4 %); caption -0.8 %; 12 pairs +-0.
+            return max(1, min(int(tgt / self.tiles + 0.5), K // 256))
         per = _ab.get("splitk_len")
         ks = max(1, (K + per - 1) // per)
         cap = _ab.get("splitk_maxwg")
+        if dgrad and _ab.get("splitk_dgrad_maxwg"):
+            cap = min(cap, _ab.get("splitk_dgrad_maxwg"))
         while ks > 1 and self.tiles * ks > cap:
             ks -= 1
         return ks
@@ -865,11 +879,11 @@ class EncoderStack:
             qkv = ws["qkv"]
             qkv_desc = _gemm_desc(dt, x16, H, wqkv, H, T, 3 * H, H, out16=qkv, ldc=3 * H, bias=bqkv)
             o_desc = _gemm_desc(dt, ws["ctx"], H, fl.wop(nm["o_w"]), H, T, H, H, out32=ws["y1"], ldc=H,
-                                bias=fl.w32(nm["o_b"]), ksplit=self.ksplit_for(H))
+                                bias=fl.w32(nm["o_b"]), ksplit=self.ksplit_for(H, site="o_fwd"))
             f1_desc = _gemm_desc(dt, ws["a16"], H, fl.wop(nm["w1"]), H, T, I, H, out16=ws["f"], ldc=I,
                                  bias=fl.w32(nm["b1"]), aux=ws["u"], ldaux=I, gelu="fwd", aux_f32=self.u_f32)
             f2_desc = _gemm_desc(dt, ws["f"], I, fl.wop(nm["w2"]), I, T, H, I, out32=ws["y2"], ldc=H,
-                                 bias=fl.w32(nm["b2"]), ksplit=self.ksplit_for(I))
+                                 bias=fl.w32(nm["b2"]), ksplit=self.ksplit_for(I, site="ffn2_fwd"))
             attn_f = ops.attention_desc(
                 dt, B, self.NH, S, S, (qkv, 0), 3 * H, (qkv, H), 3 * H, (qkv, 2 * H), 3 * H, ws["ctx"], H, ws["lse"],
                 key_mask=self.key_mask, p_drop=p, offset=ws["off"][0], seed_dev=self.seed_dev)
@@ -1040,7 +1054,7 @@ class EncoderStack:
                 dgamma=fl.g(nm["ln1_g"]), dbeta=fl.g(nm["ln1_b"]), dbias=fl.g(nm["o_b"]), p_pre=p, off_pre=ws["off"][1],
                 seed_dev=self.seed_dev)
             if not emit(_gemm_desc(dt, s_du, I, fl.wop(nm["w1"]), H, T, H, I, trans_b=1, out32=da, ldc=H,
-                                   residual=dz, ldr=H, ksplit=self.ksplit_for(I)), w_ffn1, ln1, 0):
+                                   residual=dz, ldr=H, ksplit=self.ksplit_for(I, dgrad=True, site="ffn1_dgrad")), w_ffn1, ln1, 0):
                 ln_bwd(ln1)
             w_o = _gemm_desc(dt, s_dxd2, H, ws["ctx"], H, H, H, T, trans_a=1, trans_b=1,
                              out32=fl.g(nm["o_w"]), ldc=H, accumulate=gs.acc(nm["o_w"]), **wg_tile, **gs.sumsq_args(nm["o_w"], H, H))
@@ -1070,7 +1084,7 @@ class EncoderStack:
             dx = self.garena[l, 1]
             # ... the QKV dgrad feeds the output LayerNorm backward of the layer BELOW (next iteration)
             ln2_folded = emit(_gemm_desc(dt, dqkv, 3 * H, fl.wop_fused(nm["qkv_w"]), H, T, H, 3 * H, trans_b=1,
-                                         out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ksplit_for(3 * H)), w_qkv,
+                                         out32=dx, ldc=H, residual=dy, ldr=H, ksplit=self.ksplit_for(3 * H, dgrad=True, site="qkv_dgrad")), w_qkv,
                                       ln2_desc(l - 1, dx) if (l > 0 and not wgrads) else None, 1)   # (a deferred weight gradient of this layer still reads s_dxd, which the folded LayerNorm overwrites)
             # the layer's four weight-gradient GEMMs only consume tensors the chain above produced (dxd, du, dxd2, dqkv
             # are distinct buffers): one grouped launch, after which the scratch may be reused by the next layer
