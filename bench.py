@@ -780,7 +780,7 @@ def main():
             import glob
             import hashlib
             hs = hashlib.sha256()
-            for name in ("gemm.hip", "gemm256.h", "attn_body.h", "common.h"):
+            for name in ("gemm.hip", "gemm256.h", "attn_body.h", "vocab_ce.h", "common.h"):
                 hs.update(open(os.path.join(ROOT, "univl_amd", "csrc", name), "rb").read())
             for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_pmc.json")), reverse=True):
                 try:

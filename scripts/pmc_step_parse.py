@@ -75,7 +75,7 @@ def main(fetch_dir, write_dir, mfma_dir, elements, steps, out):
     import hashlib, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for name in ("gemm.hip", "gemm256.h", "attn_body.h", "common.h"):
+    for name in ("gemm.hip", "gemm256.h", "attn_body.h", "vocab_ce.h", "common.h"):
         h.update(open(os.path.join(root, "univl_amd", "csrc", name), "rb").read())
     res["kernel_source_sha16"] = h.hexdigest()[:16]
     json.dump(res, open(out, "w"), indent=1)

@@ -206,7 +206,7 @@ def _worker_nccl(port, q):
         def train(dp, graphed, capture=True):
             model, args, kw = _model_and_batch(0, ROWS)
             if dp:
-                os.environ["UNIVL_AB"] = "dp_capture=%d" % (1 if capture else 0)
+                model.dp_capture = capture            # the operational switch a training process has
                 model.enable_data_parallel(force=True)
                 assert model._reducer is not None and model._reducer._avg and model._reducer.world == 1
                 assert model._reducer.capturable == capture

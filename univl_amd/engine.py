@@ -815,7 +815,7 @@ class EncoderStack:
 
     def ksplit_for(self, K, dgrad=False, site=None):
         if self.splitk_mid:
-            return 3 if K >= 2304 else 1
+            return int(_ab.get("splitk_mid_ks")) if K >= 2304 else int(_ab.get("splitk_mid_ks_768"))
         if not self.splitk:
             return 1
         if site is not None and _ab.get("ks_" + site):       # A/B: explicit slice count of one product of the layer
