@@ -31,7 +31,8 @@ KEYS = {
     "ks_o_fwd": (0, "A/B: slices of the attention-output product (0: policy)"), "ks_ffn2_fwd": (0, "A/B: slices of the FFN2 forward product"),
     "ks_ffn1_dgrad": (0, "A/B: slices of the FFN1 dgrad"), "ks_qkv_dgrad": (0, "A/B: slices of the QKV dgrad"),
     "splitk_mid": (1, "three-slice split of the deep (K >= 2304) N = 768 products at 128 .. 255 tiles"),
-    "splitk_mid_ks": (3, "slices of the deep (K >= 2304) N = 768 products in the splitk_mid regime"),
+    "splitk_mid_ks": (3, "slices of the deep (K >= 2304) N = 768 products in the splitk_mid regime up to 160 tiles"),
+    "splitk_mid_ks_big": (2, "... from 161 tiles on"),
     "splitk_mid_ks_768": (1, "slices of the K = 768 N = 768 products in the splitk_mid regime"),
     "splitk_mid_tiles": (256, "upper tile bound of that regime"),
     "ln_fold": (1, "LayerNorm forward finished inside its product's launch (univl_gemm_ln) up to 512 tokens"),

@@ -815,7 +815,10 @@ class EncoderStack:
 
     def ksplit_for(self, K, dgrad=False, site=None):
         if self.splitk_mid:
-            return int(_ab.get("splitk_mid_ks")) if K >= 2304 else int(_ab.get("splitk_mid_ks_768"))
+            # round 6 (profiles/r06k_ab_splitk_mid.txt, r06l_ab_splitk_mid_tiles.txt): three slices up to 160 tiles (16 pairs: 3.26 vs 3.29 ms
+            # with two), two beyond (20 pairs 3.575 vs 3.626, 24 pairs 3.94 vs 4.05, 28 pairs 4.49 vs 4.60); K = 768 stays whole
+            deep = int(_ab.get("splitk_mid_ks")) if self.tiles <= 160 else int(_ab.get("splitk_mid_ks_big"))
+            return deep if K >= 2304 else int(_ab.get("splitk_mid_ks_768"))
         if not self.splitk:
             return 1
         if site is not None and _ab.get("ks_" + site):       # A/B: explicit slice count of one product of the layer
