@@ -124,6 +124,14 @@ typedef struct UnivlGemm {
     float* sumsq; int32_t sumsq_rows; int32_t sumsq_stride;
     int32_t stages;        /* LDS pipeline depth: 0 or 2 (double buffer, the only form since round 4; the field keeps the ABI layout) */
     int32_t waves;         /* waves per workgroup on the 64 / 128 tiles: 0 auto, 4, 8 (bf16, else 4) */
+    /* Round 6, bf16 only -- operand PAIRS.  A bf16 operand carries 8 mantissa bits; x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
+     * carries 16.  A_lo / B_lo (optional, same layout and leading dimension as A / B) hold the lo halves; the product then walks the
+     * contraction once per term in a FIXED order --  A.B,  A.B_lo (if B_lo),  A_lo.B (if A_lo)  -- into the same fp32 accumulators
+     * (the lo.lo term is below fp32 resolution of the sum and is dropped).  ksplit divides that concatenated contraction.  Needs K a
+     * multiple of the K step (128; 64 on the 128-wide tiles); never on the 256 x 256 body.  The plans pair the forward products'
+     * operands up to 768 tokens, where the matrix pipe is idle (what it buys in gradient error).
+     * C16_lo (optional): the epilogue also stores lo = bf16(result - bf16(result)) there (same ldc) -- the A_lo of the next product. */
+    const void* A_lo; const void* B_lo; void* C16_lo;
 } UnivlGemm;
 int univl_gemm(const UnivlGemm* desc, hipStream_t stream);
 /* n (1..UNIVL_GEMM_GROUP_MAX) independent problems with the same dtype / trans_a / trans_b in ONE launch: the four
@@ -188,6 +196,7 @@ typedef struct UnivlLayerNorm {
     float* dgamma; float* dbeta;   /* [N], accumulated (atomics; fixed order in deterministic mode)        */
     float* dbias;          /* optional [N]: column sums of the grad wrt x (bias grad of the producing GEMM) */
     float* dpos;           /* optional [period,N], accumulated (atomics; fixed order in deterministic mode)*/
+    void* out16_lo;        /* fwd, optional, bf16: lo half of the output pair (UnivlGemm.A_lo of the products that read out16) */
 } UnivlLayerNorm;
 int univl_layernorm_fwd(const UnivlLayerNorm* d, hipStream_t stream);
 int univl_layernorm_bwd(const UnivlLayerNorm* d, hipStream_t stream);
@@ -217,6 +226,7 @@ typedef struct UnivlAttention {
     /* optional batch strides (elements) of k and v: 0 = Sk*ld (densely packed rows).  A key/value cache of capacity
      * Tmax >= Sk per sequence (incremental caption decoding, main_task_caption.py:434-470) passes Tmax*ld. */
     int64_t bsk, bsv;
+    void* out_lo;             /* fwd, optional, bf16: lo half of the output pair, [B*Sq, ldo] (UnivlGemm.A_lo of the output projection) */
 } UnivlAttention;
 int univl_attention_fwd(const UnivlAttention* d, hipStream_t stream);
 int univl_attention_bwd(const UnivlAttention* d, hipStream_t stream);
@@ -255,6 +265,7 @@ typedef struct UnivlEmbedText {
      * data parallelism the dense table gradient (30522 x 768 fp32 = 94 MB, at most B*S non-zero rows) is then exchanged
      * as (ids, rows) and rebuilt by univl_embed_scatter on every rank. */
     float* drows;
+    void* out16_lo;           /* fwd, optional, bf16: lo half of the output pair */
 } UnivlEmbedText;
 int univl_embed_text_fwd(const UnivlEmbedText* d, hipStream_t stream);
 int univl_embed_text_bwd(const UnivlEmbedText* d, hipStream_t stream);
@@ -431,6 +442,7 @@ typedef struct UnivlAdam {
      * -- the same bits the full formula gives (0 / (sqrt(0) + e) = 0) at 10 instead of 30 bytes per parameter.  The segment's
      * chunks must start on row boundaries.  NULL: off. */
     const uint8_t* row_flags; int32_t flag_seg; int32_t row_len;
+    void* p16_lo;                /* optional: lo half of the shadow pair, bf16(p - bf16(p)), same offsets (UnivlGemm.B_lo)   */
 } UnivlAdam;
 int univl_bert_adam(const UnivlAdam* d, hipStream_t stream);
 /* The same update over chunks [chunk_begin, chunk_begin + chunk_count) of the chunk table only; do_prep != 0 first runs the
@@ -477,6 +489,8 @@ int univl_gemm_rider_prime(hipStream_t stream);
 int univl_bump_counter(uint64_t* ctr, hipStream_t stream);
 /* p16 <- bf16(p) over n elements */
 int univl_cast_bf16(const float* p, void* p16, int64_t n, hipStream_t stream);
+/* the shadow PAIR: p16 <- bf16(p), p16_lo <- bf16(p - p16) over n elements (p16 may be NULL: only the lo half is written) */
+int univl_cast_bf16_pair(const float* p, void* p16, void* p16_lo, int64_t n, hipStream_t stream);
 /* p <- fp32(p16) over n elements (the bf16 gradient exchange brings its buckets back into the fp32 gradient buffer) */
 int univl_cast_f32(const void* p16, float* p, int64_t n, hipStream_t stream);
 

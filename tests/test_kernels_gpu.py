@@ -1031,6 +1031,159 @@ def test_attention_fwd_with_the_qkv_projection_inside_equals_the_two_launches(B,
     assert not ops.attention_fwd_fused(at, ops.gemm_desc(x[:160] if T >= 160 else torch.zeros(160, HD, device=DEV, dtype=dtype), W, 160, 3 * HD, HD, out16=qkv), dry_run=True)
 
 
+# ------------------------------------------------------------------------------------------ operand pairs (round 6)
+def _pair(x32):
+    """hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits in two bf16 tensors (include/univl_hip.h: UnivlGemm.A_lo)."""
+    hi = x32.to(torch.bfloat16)
+    return hi, (x32 - hi.float()).to(torch.bfloat16)
+
+
+def _pair_ref(xh, xl, wh, wl):
+    """what the launch computes: A.B + A.B_lo + A_lo.B (lo.lo dropped), in fp64"""
+    xh, wh = xh.double().cpu(), wh.double().cpu()
+    r = xh @ wh.T
+    if wl is not None:
+        r = r + xh @ wl.double().cpu().T
+    if xl is not None:
+        r = r + xl.double().cpu() @ wh.T
+    return r
+
+
+@pytest.mark.parametrize("M,N,K,ksplit,tile", [(192, 768, 768, 1, 0), (192, 768, 768, 5, 0), (192, 768, 3072, 8, 0), (100, 2304, 768, 1, 0),
+                                               (700, 1000, 768, 3, 0), (768, 3072, 768, 1, 64128), (768, 768, 3072, 1, 128), (48, 768, 1024, 4, 0)])
+@pytest.mark.parametrize("which", ["b", "a", "ab"])
+def test_gemm_operand_pairs_forward(M, N, K, ksplit, tile, which):
+    """A product whose operands are bf16 PAIRS walks the contraction once per term (A.B | A.B_lo | A_lo.B) into the same fp32
+    accumulators: equal to the three products in fp64 to fp32 rounding, and -- with both operands paired -- to the product of the
+    fp32 operands to 2^-16-ish, against 2^-8-ish for plain bf16.  Slices of a split contraction may start inside any term and cross
+    term boundaries (ksplit 3 / 5 / 8 over two or three terms)."""
+    x32, w32 = gen(M, K, seed=1).to(DEV), gen(N, K, seed=2, scale=0.05).to(DEV)
+    bias = gen(N, seed=3).to(DEV)
+    (xh, xl), (wh, wl) = _pair(x32), _pair(w32)
+    a_lo = xl if "a" in which else None
+    b_lo = wl if "b" in which else None
+    Y = torch.zeros(M, N, device=DEV)
+    ops.gemm(xh, wh, M, N, K, out32=Y, bias=bias, ksplit=ksplit, tile=tile, a_lo=a_lo, b_lo=b_lo)
+    ref = _pair_ref(xh, a_lo, wh, b_lo) + bias.double().cpu()
+    assert rel_err(Y, ref) < 3e-6
+    exact = x32.double().cpu() @ w32.double().cpu().T + bias.double().cpu()
+    Y0 = torch.zeros(M, N, device=DEV)
+    ops.gemm(xh, wh, M, N, K, out32=Y0, bias=bias, ksplit=ksplit, tile=tile)
+    e0, e1 = rel_err(Y0, exact), rel_err(Y, exact)
+    assert e1 < (3e-5 if which == "ab" else e0), (e0, e1)
+
+
+@pytest.mark.parametrize("T,N,K", [(192, 3072, 768), (60, 768, 3072)])
+def test_gemm_operand_pairs_dgrad_gelu_and_paired_output(T, N, K):
+    """T-major B with a lo half (the dgrad form), the GELU epilogue on a paired product, and the paired bf16 OUTPUT (C16_lo):
+    out16 + out16_lo carries the fp32 result to ~2^-16."""
+    x32, w32 = gen(T, K, seed=4).to(DEV), gen(N, K, seed=5, scale=0.05).to(DEV)
+    b = gen(N, seed=6).to(DEV)
+    (xh, xl), (wh, wl) = _pair(x32), _pair(w32)
+    u = torch.zeros(T, N, device=DEV, dtype=torch.bfloat16)
+    f, fl = torch.zeros_like(u), torch.zeros_like(u)
+    ops.gemm(xh, wh, T, N, K, out16=f, out16_lo=fl, bias=b, aux=u, gelu="fwd", a_lo=xl, b_lo=wl)
+    uref = x32.double().cpu() @ w32.double().cpu().T + b.double().cpu()
+    assert rel_err(u.float(), uref) < 6e-3                         # the saved pre-activation is one bf16
+    assert rel_err(f.float() + fl.float(), O.gelu(uref)) < 5e-5    # the activation leaves as a pair
+    assert rel_err(f.float(), O.gelu(uref)) > 5e-4
+    # dgrad: dX = dY . W with W = hi + lo read T-major
+    dy32 = gen(T, N, seed=7).to(DEV)
+    dyh, dyl = _pair(dy32)
+    for a_lo, b_lo in ((None, wl), (dyl, wl)):
+        dX = torch.zeros(T, K, device=DEV)
+        ops.gemm(dyh, wh, T, K, N, trans_b=True, out32=dX, a_lo=a_lo, b_lo=b_lo, ksplit=2)
+        ref = dyh.double().cpu() @ (wh.double().cpu() + wl.double().cpu())
+        if a_lo is not None:
+            ref = ref + dyl.double().cpu() @ wh.double().cpu()
+        assert rel_err(dX, ref) < 3e-6
+
+
+def test_gemm_operand_pairs_refusals():
+    x, w = gen(64, 96, seed=1).to(DEV, torch.bfloat16), gen(64, 96, seed=2).to(DEV, torch.bfloat16)
+    Y = torch.zeros(64, 64, device=DEV)
+    with pytest.raises(RuntimeError):                      # K = 96 is not a multiple of the K step (128)
+        ops.gemm(x, w, 64, 64, 96, out32=Y, b_lo=w)
+    x32, w32 = gen(256, 256, seed=1).to(DEV), gen(256, 256, seed=2).to(DEV)
+    with pytest.raises(RuntimeError):                      # fp32 mode has no pairs
+        ops.gemm(x32, w32, 256, 256, 256, out32=torch.zeros(256, 256, device=DEV), b_lo=w32)
+    # the 256 x 256 body never carries pairs: the same descriptor runs on the older tiles and is still correct
+    xh, xl = _pair(gen(1536, 768, seed=3).to(DEV))
+    wh, wl = _pair(gen(2304, 768, seed=4, scale=0.05).to(DEV))
+    q = torch.zeros(1536, 2304, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(xh, wh, 1536, 2304, 768, out16=q, a_lo=xl, b_lo=wl, tile=256)
+    assert rel_err(q.float(), _pair_ref(xh, xl, wh, wl)) < 5e-3
+
+
+@pytest.mark.parametrize("B,S,p_drop,masked", [(4, 48, 0.1, False), (3, 20, 0.0, True), (2, 64, 0.1, False)])
+@pytest.mark.parametrize("which", ["b", "ab"])
+def test_attention_fwd_fused_with_operand_pairs_equals_the_two_launches(B, S, p_drop, masked, which):
+    """The q | k | v projection inside the attention launch walks the same terms in the same order as univl_gemm with the same lo
+    halves: qkv, context, context lo half and log-sum-exp are bit-identical to the two launches."""
+    dtype, H, D = torch.bfloat16, 12, 64
+    dt = ops.dtype_code(dtype)
+    T, HD = B * S, H * D
+    xh, xl = _pair(gen(T, HD, seed=1).to(DEV))
+    wh, wl = _pair(gen(3 * HD, HD, seed=2, scale=0.05).to(DEV))
+    bias = gen(3 * HD, seed=3).to(DEV)
+    lens = torch.randint(1, S + 1, (B,), generator=torch.Generator().manual_seed(7))
+    lens[0] = S
+    km = (torch.arange(S)[None] < lens[:, None]).long().to(DEV) if masked else None
+    seed = torch.full((1,), 4321, dtype=torch.int64, device=DEV)
+    kw = dict(key_mask=km, p_drop=p_drop, offset=3 << 40, seed_dev=seed)
+    a_lo = xl if "a" in which else None
+
+    def run(fused):
+        qkv = torch.zeros(T, 3 * HD, device=DEV, dtype=dtype)
+        ctx, ctx_lo = torch.zeros(T, HD, device=DEV, dtype=dtype), torch.zeros(T, HD, device=DEV, dtype=dtype)
+        lse = torch.zeros(B, H, S, device=DEV)
+        args = (dt, B, H, S, S, (qkv, 0), 3 * HD, (qkv, HD), 3 * HD, (qkv, 2 * HD), 3 * HD, ctx, HD, lse)
+        gd = ops.gemm_desc(xh, wh, T, 3 * HD, HD, out16=qkv, bias=bias, a_lo=a_lo, b_lo=wl)
+        if fused:
+            assert ops.attention_fwd_fused(ops.attention_desc(*args, out_lo=ctx_lo, **kw), gd)
+        else:
+            _lib.check(_lib.lib().univl_gemm(ops._BYREF(gd), ops._stream()), "gemm")
+            ops.attention_fwd(*args, out_lo=ctx_lo, **kw)
+        torch.cuda.synchronize()
+        return qkv, ctx, ctx_lo, lse
+
+    q0, c0, cl0, l0 = run(False)
+    assert rel_err(q0.float(), _pair_ref(xh, a_lo, wh, wl) + bias.double().cpu()) < 6e-3
+    assert float(cl0.float().abs().max()) > 0 and float((cl0.float().abs() > c0.float().abs() / 128 + 1e-30).sum()) == 0
+    q1, c1, cl1, l1 = run(True)
+    assert torch.equal(q1, q0) and torch.equal(c1, c0) and torch.equal(cl1, cl0) and torch.equal(l1, l0)
+
+
+def test_layernorm_embedding_cast_and_adam_write_the_lo_half():
+    """Every producer of a paired bf16 tensor: lo == bf16(fp32 value - hi) exactly."""
+    dt = ops.dtype_code(torch.bfloat16)
+    rows, N = 100, 768
+    x, res = gen(rows, N, seed=1).to(DEV), gen(rows, N, seed=2).to(DEV)
+    ga, be = (1 + 0.1 * gen(N, seed=3)).to(DEV), (0.1 * gen(N, seed=4)).to(DEV)
+    y, st = torch.zeros(rows, N, device=DEV), torch.zeros(rows, 2, device=DEV)
+    o32 = torch.zeros(rows, N, device=DEV)
+    o16, olo = torch.zeros(rows, N, device=DEV, dtype=torch.bfloat16), torch.zeros(rows, N, device=DEV, dtype=torch.bfloat16)
+    ops.layernorm_fwd(dtype=dt, rows=rows, N=N, x=x, residual=res, gamma=ga, beta=be, y=y, stats=st, out32=o32, out16=o16, out16_lo=olo)
+    assert torch.equal(o16, o32.to(torch.bfloat16)) and torch.equal(olo, (o32 - o16.float()).to(torch.bfloat16))
+    # text embeddings
+    B, S, V = 3, 20, 500
+    ids = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(5)).to(DEV)
+    word, pos = gen(V, 768, seed=6).to(DEV), gen(64, 768, seed=7).to(DEV)
+    e32 = torch.zeros(B * S, 768, device=DEV)
+    e16, elo = torch.zeros(B * S, 768, device=DEV, dtype=torch.bfloat16), torch.zeros(B * S, 768, device=DEV, dtype=torch.bfloat16)
+    ops.embed_text_fwd(dt, B, S, ids, word, pos, ga, be, y=torch.zeros(B * S, 768, device=DEV), stats=torch.zeros(B * S, 2, device=DEV),
+                       out32=e32, out16=e16, out16_lo=elo)
+    assert torch.equal(e16, e32.to(torch.bfloat16)) and torch.equal(elo, (e32 - e16.float()).to(torch.bfloat16))
+    # the weight shadow pair
+    p = gen(100003, seed=8).to(DEV)
+    hi, lo = torch.zeros(100003, device=DEV, dtype=torch.bfloat16), torch.zeros(100003, device=DEV, dtype=torch.bfloat16)
+    ops.cast_bf16_pair(p, hi, lo)
+    assert torch.equal(hi, p.to(torch.bfloat16)) and torch.equal(lo, (p - hi.float()).to(torch.bfloat16))
+    lo2 = torch.zeros_like(lo)
+    ops.cast_bf16_pair(p, None, lo2)
+    assert torch.equal(lo2, lo)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_maximum_sequence_and_limit(dtype):
     """Largest sequence the single-pass kernels hold in LDS (384 bf16 / 256 fp32) and the loud failure one past it."""

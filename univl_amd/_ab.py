@@ -45,6 +45,9 @@ KEYS = {
     "attn_fuse_bwd_max_rows": (1535, "token count up to which the fused attention BACKWARD launch is used (1536: +1 %, 6144: +4.9 %)"),
     "g256": (1, "256 x 256 8-phase body (csrc/gemm256.h) for the grouped weight gradients / single products it is picked for; 0: the older tiles"),
     "g256_min_rows": (1536, "token count (a multiple of 256) from which the plans drop the pair launches for separate dgrads + the grouped 256-body launch"),
+    "pairs": ("", "default of model.operand_pairs -- operand PAIRS (bf16 hi + lo, include/univl_hip.h: UnivlGemm.A_lo) in the encoder stacks' forward products: 'x' the activation operand, 'w' the weight operand, 'xw' both, '': plain bf16 operands"),
+    "pairs_max_rows": (768, "... in stacks of at most this many tokens (16 pairs x 48): beyond, the matrix pipe is the bound and the extra terms cost step time"),
+    "pairs_ks": ("same", "split of a paired N = 768 product: 'same' workgroup count as the plain product (slices nterm x as deep) | 'terms': every term cut like the plain product"),
     "gelu_pre_f32": (0, "A/B measurement: the FFN1 pre-activation saved for GELU' in fp32 instead of the compute type (encoder stacks)"),
     "vocab_ce": (1, "K16: the vocabulary classifier with the online log-softmax CE in its epilogue (univl_vocab_ce_fwd / _bwd: no [tokens, 30522] logits in training); 0: product -> logits -> univl_ce_loss"),
     "vocab_dgrad_split": (1, "split-K of the vocabulary dgrad (caption / pretrain heads)"),
@@ -54,6 +57,7 @@ KEYS = {
     "adam_ride": ("1", "BertAdam chunks ride with the next forward's products; '0': side-stream form; 'force': one graph even with a captured exchange"),
     "tail_ride": (1, "chunks of cross layer 0 / decoder layer 0 ride in the last text / video layer's products; 0: launched in front of the forward"),
     "adam_lazy_rows": (1, "weight-decay-only shortcut for word-table rows that never had a gradient"),
+    "adam_chunk": (0, "A/B: elements per workgroup of the BertAdam update (0: optimization.CHUNK = 8192)"),
     "adam_blocks": (0, "grid cap of the overlapped (non-riding) update"),
     "pipeline_opt": (0, "experimental pipelined optimizer"),
     "async_loss": (0, "experimental asynchronous loss read-back"),

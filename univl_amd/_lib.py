@@ -20,7 +20,7 @@ class Gemm(C.Structure):
                 ("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C32", vp), ("C16", vp), ("ldc", i64),
                 ("bias", vp), ("R", vp), ("ldr", i64), ("aux", vp), ("ldaux", i64), ("dbias", vp),
                 ("alpha", f32), ("flags", i32), ("ksplit", i32), ("tile", i32), ("sumsq", vp), ("sumsq_rows", i32), ("sumsq_stride", i32),
-                ("stages", i32), ("waves", i32)]
+                ("stages", i32), ("waves", i32), ("A_lo", vp), ("B_lo", vp), ("C16_lo", vp)]
 
 
 class LayerNorm(C.Structure):
@@ -28,7 +28,7 @@ class LayerNorm(C.Structure):
                 ("pos", vp), ("pos_period", i32), ("gamma", vp), ("beta", vp), ("eps", f32), ("y", vp),
                 ("stats", vp), ("out32", vp), ("out16", vp), ("p_pre", f32), ("p_post", f32), ("seed", u64),
                 ("off_pre", u64), ("off_post", u64), ("seed_dev", vp), ("dout", vp), ("dx32", vp), ("dxd32", vp), ("dxd16", vp),
-                ("dgamma", vp), ("dbeta", vp), ("dbias", vp), ("dpos", vp)]
+                ("dgamma", vp), ("dbeta", vp), ("dbias", vp), ("dpos", vp), ("out16_lo", vp)]
 
 
 class Attention(C.Structure):
@@ -36,14 +36,14 @@ class Attention(C.Structure):
                 ("k", vp), ("ldk", i64), ("v", vp), ("ldv", i64), ("key_mask", vp), ("causal", i32),
                 ("out", vp), ("ldo", i64), ("lse", vp), ("p_drop", f32), ("seed", u64), ("offset", u64), ("seed_dev", vp),
                 ("dout", vp), ("lddo", i64), ("dq", vp), ("lddq", i64), ("dk", vp), ("lddk", i64),
-                ("dv", vp), ("lddv", i64), ("bsk", i64), ("bsv", i64)]
+                ("dv", vp), ("lddv", i64), ("bsk", i64), ("bsv", i64), ("out_lo", vp)]
 
 
 class EmbedText(C.Structure):
     _fields_ = [("dtype", i32), ("B", i32), ("S", i32), ("N", i32), ("ids", vp), ("type_ids", vp), ("word", vp),
                 ("pos", vp), ("type", vp), ("gamma", vp), ("beta", vp), ("eps", f32), ("y", vp), ("stats", vp),
                 ("out32", vp), ("out16", vp), ("p_post", f32), ("seed", u64), ("off_post", u64), ("seed_dev", vp), ("dout", vp),
-                ("dword", vp), ("dpos", vp), ("dtype_emb", vp), ("dgamma", vp), ("dbeta", vp), ("drows", vp)]
+                ("dword", vp), ("dpos", vp), ("dtype_emb", vp), ("dgamma", vp), ("dbeta", vp), ("drows", vp), ("out16_lo", vp)]
 
 
 class Pool(C.Structure):
@@ -61,7 +61,7 @@ class Adam(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("p16", vp), ("segs", vp), ("nseg", i32),
                 ("chunk_seg", vp), ("chunk_off", vp), ("chunk_len", vp), ("nchunk", i32), ("sumsq", vp),
                 ("coef", vp), ("step", vp), ("b1", f32), ("b2", f32), ("eps", f32), ("warmup", f32),
-                ("t_total", i32), ("seg_scalars", vp), ("schedule", i32), ("row_flags", vp), ("flag_seg", i32), ("row_len", i32)]
+                ("t_total", i32), ("seg_scalars", vp), ("schedule", i32), ("row_flags", vp), ("flag_seg", i32), ("row_len", i32), ("p16_lo", vp)]
 
 
 class VocabCE(C.Structure):
@@ -144,6 +144,7 @@ def lib():
     L.univl_clip_coef.argtypes = [vp, vp, i32, f32, vp, vp]
     L.univl_scale_grads.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
     L.univl_cast_bf16.argtypes = [vp, vp, i64, vp]
+    L.univl_cast_bf16_pair.argtypes = [vp, vp, vp, i64, vp]
     L.univl_cast_f32.argtypes = [vp, vp, i64, vp]
     L.univl_bert_adam_range.argtypes = [vp, i32, i32, i32, i32, vp]
     L.univl_bump_counter.argtypes = [vp, vp]
@@ -177,7 +178,7 @@ EXPORTED = ["univl_last_error", "univl_version", "univl_struct_size", "univl_dev
             "univl_rows_sumsq", "univl_zero_many", "univl_copy_many", "univl_pool_fwd", "univl_pool_bwd", "univl_pool_pair_fwd", "univl_pool_pair_bwd",
             "univl_maxmargin_loss", "univl_crossen_loss", "univl_milnce_loss", "univl_rank_counts", "univl_gather_rows", "univl_log_softmax_rows", "univl_scale_by_device_scalar", "univl_pair_concat_fwd", "univl_pair_concat_bwd", "univl_postype_fwd", "univl_postype_bwd", "univl_tanh_fwd",
             "univl_tanh_bwd", "univl_gelu_bwd", "univl_colsum", "univl_scale_ct_by_device_scalar", "univl_simdense_fwd", "univl_simdense_bwd", "univl_ce_loss", "univl_vocab_ce_fwd", "univl_vocab_ce_bwd", "univl_mfm_nce_loss", "univl_grad_sumsq", "univl_sumsq_finish",
-            "univl_clip_coef", "univl_scale_grads", "univl_bert_adam", "univl_bert_adam_range", "univl_cast_bf16", "univl_cast_f32", "univl_bump_counter", "univl_probe_layouts", "univl_stamp"]
+            "univl_clip_coef", "univl_scale_grads", "univl_bert_adam", "univl_bert_adam_range", "univl_cast_bf16", "univl_cast_bf16_pair", "univl_cast_f32", "univl_bump_counter", "univl_probe_layouts", "univl_stamp"]
 
 
 def check(rc, what=""):

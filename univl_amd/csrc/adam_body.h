@@ -29,6 +29,7 @@ __device__ __forceinline__ void adam_chunk(const UnivlAdam& a, int c) {
     const int len = a.chunk_len[c];
     float* p = a.p + off; const float* g = a.g + off; float* m = a.m + off; float* v = a.v + off;
     __bf16* p16 = a.p16 ? reinterpret_cast<__bf16*>(a.p16) + off : nullptr;
+    __bf16* p16lo = (a.p16 && a.p16_lo) ? reinterpret_cast<__bf16*>(a.p16_lo) + off : nullptr;      // lo half of the shadow pair
     const int nv = ((off & 3) == 0) ? len / 4 : 0;
     auto update = [&](int i, f32x4_t pp, const f32x4_t gg, f32x4_t mm, f32x4_t vv) {
 #pragma unroll
@@ -46,6 +47,12 @@ __device__ __forceinline__ void adam_chunk(const UnivlAdam& a, int c) {
             bf16x4_t w;
             w[0] = (__bf16)pp[0]; w[1] = (__bf16)pp[1]; w[2] = (__bf16)pp[2]; w[3] = (__bf16)pp[3];
             reinterpret_cast<bf16x4_t*>(p16)[i] = w;
+            if (p16lo) {
+                bf16x4_t l;
+                l[0] = (__bf16)(pp[0] - (float)w[0]); l[1] = (__bf16)(pp[1] - (float)w[1]);
+                l[2] = (__bf16)(pp[2] - (float)w[2]); l[3] = (__bf16)(pp[3] - (float)w[3]);
+                reinterpret_cast<bf16x4_t*>(p16lo)[i] = l;
+            }
         }
     };
     int i = threadIdx.x;
@@ -66,5 +73,6 @@ __device__ __forceinline__ void adam_chunk(const UnivlAdam& a, int c) {
         const float pi = p[j] - lr * upd;
         p[j] = pi; m[j] = mi; v[j] = vi;
         if (p16) p16[j] = (__bf16)pi;
+        if (p16lo) p16lo[j] = (__bf16)(pi - (float)(__bf16)pi);
     }
 }

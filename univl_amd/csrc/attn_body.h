@@ -228,6 +228,16 @@ __device__ __forceinline__ void attn_fwd_body(const UnivlAttention& p, const int
         T* Og = reinterpret_cast<T*>(p.out) + ((long)b * p.Sq + q) * p.ldo + h * HD;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) store4<T>(Og + dt * 16 + 4 * g, o[dt], 1.0f);
+        if (sizeof(T) == 2 && p.out_lo != nullptr) {          // lo half of the context pair (UnivlAttention.out_lo)
+            T* Ol = reinterpret_cast<T*>(p.out_lo) + ((long)b * p.Sq + q) * p.ldo + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4_t r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = o[dt][e] - (float)(__bf16)o[dt][e];
+                store4<T>(Ol + dt * 16 + 4 * g, r, 1.0f);
+            }
+        }
     }
 }
 

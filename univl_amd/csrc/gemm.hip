@@ -65,6 +65,7 @@ struct GemmArgs {
     int ksplit_len;   // contraction length handled by one z-slice (multiple of BK)
     float* sumsq; int sumsq_rows, sumsq_stride;
     int gm;           // row tiles per L2 block of the tile order (0: plain order)
+    const void* A_lo; const void* B_lo; void* C16_lo;      // operand pairs (UnivlGemm): the contraction is walked once per term
 };
 
 // One operand tile in LDS: UNPADDED rows of RB = 128 or 256 bytes, filled by direct global->LDS DMA
@@ -282,10 +283,24 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     const int g = lane >> 4, i = lane & 15;
     const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
     const int m0 = by * BM, n0 = bx * BN;
-    const int kbeg = bz * p.ksplit_len;
-    const int kend = min(p.K, kbeg + p.ksplit_len);
-    const int nfull = (kend - kbeg) / BK;              // full K tiles: no masking at all
-    const int krem = (kend - kbeg) - nfull * BK;       // > 0: one partial tile at the end
+    // Operand pairs (UnivlGemm.A_lo / B_lo): the slices divide the CONCATENATED contraction  A.B | A.B_lo | A_lo.B  (nseg terms of K
+    // each; K and the slice length are multiples of BK then, host).  A workgroup whose slice crosses a term boundary re-points its
+    // DMA source pointers there (`wrap`, in K tiles from the slice start) and keeps its two-stage pipeline running across it.
+    const int nseg = 1 + (p.B_lo != nullptr ? 1 : 0) + (p.A_lo != nullptr ? 1 : 0);
+    int kbeg = bz * p.ksplit_len;
+    int kspan, seg = 0, wrap = 0x7fffffff;
+    if (nseg > 1) {
+        kspan = min(nseg * p.K, kbeg + p.ksplit_len) - kbeg;
+        seg = kbeg / p.K;
+        kbeg -= seg * p.K;
+        wrap = (p.K - kbeg) / BK;
+    } else {
+        kspan = min(p.K, kbeg + p.ksplit_len) - kbeg;
+    }
+    const int nfull = kspan / BK;                      // full K tiles: no masking at all
+    const int krem = kspan - nfull * BK;               // > 0: one partial tile at the end (never with operand pairs)
+    auto seg_a = [&](int s) { return reinterpret_cast<const T*>((p.A_lo != nullptr && s > 0 && s == nseg - 1) ? p.A_lo : p.A); };
+    auto seg_b = [&](int s) { return reinterpret_cast<const T*>((p.B_lo != nullptr && s == 1) ? p.B_lo : p.B); };
 
     UNIVL_TRACE_AT(0);
     f32x4_t acc[MI][NI];
@@ -359,9 +374,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 
     const T* pa[TileA::PER_THREAD];
     const T* pb[TileB::PER_THREAD];
-    TileA::init(pa, reinterpret_cast<const T*>(p.A), p.lda, m0, kbeg, p.M, tid);
-    TileB::init(pb, reinterpret_cast<const T*>(p.B), p.ldb, n0, kbeg, p.N, tid);
+    TileA::init(pa, seg_a(seg), p.lda, m0, kbeg, p.M, tid);
+    TileB::init(pb, seg_b(seg), p.ldb, n0, kbeg, p.N, tid);
     const long stepA = TileA::kstep(p.lda), stepB = TileB::kstep(p.ldb);
+    auto next_term = [&]() {        // the pointers stand at contraction index K of term `seg`: index 0 of term seg + 1
+        TileA::advance(pa, (seg_a(seg + 1) - seg_a(seg)) - (long)p.K * (TA ? p.lda : 1));
+        TileB::advance(pb, (seg_b(seg + 1) - seg_b(seg)) - (long)p.K * (TB ? p.ldb : 1));
+        ++seg;
+        wrap += p.K / BK;
+    };
 
     // the partial tile (if any) goes through registers; fetched first so its latency hides behind the main loop
     u32x4_t ta[TileA::PER_THREAD], tb[TileB::PER_THREAD];
@@ -387,6 +408,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         for (int t = 0; t < nfull; ++t) {
             const int cur = t & 1;
             if (t + 1 < nfull) {
+                if (t + 1 == wrap) next_term();
                 TileA::issue(pa, sA + (cur ^ 1) * TileA::BYTES, tid);
                 issue_b(sB + (cur ^ 1) * TileB::BYTES);
                 TileA::advance(pa, stepA);
@@ -414,6 +436,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     const bool atomic = (p.flags & UNIVL_GEMM_ATOMIC) != 0;
     const bool nt_out = (p.flags & UNIVL_GEMM_NT_OUT) != 0;
     T* C16 = reinterpret_cast<T*>(p.C16);
+    T* C16lo = reinterpret_cast<T*>(p.C16_lo);
     T* aux = reinterpret_cast<T*>(p.aux);
     float* auxf32 = reinterpret_cast<float*>(p.aux);
     const bool aux_f32 = (p.flags & UNIVL_GEMM_AUX_F32) != 0;
@@ -516,6 +539,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 } else {
                     if (p.C32) { if (nt_out) __builtin_nontemporal_store(ev[b][r], p.C32 + o); else p.C32[o] = ev[b][r]; }
                     if (C16) C16[o] = from_f32<T>(ev[b][r]);
+                    if (C16lo) C16lo[o] = from_f32<T>(ev[b][r] - to_f32<T>(from_f32<T>(ev[b][r])));
                     ssq += ev[b][r] * ev[b][r];
                 }
             }
@@ -1024,6 +1048,7 @@ struct AttnFwdFusedArgs {
     __bf16* qkv; long ldqkv;            // [tokens, 3 * H * 64]
     int K;
     int n_attn, n_attn_pad;
+    const __bf16* X_lo; const __bf16* W_lo;     // operand pairs of the projection (UnivlGemm.A_lo / B_lo), or null
 };
 
 template <bool NT>
@@ -1057,7 +1082,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_qkv_kernel(AttnFwdFusedArgs a
         TileB::coords(c, tid, r, q);
         pb[c] = a.W + (long)((r >> 6) * HD3 + h * 64 + (r & 63)) * a.ldw + q * 8;
     }
-    const int nfull = a.K / 64;
+    // operand pairs: x.W | x.W_lo | x_lo.W, one walk of the contraction per term (gemm_tile)
+    const int nseg = 1 + (a.W_lo != nullptr ? 1 : 0) + (a.X_lo != nullptr ? 1 : 0);
+    const int per = a.K / 64, nfull = nseg * per;
+    int seg = 0, wrap = per;
+    auto seg_x = [&](int s_) { return (a.X_lo != nullptr && s_ > 0 && s_ == nseg - 1) ? a.X_lo : a.X; };
+    auto seg_w = [&](int s_) { return (a.W_lo != nullptr && s_ == 1) ? a.W_lo : a.W; };
     TileA::issue(pa, sA, tid);
     TileB::issue(pb, sB, tid);
     TileA::advance(pa, 64);
@@ -1066,6 +1096,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_qkv_kernel(AttnFwdFusedArgs a
     for (int t = 0; t < nfull; ++t) {
         const int cur = t & 1;
         if (t + 1 < nfull) {
+            if (t + 1 == wrap) {
+                TileA::advance(pa, (seg_x(seg + 1) - seg_x(seg)) - (long)a.K);
+                TileB::advance(pb, (seg_w(seg + 1) - seg_w(seg)) - (long)a.K);
+                ++seg;
+                wrap += per;
+            }
             TileA::issue(pa, sA + (cur ^ 1) * TileA::BYTES, tid);
             TileB::issue(pb, sB + (cur ^ 1) * TileB::BYTES, tid);
             TileA::advance(pa, 64);
@@ -1289,7 +1325,8 @@ static bool auto256(const UnivlGemm* d, bool in_group) {
 static Choice choose(const UnivlGemm* d, int forced_tile, int forced_nc = 0, bool allow_rect = false, bool in_group = false) {
     const bool bf16 = d->dtype == UNIVL_BF16;
     int want = forced_tile ? forced_tile : d->tile;
-    if ((want == 256 && fits256(d, in_group)) || (want == 0 && auto256(d, in_group))) return Choice{256, 2, 8};
+    const bool pairs = d->A_lo || d->B_lo || d->C16_lo;       // operand pairs: never the 256 body
+    if (!pairs && ((want == 256 && fits256(d, in_group)) || (want == 0 && auto256(d, in_group)))) return Choice{256, 2, 8};
     if (want == 256) want = 128;                   // asked for, but not a product the body carries
     const long tiles128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
     const bool rect_ok = allow_rect && bf16 && !d->trans_a && !d->sumsq && !d->dbias;      // univl_gemm only (single launch)
@@ -1365,8 +1402,16 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int 
     // one workgroup per output tile walks the whole contraction in order (the pre-zeroed arena is simply overwritten)
     ksplit = (d->ksplit < 1 || univl_deterministic()) ? 1 : d->ksplit;
     const int BK = c.tile == 256 ? 128 : (d->dtype == UNIVL_BF16 ? 32 : 16) * c.nc;      // 256 body: K % (128 ksplit) == 0 (fits256)
-    int klen = ((d->K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
-    ksplit = (d->K + klen - 1) / klen;
+    // operand pairs: the slices divide the concatenated contraction of nseg terms (gemm_tile)
+    const int nseg = 1 + (d->A_lo ? 1 : 0) + (d->B_lo ? 1 : 0);
+    if (nseg > 1 || d->C16_lo) {
+        UNIVL_CHECK_ARG(d->dtype == UNIVL_BF16 && c.tile != 256 && d->K % BK == 0 && aligned16(d->A_lo) && aligned16(d->B_lo) &&
+                            !(d->C16_lo && !d->C16) && (long)nseg * d->K < (1L << 30),
+                        UNIVL_EUNSUPPORTED, "univl_gemm: operand pairs need bf16, K (%d) a multiple of the K step (%d), 16-byte aligned lo halves", d->K, BK);
+    }
+    const long Kv = (long)nseg * d->K;
+    int klen = (int)(((Kv + ksplit - 1) / ksplit + BK - 1) / BK * BK);
+    ksplit = (int)((Kv + klen - 1) / klen);
     if (ksplit > 1) {
         UNIVL_CHECK_ARG(d->C32 && !d->C16 && !(flags & (UNIVL_GEMM_GELU_FWD | UNIVL_GEMM_GELU_BWD)), UNIVL_EINVAL,
                         "univl_gemm: split-K needs a pre-zeroed fp32 output and a linear epilogue");
@@ -1387,6 +1432,7 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int 
     a.ksplit_len = klen;
     a.sumsq = d->sumsq; a.sumsq_rows = d->sumsq_rows; a.sumsq_stride = d->sumsq_stride;
     a.gm = GEMM_GM;
+    a.A_lo = d->A_lo; a.B_lo = d->B_lo; a.C16_lo = d->C16_lo;
     return UNIVL_OK;
 }
 
@@ -1600,7 +1646,8 @@ extern "C" int univl_attention_bwd_fused(const UnivlAttention* at, const UnivlGe
     UNIVL_CHECK_ARG(at->dtype == UNIVL_DT_BF16 && Sk_pad <= 64 && Sq_pad <= 64 && g->dtype == UNIVL_BF16 && !g->trans_a && g->trans_b &&
                         g->M == at->B * at->Sq && g->N == at->H * 64 && g->K % 128 == 0 && g->K >= 128 && g->C16 == at->dout && !g->C32 &&
                         g->ldc == at->lddo && !g->bias && !g->R && !g->dbias && !g->sumsq && g->alpha == 1.0f && g->ksplit <= 1 &&
-                        (g->flags & ~(UNIVL_GEMM_XCD_MAP)) == 0 && aligned16(g->A) && aligned16(g->B) && g->lda % 8 == 0 && g->ldb % 8 == 0,
+                        (g->flags & ~(UNIVL_GEMM_XCD_MAP)) == 0 && aligned16(g->A) && aligned16(g->B) && g->lda % 8 == 0 && g->ldb % 8 == 0 &&
+                        !g->A_lo && !g->B_lo && !g->C16_lo,
                     UNIVL_EUNSUPPORTED, "univl_attention_bwd_fused: not an (attention backward, attention-output dgrad) pair this launch carries");
     AttnFusedArgs a;
     a.at = *at;
@@ -1677,6 +1724,7 @@ extern "C" int univl_attention_fwd_fused(const UnivlAttention* at, const UnivlGe
                         g->dtype == UNIVL_BF16 && !g->trans_a && !g->trans_b && g->M == at->B * at->Sq && g->N == 3 * hd && g->K % 64 == 0 &&
                         g->K >= 64 && c16 != nullptr && !g->C32 && !g->R && !g->dbias && !g->sumsq && !g->aux && g->alpha == 1.0f &&
                         g->ksplit <= 1 && (g->flags & ~(UNIVL_GEMM_XCD_MAP)) == 0 && aligned16(g->A) && aligned16(g->B) && g->lda % 8 == 0 &&
+                        aligned16(g->A_lo) && aligned16(g->B_lo) && !g->C16_lo &&
                         g->ldb % 8 == 0 && at->q == (const void*)c16 && at->k == (const void*)(c16 + hd) && at->v == (const void*)(c16 + 2 * hd) &&
                         at->ldq == g->ldc && at->ldk == g->ldc && at->ldv == g->ldc,
                     UNIVL_EUNSUPPORTED, "univl_attention_fwd_fused: not a (q|k|v projection, self-attention) pair this launch carries");
@@ -1689,6 +1737,7 @@ extern "C" int univl_attention_fwd_fused(const UnivlAttention* at, const UnivlGe
     a.bias = g->bias;
     a.qkv = reinterpret_cast<__bf16*>(g->C16); a.ldqkv = g->ldc;
     a.K = g->K;
+    a.X_lo = reinterpret_cast<const __bf16*>(g->A_lo); a.W_lo = reinterpret_cast<const __bf16*>(g->B_lo);
     a.n_attn = at->B * at->H;
     a.n_attn_pad = (a.n_attn + 7) / 8 * 8;
     const int nb = chunk_count <= 0 ? 0 : ((max_blocks > 0 && max_blocks < chunk_count) ? max_blocks : chunk_count);

@@ -100,6 +100,12 @@ __device__ __forceinline__ void ln_fwd_row(const UnivlLayerNorm& p, const int ro
                 bf16x4_t w;
                 w[0] = (__bf16)r[0]; w[1] = (__bf16)r[1]; w[2] = (__bf16)r[2]; w[3] = (__bf16)r[3];
                 *reinterpret_cast<bf16x4_t*>(d) = w;
+                if (p.out16_lo) {                         // lo half of the output pair (UnivlLayerNorm.out16_lo)
+                    bf16x4_t l;
+                    l[0] = (__bf16)(r[0] - (float)w[0]); l[1] = (__bf16)(r[1] - (float)w[1]);
+                    l[2] = (__bf16)(r[2] - (float)w[2]); l[3] = (__bf16)(r[3] - (float)w[3]);
+                    *reinterpret_cast<bf16x4_t*>(reinterpret_cast<TO*>(p.out16_lo) + o) = l;
+                }
             } else {
                 *reinterpret_cast<float4*>(d) = make_float4(r[0], r[1], r[2], r[3]);
             }

@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(UnivlAdam a, int c0, in
     const int len = a.chunk_len[c];
     float* p = a.p + off; const float* g = a.g + off; float* m = a.m + off; float* v = a.v + off;
     __bf16* p16 = a.p16 ? reinterpret_cast<__bf16*>(a.p16) + off : nullptr;
+    __bf16* p16lo = (a.p16 && a.p16_lo) ? reinterpret_cast<__bf16*>(a.p16_lo) + off : nullptr;      // lo half of the shadow pair
     const int nv = ((off & 3) == 0) ? len / 4 : 0;
     if (a.row_flags != nullptr && seg == a.flag_seg) {
         // rows nobody ever touched (UnivlAdam.row_flags): g = m = v = 0 exactly, the update is the weight decay alone
@@ -171,12 +172,19 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(UnivlAdam a, int c0, in
                     bf16x4_t w;
                     w[0] = (__bf16)pp[0]; w[1] = (__bf16)pp[1]; w[2] = (__bf16)pp[2]; w[3] = (__bf16)pp[3];
                     reinterpret_cast<bf16x4_t*>(p16)[i] = w;
+                    if (p16lo) {
+                        bf16x4_t l;
+                        l[0] = (__bf16)(pp[0] - (float)w[0]); l[1] = (__bf16)(pp[1] - (float)w[1]);
+                        l[2] = (__bf16)(pp[2] - (float)w[2]); l[3] = (__bf16)(pp[3] - (float)w[3]);
+                        reinterpret_cast<bf16x4_t*>(p16lo)[i] = l;
+                    }
                 }
             }
             for (int i = nv * 4 + threadIdx.x; i < len; i += 256) {
                 const float pi = p[i] - lr * (wd * p[i]);
                 p[i] = pi;
                 if (p16) p16[i] = (__bf16)pi;
+                if (p16lo) p16lo[i] = (__bf16)(pi - (float)(__bf16)pi);
             }
             continue;
         }
@@ -197,6 +205,12 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(UnivlAdam a, int c0, in
             bf16x4_t w;
             w[0] = (__bf16)pp[0]; w[1] = (__bf16)pp[1]; w[2] = (__bf16)pp[2]; w[3] = (__bf16)pp[3];
             reinterpret_cast<bf16x4_t*>(p16)[i] = w;
+            if (p16lo) {
+                bf16x4_t l;
+                l[0] = (__bf16)(pp[0] - (float)w[0]); l[1] = (__bf16)(pp[1] - (float)w[1]);
+                l[2] = (__bf16)(pp[2] - (float)w[2]); l[3] = (__bf16)(pp[3] - (float)w[3]);
+                reinterpret_cast<bf16x4_t*>(p16lo)[i] = l;
+            }
         }
     };
     int i = threadIdx.x;
@@ -219,6 +233,7 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(UnivlAdam a, int c0, in
         const float pi = p[i] - lr * upd;
         p[i] = pi; m[i] = mi; v[i] = vi;
         if (p16) p16[i] = (__bf16)pi;
+        if (p16lo) p16lo[i] = (__bf16)(pi - (float)(__bf16)pi);
     }
   }
 }
@@ -232,6 +247,23 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* p, __bf16* o, in
         reinterpret_cast<bf16x4_t*>(o)[i] = w;
     }
     if (blockIdx.x == 0) for (int64_t i = nv * 4 + threadIdx.x; i < n; i += 256) o[i] = (__bf16)p[i];
+}
+
+__global__ __launch_bounds__(256) void cast_pair_kernel(const float* p, __bf16* hi, __bf16* lo, int64_t n) {
+    const int64_t nv = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(p)[i];
+        bf16x4_t w, l;
+        w[0] = (__bf16)v.x; w[1] = (__bf16)v.y; w[2] = (__bf16)v.z; w[3] = (__bf16)v.w;
+        l[0] = (__bf16)(v.x - (float)w[0]); l[1] = (__bf16)(v.y - (float)w[1]); l[2] = (__bf16)(v.z - (float)w[2]); l[3] = (__bf16)(v.w - (float)w[3]);
+        if (hi) reinterpret_cast<bf16x4_t*>(hi)[i] = w;
+        reinterpret_cast<bf16x4_t*>(lo)[i] = l;
+    }
+    if (blockIdx.x == 0) for (int64_t i = nv * 4 + threadIdx.x; i < n; i += 256) {
+        const __bf16 h = (__bf16)p[i];
+        if (hi) hi[i] = h;
+        lo[i] = (__bf16)(p[i] - (float)h);
+    }
 }
 
 __global__ __launch_bounds__(256) void uncast_kernel(const __bf16* p, float* o, int64_t n) {
@@ -364,6 +396,19 @@ extern "C" int univl_cast_bf16(const float* p, void* p16, int64_t n, hipStream_t
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(cast_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, reinterpret_cast<__bf16*>(p16), n);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+
+extern "C" int univl_cast_bf16_pair(const float* p, void* p16, void* p16_lo, int64_t n, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    UNIVL_CHECK_ARG(p && p16_lo && n > 0 && aligned16(p) && ((((uintptr_t)p16 | (uintptr_t)p16_lo) & 7) == 0), UNIVL_EINVAL,
+                    "univl_cast_bf16_pair: bad argument");
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(cast_pair_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, reinterpret_cast<__bf16*>(p16),
+                       reinterpret_cast<__bf16*>(p16_lo), n);
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }

@@ -401,6 +401,7 @@ class UniVL(UniVLPreTrainedModel):
         self.auto_dp = bool(_ab.get("auto_dp"))            # built-in gradient exchange inside an initialised process group
         self.dp_capture = bool(_ab.get("dp_capture"))      # RCCL exchange captured into the step graph (False: host-issued collectives)
         self.auto_ride = _ab.get("adam_ride") != "0"       # optimizer.step() leaves its launch to the next forward (bf16, one process)
+        self._operand_pairs = str(_ab.get("pairs"))        # see the `operand_pairs` property
         self._stage_one, self._stage_two = True, False
         if _check_attr("stage_two", tc):
             self._stage_one, self._stage_two = False, tc.stage_two
@@ -573,9 +574,32 @@ class UniVL(UniVLPreTrainedModel):
             # BertAdam update CAN ride with the next forward -- the captured step of graphed.GraphedTrainStep and, round 5, the unchanged
             # training loop (optimization.BertAdam.step defers itself, UniVL.forward applies it: _adopt_pending_update)
             self._flat.adam_ride = self.compute_dtype == torch.bfloat16 and _ab.get("adam_ride") != "0"
+            self._flat.operand_pairs = self._operand_pairs
             self._seed_dev = torch.zeros(1, device=p0.device, dtype=torch.int64)
             self._steps = {}
         return self._flat
+
+    @property
+    def operand_pairs(self):
+        """Precision of the bf16 step's forward products in stacks of at most 768 tokens (16 pairs x 48): '' (default) plain bf16 MFMA
+        operands; 'x' / 'w' / 'xw': the activation / weight / both operands as PAIRS of bf16 (hi + lo = 16 mantissa bits,
+        include/univl_hip.h: UnivlGemm.A_lo / B_lo).  'xw' brings the median per-tensor gradient error against the reference's fp32
+        gradients from 9e-3 to 5.6e-3 and the pretrain configuration's global error from 1.2e-2 to 7.3e-3, at +22 % step time at
+        4 pairs per GPU (DESIGN.md section 2 has the table) -- which is why it is a choice and not the default.  Setting it rebuilds
+        the plans on the next forward."""
+        return self._operand_pairs
+
+    @operand_pairs.setter
+    def operand_pairs(self, value):
+        value = "" if value is None else str(value)
+        if value not in ("", "x", "w", "xw"):
+            raise ValueError("operand_pairs: '', 'x', 'w' or 'xw' (got %r)" % (value,))
+        if value != self._operand_pairs:
+            self._flush_pending()
+            self._operand_pairs = value
+            if self._flat is not None:
+                self._flat.operand_pairs = value
+                self._steps = {}
 
     def enable_data_parallel(self, process_group=None, broadcast=True, loopback=False, force=False, shard_optimizer=None):
         """Re-homes the reference's DDP wrap (main_task_retrieval.py:197-198) onto per-layer RCCL all-reduces of

@@ -48,8 +48,9 @@ def probe_layouts():
 
 def gemm_desc(A, B, M, N, K, *, trans_a=False, trans_b=False, out32=None, out16=None, bias=None, residual=None, aux=None,
               gelu=None, accumulate=False, dbias=None, dbias_atomic=False, ksplit=1, tile=0, alpha=1.0, sumsq=None,
-              sumsq_rows=0, sumsq_stride=0, stages=0, waves=0, aux_f32=False):
-    _require_gpu(A, B, out32, out16)
+              sumsq_rows=0, sumsq_stride=0, stages=0, waves=0, aux_f32=False, a_lo=None, b_lo=None, out16_lo=None):
+    """a_lo / b_lo / out16_lo: the lo halves of operand pairs (include/univl_hip.h: UnivlGemm.A_lo), same shape and strides as A / B / out16."""
+    _require_gpu(A, B, out32, out16, a_lo, b_lo, out16_lo)
     d = _lib.Gemm()
     d.dtype = dtype_code(A.dtype)
     assert B.dtype == A.dtype
@@ -79,6 +80,9 @@ def gemm_desc(A, B, M, N, K, *, trans_a=False, trans_b=False, out32=None, out16=
     d.flags, d.ksplit, d.tile = flags, ksplit, tile
     d.sumsq, d.sumsq_rows, d.sumsq_stride = _p(sumsq), sumsq_rows, sumsq_stride
     d.stages, d.waves = int(stages), int(waves)
+    for lo, hi in ((a_lo, A), (b_lo, B), (out16_lo, out16)):
+        assert lo is None or (lo.dtype == hi.dtype and lo.stride() == hi.stride())
+    d.A_lo, d.B_lo, d.C16_lo = _p(a_lo), _p(b_lo), _p(out16_lo)
     return d
 
 
@@ -127,7 +131,7 @@ def gemm_pair_ln(dgrad, wgrad, ln, counters, dry_run=False):
 def layernorm_desc(dtype, rows, N, *, x=None, x_f64=False, residual=None, pos=None, pos_period=0, gamma=None,
                    beta=None, eps=1e-12, y=None, stats=None, out32=None, out16=None, p_pre=0.0, p_post=0.0, seed=0,
                    off_pre=0, off_post=0, seed_dev=None, dout=None, dx32=None, dxd32=None, dxd16=None, dgamma=None,
-                   dbeta=None, dbias=None, dpos=None):
+                   dbeta=None, dbias=None, dpos=None, out16_lo=None):
     d = _lib.LayerNorm()
     d.dtype, d.rows, d.N, d.x_f64 = dtype, rows, N, int(x_f64)
     d.x, d.residual, d.pos, d.pos_period = _p(x), _p(residual), _p(pos), pos_period
@@ -136,6 +140,7 @@ def layernorm_desc(dtype, rows, N, *, x=None, x_f64=False, residual=None, pos=No
     d.p_pre, d.p_post, d.seed, d.off_pre, d.off_post, d.seed_dev = p_pre, p_post, seed, off_pre, off_post, _p(seed_dev)
     d.dout, d.dx32, d.dxd32, d.dxd16 = _p(dout), _p(dx32), _p(dxd32), _p(dxd16)
     d.dgamma, d.dbeta, d.dbias, d.dpos = _p(dgamma), _p(dbeta), _p(dbias), _p(dpos)
+    d.out16_lo = _p(out16_lo)
     return d
 
 
@@ -151,7 +156,7 @@ def layernorm_bwd(**kw):
 
 def attention_desc(dtype, B, H, Sq, Sk, q, ldq, k, ldk, v, ldv, out, ldo, lse, *, key_mask=None, causal=False,
                    p_drop=0.0, seed=0, offset=0, seed_dev=None, dout=None, lddo=0, dq=None, lddq=0, dk=None, lddk=0,
-                   dv=None, lddv=0, bsk=0, bsv=0):
+                   dv=None, lddv=0, bsk=0, bsv=0, out_lo=None):
     """q/k/v/out/... are (tensor, element_offset) pairs or tensors; ld in elements."""
     def ptr(t):
         if t is None:
@@ -167,6 +172,7 @@ def attention_desc(dtype, B, H, Sq, Sk, q, ldq, k, ldk, v, ldv, out, ldo, lse, *
     d.p_drop, d.seed, d.offset, d.seed_dev = p_drop, seed, offset, _p(seed_dev)
     d.dout, d.lddo, d.dq, d.lddq, d.dk, d.lddk, d.dv, d.lddv = ptr(dout), lddo, ptr(dq), lddq, ptr(dk), lddk, ptr(dv), lddv
     d.bsk, d.bsv = bsk, bsv
+    d.out_lo = ptr(out_lo)
     return d
 
 
@@ -203,7 +209,7 @@ def attention_fwd_fused(attn, qkv, dry_run=False):
 
 def embed_text_desc(dtype, B, S, ids, word, pos, gamma, beta, *, type_ids=None, type_emb=None, eps=1e-12, y=None,
                     stats=None, out32=None, out16=None, p_post=0.0, seed=0, off_post=0, seed_dev=None, dout=None,
-                    dword=None, dpos=None, dtype_emb=None, dgamma=None, dbeta=None, drows=None):
+                    dword=None, dpos=None, dtype_emb=None, dgamma=None, dbeta=None, drows=None, out16_lo=None):
     d = _lib.EmbedText()
     d.dtype, d.B, d.S, d.N = dtype, B, S, 768
     d.ids, d.type_ids = _p(ids), _p(type_ids)
@@ -213,6 +219,7 @@ def embed_text_desc(dtype, B, S, ids, word, pos, gamma, beta, *, type_ids=None, 
     d.p_post, d.seed, d.off_post, d.seed_dev = p_post, seed, off_post, _p(seed_dev)
     d.dout, d.dword, d.dpos, d.dtype_emb, d.dgamma, d.dbeta = _p(dout), _p(dword), _p(dpos), _p(dtype_emb), _p(dgamma), _p(dbeta)
     d.drows = _p(drows)
+    d.out16_lo = _p(out16_lo)
     return d
 
 
@@ -357,6 +364,11 @@ def rank_counts(sim):
 
 def cast_bf16(src, dst):
     _lib.check(_lib.lib().univl_cast_bf16(_p(src), _p(dst), src.numel(), _stream()), "cast_bf16")
+
+
+def cast_bf16_pair(src, hi, lo):
+    """hi <- bf16(src), lo <- bf16(src - hi); hi may be None (only the lo half is written)."""
+    _lib.check(_lib.lib().univl_cast_bf16_pair(_p(src), _p(hi), _p(lo), src.numel(), _stream()), "cast_bf16_pair")
 
 
 def cast_f32(src16, dst):

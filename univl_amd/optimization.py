@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 from torch.optim import Optimizer
 
-from . import _lib
+from . import _ab, _lib
 from .engine import FLAT_REGISTRY
 
 CHUNK = 8192   # elements per workgroup
@@ -90,10 +90,11 @@ class _Tables:
                         pieces.append((lo, hi))
                     j += 1
             # the word table's chunks start on row boundaries (10 rows of 768): UnivlAdam.row_flags works on whole rows
-            step = CHUNK
+            chunk = int(_ab.get("adam_chunk")) or CHUNK
+            step = chunk
             if n == fl.WORD and owned is None:
                 row = fl.index[n][2][1]
-                step = max(1, CHUNK // row) * row
+                step = max(1, chunk // row) * row
             for lo, hi in pieces:
                 for o in range(lo, hi, step):
                     c_seg.append(s)
@@ -443,6 +444,8 @@ class BertAdam(Optimizer):
         red = getattr(fl, "shard_reducer", None)
         if red is not None:
             red.all_gather_ranges(fl.p16 if fl.p16 is not None else fl.p32)
+            if getattr(fl, "p16lo", None) is not None:
+                red.all_gather_ranges(fl.p16lo)
             fl.master_complete = fl.p16 is None        # other ranks' pieces of the fp32 master are stale from now on
             self._state_complete = False               # ... and so are their pieces of the moments
 
@@ -509,6 +512,7 @@ class BertAdam(Optimizer):
         d = _lib.Adam()
         d.p, d.g, d.m, d.v = fl.p32.data_ptr(), fl.g32.data_ptr(), self._m.data_ptr(), self._v.data_ptr()
         d.p16 = fl.p16.data_ptr() if fl.p16 is not None else None
+        d.p16_lo = fl.p16lo.data_ptr() if getattr(fl, "p16lo", None) is not None else None
         d.segs, d.nseg = tb.segs.data_ptr(), tb.nseg
         d.chunk_seg, d.chunk_off, d.chunk_len, d.nchunk = (tb.chunk_seg.data_ptr(), tb.chunk_off.data_ptr(),
                                                            tb.chunk_len.data_ptr(), tb.nchunk)

@@ -118,6 +118,10 @@ class EncoderPass:
         self.vis = EncoderStack(fl, "visual", m.visual_config.num_hidden_layers, B, F, self.vmask, cx.p, cx.seed_dev, cx.sites,
                                 s_main=s_vis, s_side=s_vis)
         self.off_t, self.off_v = cx.sites.next(), cx.sites.next()
+        # lo halves of the stacks' input pairs (EncoderStack.pair_x) and of the normalised video (A operand of the video embedding product)
+        self.t0_lo = e(self.Tt, H, dtype=ct) if self.text.pair_x else None
+        self.v0_lo = e(self.Tv, H, dtype=ct) if self.vis.pair_x else None
+        self.vn_lo = e(self.Tv, D, dtype=ct) if (self.vis.pair_x and not self.normalized_input) else None
         self.seq_out, self.seq_out16 = self.text.output()
         self.vis_out, self.vis_out16 = self.vis.output()
 
@@ -150,20 +154,21 @@ class EncoderPass:
         else:
             fwd.add("univl_layernorm_fwd", ops.layernorm_desc(
                 dt, Tv, D, x=self.video, x_f64=True, gamma=W32(n["nv_g"]), beta=W32(n["nv_b"]), y=self.vy, stats=self.vst,
-                out32=self.vn32, out16=self.vn_op if bf else None), SV)
-        fwd.add("univl_gemm", _gemm_desc(dt, self.vn_op, D, fl.wop(n["vw"]), D, Tv, H, D, out32=self.ve, ldc=H, bias=W32(n["vb"])), SV)
+                out32=self.vn32, out16=self.vn_op if bf else None, out16_lo=self.vn_lo), SV)
+        fwd.add("univl_gemm", _gemm_desc(dt, self.vn_op, D, fl.wop(n["vw"]), D, Tv, H, D, out32=self.ve, ldc=H, bias=W32(n["vb"]),
+                                         a_lo=self.vn_lo, b_lo=fl.wlo(n["vw"]) if self.vis.pair_w else None), SV)
         fwd.add("univl_layernorm_fwd", ops.layernorm_desc(
             dt, Tv, H, x=self.ve, pos=W32(n["vpos"]), pos_period=F, gamma=W32(n["vlg"]), beta=W32(n["vlb"]), y=self.ve,
             stats=self.vest, out32=self.v0_32, out16=self.v0_16 if bf else None, p_post=p, seed=cx.seed, off_post=self.off_v,
-            seed_dev=cx.seed_dev), SV)
+            seed_dev=cx.seed_dev, out16_lo=self.v0_lo), SV)
         cx.stamp(fwd, "f_text_start", ST)
         fwd.add("univl_embed_text_fwd", ops.embed_text_desc(
             dt, B, W, self.ids, W32(n["bw"]), W32(n["bp"]), W32(n["blg"]), W32(n["blb"]), type_ids=self.type_ids,
             type_emb=W32(n["bt"]), y=self.te, stats=self.test, out32=self.t0_32, out16=self.t0_16 if bf else None, p_post=p,
-            seed=cx.seed, off_post=self.off_t, seed_dev=cx.seed_dev), ST)
-        self.vis.build_forward(fwd, self.v0_32, self.v0_16, cx.training, zero_arena=False)
+            seed=cx.seed, off_post=self.off_t, seed_dev=cx.seed_dev, out16_lo=self.t0_lo), ST)
+        self.vis.build_forward(fwd, self.v0_32, self.v0_16, cx.training, zero_arena=False, x16_lo=self.v0_lo)
         cx.stamp(fwd, "f_vis_end", SV)
-        self.text.build_forward(fwd, self.t0_32, self.t0_16, cx.training, zero_arena=False)
+        self.text.build_forward(fwd, self.t0_32, self.t0_16, cx.training, zero_arena=False, x16_lo=self.t0_lo)
         cx.stamp(fwd, "f_text_end", ST)
         fwd.join(SV, ST)
         cx.stamp(fwd, "f_join", ST)
