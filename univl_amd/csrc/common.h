@@ -141,6 +141,26 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
+// erf-GELU (until_module.py:28-33) and its derivative for this body's epilogue.  libm's erff is two divergent branches of ~35 VALU
+// instructions each -- at 128 results per lane and ONE workgroup per compute unit (nothing else to overlap with) that is ~15 us per
+// 256 x 256 tile, longer than a 12-tile K loop.  Here: Abramowitz-Stegun 7.1.26, branch-free, |error| <= 1.5e-7 in erf (fp32
+// round-off class; the results are rounded to bf16 = 4e-3 next):  with z = |x| / sqrt 2, t = 1 / (1 + p z), E = exp(-z^2) = exp(-x^2 / 2),
+// q = poly(t) E:   Phi(x) = 0.5 (1 + erf(x / sqrt 2)) = 1 - q / 2  (x >= 0),  q / 2  (x < 0)   -- no cancellation in the negative tail;
+// gelu = x Phi,  gelu' = Phi + x E / sqrt(2 pi)  (the same exponential).
+__device__ __forceinline__ void g256_phi(float x, float& phi, float& E) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    E = __expf(-z * z);
+    float q = fmaf(t, 1.061405429f, -1.453152027f);
+    q = fmaf(t, q, 1.421413741f);
+    q = fmaf(t, q, -0.284496736f);
+    q = fmaf(t, q, 0.254829592f);
+    q = q * t * E * 0.5f;
+    phi = x >= 0.0f ? 1.0f - q : q;
+}
+__device__ __forceinline__ float g256_gelu(float x) { float phi, E; g256_phi(x, phi, E); return x * phi; }
+__device__ __forceinline__ float g256_gelu_grad(float x) { float phi, E; g256_phi(x, phi, E); return fmaf(x * 0.39894228040143267794f, E, phi); }
+
 // Counter-based RNG for dropout: one 32-bit draw per (seed, stream offset, element index); the same function
 // regenerates the mask in the backward pass.  (No bit-parity with torch's Philox stream is possible or required:
 // parity is checked at p = 0)
