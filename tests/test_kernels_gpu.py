@@ -981,12 +981,14 @@ def test_attention_bwd_with_the_output_dgrad_inside_equals_the_two_launches(B, S
     assert not ops.attention_bwd_fused(at_long, ops.gemm_desc(dY, Wo, 80, HD, HD, trans_b=True, out16=dctx2), None, dry_run=True)
 
 
-@pytest.mark.parametrize("B,S,p_drop,masked", [(4, 48, 0.1, False), (4, 48, 0.0, True), (3, 20, 0.1, True), (2, 64, 0.0, False), (5, 33, 0.1, True)])
+@pytest.mark.parametrize("B,S,p_drop,masked", [(4, 48, 0.1, False), (4, 48, 0.0, True), (3, 20, 0.1, True), (2, 64, 0.0, False), (5, 33, 0.1, True),
+                                               (4, 128, 0.1, False), (4, 96, 0.0, True), (3, 100, 0.1, True), (2, 65, 0.0, True), (6, 112, 0.1, False)])
 def test_attention_fwd_with_the_qkv_projection_inside_equals_the_two_launches(B, S, p_drop, masked):
     """univl_attention_fwd_fused (round 5): the workgroup of a (batch row, head) multiplies its 64 x 192 block of q | k | v, stores it
     and attends on it from LDS.  The qkv buffer, the attention output and the log-sum-exp are BIT-IDENTICAL to univl_gemm +
     univl_attention_fwd (ragged key masks, a fully masked row, dropout, sequences that are not multiples of 16); rows of the qkv buffer
-    that belong to no sequence position are not touched."""
+    that belong to no sequence position are not touched.  Round 6: sequences of 65 .. 128 positions run as TWO workgroups per (batch row,
+    head) -- one per block of 64 queries, each multiplying the whole sequence's q | k | v -- with the same bits."""
     dtype, H, D = torch.bfloat16, 12, 64
     dt = ops.dtype_code(dtype)
     T, HD = B * S, H * D
@@ -1023,12 +1025,15 @@ def test_attention_fwd_with_the_qkv_projection_inside_equals_the_two_launches(B,
         assert torch.equal(q1, q0), float((q1.float() - q0.float()).abs().max())
         assert torch.equal(c1, c0), float((c1.float() - c0.float()).abs().max())
         assert torch.equal(l1, l0)
-    # not carried: cross attention shapes (Sq != Sk), more than 64 positions, a causal mask
-    qkv = torch.zeros(160, 3 * HD, device=DEV, dtype=dtype)
-    ctx = torch.zeros(160, HD, device=DEV, dtype=dtype)
-    lse = torch.zeros(2, H, 80, device=DEV)
-    at = ops.attention_desc(dt, 2, H, 80, 80, (qkv, 0), 3 * HD, (qkv, HD), 3 * HD, (qkv, 2 * HD), 3 * HD, ctx, HD, lse)
-    assert not ops.attention_fwd_fused(at, ops.gemm_desc(x[:160] if T >= 160 else torch.zeros(160, HD, device=DEV, dtype=dtype), W, 160, 3 * HD, HD, out16=qkv), dry_run=True)
+    # not carried: more than 128 positions, a causal mask
+    qkv = torch.zeros(320, 3 * HD, device=DEV, dtype=dtype)
+    ctx = torch.zeros(320, HD, device=DEV, dtype=dtype)
+    lse = torch.zeros(2, H, 160, device=DEV)
+    x320 = torch.zeros(320, HD, device=DEV, dtype=dtype)
+    at = ops.attention_desc(dt, 2, H, 160, 160, (qkv, 0), 3 * HD, (qkv, HD), 3 * HD, (qkv, 2 * HD), 3 * HD, ctx, HD, lse)
+    assert not ops.attention_fwd_fused(at, ops.gemm_desc(x320, W, 320, 3 * HD, HD, out16=qkv), dry_run=True)
+    at = ops.attention_desc(dt, 2, H, 160, 160, (qkv, 0), 3 * HD, (qkv, HD), 3 * HD, (qkv, 2 * HD), 3 * HD, ctx, HD, lse, causal=True)
+    assert not ops.attention_fwd_fused(at, ops.gemm_desc(x320, W, 320, 3 * HD, HD, out16=qkv), dry_run=True)
 
 
 # ------------------------------------------------------------------------------------------ operand pairs (round 6)
@@ -1115,7 +1120,7 @@ def test_gemm_operand_pairs_refusals():
     assert rel_err(q.float(), _pair_ref(xh, xl, wh, wl)) < 5e-3
 
 
-@pytest.mark.parametrize("B,S,p_drop,masked", [(4, 48, 0.1, False), (3, 20, 0.0, True), (2, 64, 0.1, False)])
+@pytest.mark.parametrize("B,S,p_drop,masked", [(4, 48, 0.1, False), (3, 20, 0.0, True), (2, 64, 0.1, False), (4, 128, 0.1, True), (3, 96, 0.0, False)])
 @pytest.mark.parametrize("which", ["b", "ab"])
 def test_attention_fwd_fused_with_operand_pairs_equals_the_two_launches(B, S, p_drop, masked, which):
     """The q | k | v projection inside the attention launch walks the same terms in the same order as univl_gemm with the same lo

@@ -41,6 +41,7 @@ KEYS = {
     "wgrad_big_min": (0, "token count from which a layer's grouped weight gradients take the big tile (0: where every dgrad does)"),
     "attn_fuse_fwd": (1, "the q | k | v projection computed inside the attention forward launch (univl_attention_fwd_fused); 0: two launches"),
     "attn_fuse_bwd": (1, "the attention-output dgrad computed inside the attention backward launch (univl_attention_bwd_fused); 0: two launches"),
+    "attn_fuse_fwd_max_seq": (64, "longest sequence the fused attention FORWARD launch is used for.  128: the round-6 form for 65 .. 128 positions (two workgroups per (batch row, head), bit-identical) -- measured NEUTRAL: caption 5.150 vs 5.150 ms, pretrain 9.09 vs 9.09, FT-Align 2.90 vs 2.90 with 18 launches fewer (profiles/r06t_ab_attn_big.txt), so the plans keep the two launches"),
     "attn_fuse_fwd_max_rows": (1536, "token count up to which the fused attention FORWARD launch is used (1536: -1.9 %, 3072: +0.7 %, profiles/r05ae)"),
     "attn_fuse_bwd_max_rows": (1535, "token count up to which the fused attention BACKWARD launch is used (1536: +1 %, 6144: +4.9 %)"),
     "g256": (1, "256 x 256 8-phase body (csrc/gemm256.h) for the grouped weight gradients / single products it is picked for; 0: the older tiles"),

@@ -1057,7 +1057,11 @@ struct AttnFwdFusedArgs {
     const __bf16* X_lo; const __bf16* W_lo;     // operand pairs of the projection (UnivlGemm.A_lo / B_lo), or null
 };
 
-template <bool NT>
+// BIG (round 6): sequences of 65 .. 128 positions (the caption configuration's 128 words / 96 frames, the cross encoder's 96 / 112).  Two
+// workgroups per (batch row, head), one per block of 64 queries; each multiplies the 128 x 192 block of q | k | v of the WHOLE sequence (the
+// attention of its query block needs every key and value; the other block's q rows are recomputed -- at these sizes the product is a
+// latency chain, not MFMA time), stores the q | k | v rows of ITS OWN block to the qkv buffer (every row written once) and attends.
+template <bool NT, bool BIG>
 __global__ __launch_bounds__(512, 2) void attn_fwd_qkv_kernel(AttnFwdFusedArgs a, UnivlAdam ad, int c0, int c1) {
     const int w0 = blockIdx.x;
     if (w0 >= a.n_attn_pad) {
@@ -1066,17 +1070,18 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_qkv_kernel(AttnFwdFusedArgs a
         return;
     }
     if (w0 >= a.n_attn) return;
-    using TileA = Tile<__bf16, false, 64, 64, 512>;
+    constexpr int ROWS = BIG ? 128 : 64, MI = ROWS / 32;
+    using TileA = Tile<__bf16, false, ROWS, 64, 512>;
     using TileB = Tile<__bf16, false, 192, 64, 512>;
-    const int bh = w0, b = bh / a.at.H, h = bh % a.at.H;
+    const int bh = BIG ? (w0 >> 1) : w0, yblk = BIG ? (w0 & 1) : 0, b = bh / a.at.H, h = bh % a.at.H;
     const int HD3 = a.at.H * 64, Sq = a.at.Sq;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
-    const int wm0 = (wave >> 2) * 32, wn0 = (wave & 3) * 48;
+    const int wm0 = (wave >> 2) * (ROWS / 2), wn0 = (wave & 3) * 48;
     unsigned char* sA = smem_raw;
     unsigned char* sB = sA + 2 * TileA::BYTES;
-    f32x4_t acc[2][3];
+    f32x4_t acc[MI][3];
 #pragma unroll
-    for (int ta = 0; ta < 2; ++ta)
+    for (int ta = 0; ta < MI; ++ta)
 #pragma unroll
         for (int tb = 0; tb < 3; ++tb) acc[ta][tb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const __bf16* pa[TileA::PER_THREAD];
@@ -1113,7 +1118,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_qkv_kernel(AttnFwdFusedArgs a
             TileA::advance(pa, 64);
             TileB::advance(pb, 64);
         }
-        tile_mma<__bf16, false, false, 2, 3, 2, TileA, TileB>(sA + cur * TileA::BYTES, sB + cur * TileB::BYTES, wm0, wn0, lane, acc);
+        tile_mma<__bf16, false, false, MI, 3, 2, TileA, TileB>(sA + cur * TileA::BYTES, sB + cur * TileB::BYTES, wm0, wn0, lane, acc);
         __syncthreads();
     }
     // epilogue: + bias -> bf16 -> the qkv buffer (rows of the sequence) and the LDS images of the attention body (rows beyond it: zero)
@@ -1127,16 +1132,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_qkv_kernel(AttnFwdFusedArgs a
         __bf16* img = panel == 0 ? im.sQ : (panel == 1 ? im.sK : im.sV);
         const int pitch = panel == 2 ? C::PT : C::PK;
 #pragma unroll
-        for (int ta = 0; ta < 2; ++ta)
+        for (int ta = 0; ta < MI; ++ta)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = wm0 + 16 * ta + 4 * g + r;
                 const __bf16 v = (__bf16)(acc[ta][tb][r] * 1.0f + bv);
-                if (row < Sq) a.qkv[((long)b * Sq + row) * a.ldqkv + gcol] = v;
-                if (row < a.Sk_pad || panel == 0) img[row * pitch + c64] = row < Sq ? v : (__bf16)0.0f;
+                if (row < Sq && (!BIG || (row >> 6) == yblk)) a.qkv[((long)b * Sq + row) * a.ldqkv + gcol] = v;
+                // images: K and V hold Sk_pad rows; the Q image 64 rows (BIG: Sk_pad rows, indexed by the position in the sequence)
+                if (row < a.Sk_pad || (!BIG && panel == 0)) img[row * pitch + c64] = row < Sq ? v : (__bf16)0.0f;
             }
     }
-    attn_fwd_body<__bf16, 4, true>(a.at, a.Sk_pad, 0.125f, bh, 0, smem_raw);
+    attn_fwd_body<__bf16, BIG ? 8 : 4, true>(a.at, a.Sk_pad, 0.125f, bh, yblk, smem_raw);
 }
 
 // EXPERIMENTAL (UNIVL_ADAM_RIDE=1 with graphed.GraphedTrainStep(pipeline_optimizer=True)): a forward product and a range of BertAdam
@@ -1706,10 +1712,13 @@ extern "C" int univl_attention_bwd_fused(const UnivlAttention* at, const UnivlGe
 // of 64, bias optional, no other epilogue.  Results (the qkv buffer, the attention output, the log-sum-exp) are bit-identical to
 // univl_gemm + univl_attention_fwd.  UNIVL_EUNSUPPORTED otherwise; adam may be NULL (chunk_count 0).
 static const size_t ATTN_FWD_FUSED_SMEM = 2 * (size_t)(64 + 192) * 64 * sizeof(__bf16);
+static const size_t ATTN_FWD_FUSED_SMEM_BIG = 2 * (size_t)(128 + 192) * 64 * sizeof(__bf16);      // 80 KB: the images of 128 positions (57 KB) fit inside
 static void attn_fwd_fused_allow_lds() {
-    static bool done_nt[UNIVL_MAX_DEVICES] = {}, done_t[UNIVL_MAX_DEVICES] = {};
-    univl_allow_lds(attn_fwd_qkv_kernel<true>, ATTN_FWD_FUSED_SMEM, done_nt);
-    univl_allow_lds(attn_fwd_qkv_kernel<false>, ATTN_FWD_FUSED_SMEM, done_t);
+    static bool done_nt[UNIVL_MAX_DEVICES] = {}, done_t[UNIVL_MAX_DEVICES] = {}, done_ntb[UNIVL_MAX_DEVICES] = {}, done_tb[UNIVL_MAX_DEVICES] = {};
+    univl_allow_lds(attn_fwd_qkv_kernel<true, false>, ATTN_FWD_FUSED_SMEM, done_nt);
+    univl_allow_lds(attn_fwd_qkv_kernel<false, false>, ATTN_FWD_FUSED_SMEM, done_t);
+    univl_allow_lds(attn_fwd_qkv_kernel<true, true>, ATTN_FWD_FUSED_SMEM_BIG, done_ntb);
+    univl_allow_lds(attn_fwd_qkv_kernel<false, true>, ATTN_FWD_FUSED_SMEM_BIG, done_tb);
 }
 
 extern "C" int univl_attention_fwd_fused(const UnivlAttention* at, const UnivlGemm* qkv, const UnivlAdam* adam, int32_t chunk_begin,
@@ -1726,7 +1735,7 @@ extern "C" int univl_attention_fwd_fused(const UnivlAttention* at, const UnivlGe
     const UnivlGemm* g = qkv;
     const long hd = (long)at->H * 64;
     const __bf16* c16 = reinterpret_cast<const __bf16*>(g->C16);
-    UNIVL_CHECK_ARG(at->dtype == UNIVL_DT_BF16 && at->Sq == at->Sk && Sk_pad <= 64 && !at->causal && at->bsk == 0 && at->bsv == 0 &&
+    UNIVL_CHECK_ARG(at->dtype == UNIVL_DT_BF16 && at->Sq == at->Sk && Sk_pad <= 128 && !at->causal && at->bsk == 0 && at->bsv == 0 &&
                         g->dtype == UNIVL_BF16 && !g->trans_a && !g->trans_b && g->M == at->B * at->Sq && g->N == 3 * hd && g->K % 64 == 0 &&
                         g->K >= 64 && c16 != nullptr && !g->C32 && !g->R && !g->dbias && !g->sumsq && !g->aux && g->alpha == 1.0f &&
                         g->ksplit <= 1 && (g->flags & ~(UNIVL_GEMM_XCD_MAP)) == 0 && aligned16(g->A) && aligned16(g->B) && g->lda % 8 == 0 &&
@@ -1744,15 +1753,22 @@ extern "C" int univl_attention_fwd_fused(const UnivlAttention* at, const UnivlGe
     a.qkv = reinterpret_cast<__bf16*>(g->C16); a.ldqkv = g->ldc;
     a.K = g->K;
     a.X_lo = reinterpret_cast<const __bf16*>(g->A_lo); a.W_lo = reinterpret_cast<const __bf16*>(g->B_lo);
-    a.n_attn = at->B * at->H;
+    const bool big = Sk_pad > 64;                      // 65 .. 128 positions: two workgroups (query blocks) per (batch row, head)
+    a.n_attn = at->B * at->H * (big ? 2 : 1);
     a.n_attn_pad = (a.n_attn + 7) / 8 * 8;
     const int nb = chunk_count <= 0 ? 0 : ((max_blocks > 0 && max_blocks < chunk_count) ? max_blocks : chunk_count);
     UnivlAdam none = {};
     const UnivlAdam& ad = chunk_count > 0 ? *adam : none;
     attn_fwd_fused_allow_lds();
     const int cb = chunk_begin, ce = chunk_begin + (chunk_count > 0 ? chunk_count : 0);
-    if (univl_adam_nt()) hipLaunchKernelGGL(attn_fwd_qkv_kernel<true>, dim3(a.n_attn_pad + nb), dim3(512), ATTN_FWD_FUSED_SMEM, stream, a, ad, cb, ce);
-    else hipLaunchKernelGGL(attn_fwd_qkv_kernel<false>, dim3(a.n_attn_pad + nb), dim3(512), ATTN_FWD_FUSED_SMEM, stream, a, ad, cb, ce);
+    const dim3 grid(a.n_attn_pad + nb);
+    if (big) {
+        if (univl_adam_nt()) hipLaunchKernelGGL((attn_fwd_qkv_kernel<true, true>), grid, dim3(512), ATTN_FWD_FUSED_SMEM_BIG, stream, a, ad, cb, ce);
+        else hipLaunchKernelGGL((attn_fwd_qkv_kernel<false, true>), grid, dim3(512), ATTN_FWD_FUSED_SMEM_BIG, stream, a, ad, cb, ce);
+    } else {
+        if (univl_adam_nt()) hipLaunchKernelGGL((attn_fwd_qkv_kernel<true, false>), grid, dim3(512), ATTN_FWD_FUSED_SMEM, stream, a, ad, cb, ce);
+        else hipLaunchKernelGGL((attn_fwd_qkv_kernel<false, false>), grid, dim3(512), ATTN_FWD_FUSED_SMEM, stream, a, ad, cb, ce);
+    }
     UNIVL_LAUNCH_CHECK();
     return UNIVL_OK;
 }

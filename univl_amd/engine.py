@@ -961,6 +961,7 @@ class EncoderStack:
             # (profiles/r05_final_bench_b128_kernel_stats.csv).
             carriers, nslots = None, 4
             fused_fwd = (self.bf and T <= int(_ab.get("attn_fuse_fwd_max_rows")) and bool(_ab.get("attn_fuse_fwd")) and
+                         S <= int(_ab.get("attn_fuse_fwd_max_seq")) and
                          _lib.lib().univl_attention_fwd_fused(C.byref(attn_f), C.byref(qkv_desc), None, 0, 0, 0, 1, None) == 0)
             # what the products of layer l carry: the chunks of the stack's next layer; behind its LAST layer those of `tail_key` (steps.
             # build_step: the first layer of the stack that runs after this one -- cross encoder / decoder -- instead of a launch in front
