@@ -35,9 +35,10 @@ KEYS = {
     "splitk_mid_ks_big": (2, "... from 161 tiles on"),
     "splitk_mid_ks_768": (1, "slices of the K = 768 N = 768 products in the splitk_mid regime"),
     "splitk_mid_tiles": (256, "upper tile bound of that regime"),
-    "ln_fold": (1, "LayerNorm forward finished inside its product's launch (univl_gemm_ln) up to 512 tokens"),
+    "ln_fold": (1, "LayerNorm forward finished inside its product's launch (univl_gemm_ln) up to ln_fold_max_rows tokens"),
+    "ln_fold_max_rows": (640, "... up to this many tokens (the library carries up to 1024).  Round 6, alternating on one box: 576 tokens 3.00 -> 2.92 ms (-2.6 %, both folds), 624 tokens -1.7 %, 672 +-0, 768 +0.5 % (profiles/r06u_ab_fold_768*.txt); rounds 4-5: 512"),
     "ln_fold_bwd": (1, "LayerNorm backward finished inside the dgrad pair launch (univl_gemm_pair_ln)"),
-    "ln_fold_bwd_max": (512, "... up to this many tokens (383: round 4's range, the square pair form only)"),
+    "ln_fold_bwd_max": (640, "... up to this many tokens (383: round 4's range, the square pair form only)"),
     "wgrad_big_min": (0, "token count from which a layer's grouped weight gradients take the big tile (0: where every dgrad does)"),
     "attn_fuse_fwd": (1, "the q | k | v projection computed inside the attention forward launch (univl_attention_fwd_fused); 0: two launches"),
     "attn_fuse_bwd": (1, "the attention-output dgrad computed inside the attention backward launch (univl_attention_bwd_fused); 0: two launches"),

@@ -779,12 +779,13 @@ class EncoderStack:
         # prologue launches are HBM streams, two of them side by side each run at half speed.)
         self.T = B * S
         # K8 / K10: the post-product LayerNorms of the forward finished inside the product's launch (Plan.add_gemm_ln, gemm.hip: ln_fold)
-        # up to 512 tokens -- where a layer is a chain of latency-bound launches and one kernel boundary per LayerNorm is worth more than
+        # up to 640 tokens (round 6; 512 before: 576 tokens -2.6 %, 624 -1.7 %, 672 +-0, 768 +0.5 %, profiles/r06u_ab_fold_768*.txt) -- where a layer is a
+        # chain of latency-bound launches and one kernel boundary per LayerNorm is worth more than
         # the fold's tail (three dependent round trips to the coherence point: atomics done, arrival counter, row loads).  Measured per
         # step, fold vs two launches (profiles/r04p_ab_ln_fold.txt, r04q_ab_ln_fold_sizes.txt): 192 tokens 2.271 vs 2.333 ms (-2.6 %),
         # 384: 2.780 vs 2.829 (-1.7 %), 576: 3.144 vs 3.148, 768: 3.469 vs 3.415 (+1.6 %); FT-Align 3.193 vs 3.318 (-3.8 %).
         # UNIVL_LN_FOLD=0: two launches (A/B).  Deterministic mode falls back to the two launches (the C side refuses).
-        self.ln_fold = (flat.compute_dtype == torch.bfloat16 and B * S <= 512 and bool(_ab.get("ln_fold"))
+        self.ln_fold = (flat.compute_dtype == torch.bfloat16 and B * S <= int(_ab.get("ln_fold_max_rows")) and bool(_ab.get("ln_fold"))
                         and prefix in ("bert", "visual", "cross"))
         self.key_mask = key_mask            # int64 [B,S] device tensor (static buffer)
         self.p = float(p_drop)
