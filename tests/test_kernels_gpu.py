@@ -646,7 +646,7 @@ def test_layernorm_dropout_mask_consistency():
 
 # ----------------------------------------------------------------------- product + LayerNorm in one launch (K8 / K10)
 @pytest.mark.parametrize("M,K,ksplit,p_drop", [(192, 768, 2, 0.0), (192, 3072, 8, 0.1), (768, 768, 1, 0.1), (768, 3072, 3, 0.0),
-                                                (100, 768, 2, 0.1), (1024, 768, 1, 0.0), (64, 3072, 8, 0.1)])
+                                                (100, 768, 2, 0.1), (1024, 768, 1, 0.0), (64, 3072, 8, 0.1), (576, 768, 2, 0.1), (624, 3072, 3, 0.0)])
 def test_gemm_ln_fold_matches_the_two_launches(M, K, ksplit, p_drop):
     """univl_gemm_ln (gemm.hip: ln_fold): the LayerNorm behind an attention-output / FFN2 product finished by the product's own launch.
     Same arithmetic per row as univl_layernorm_fwd on the same fp32 sums: bit-identical to the two launches when the product is not
@@ -702,7 +702,9 @@ def test_gemm_ln_fold_matches_the_two_launches(M, K, ksplit, p_drop):
 
 @pytest.mark.parametrize("T,K_out,ks,p_drop", [(192, 3072, 8, 0.1), (192, 2304, 6, 0.0), (100, 3072, 8, 0.1), (320, 768, 2, 0.1), (64, 2304, 6, 0.0),
                                                # round 5: the rectangular dgrad body (384+ tokens, slices up to 1536 deep)
-                                               (384, 3072, 2, 0.1), (512, 2304, 2, 0.0), (448, 3072, 8, 0.1), (512, 3072, 4, 0.1), (1024, 2304, 3, 0.0)])
+                                               (384, 3072, 2, 0.1), (512, 2304, 2, 0.0), (448, 3072, 8, 0.1), (512, 3072, 4, 0.1), (1024, 2304, 3, 0.0),
+                                               # round 6: the plans fold up to 640 tokens
+                                               (576, 3072, 3, 0.1), (624, 2304, 3, 0.0)])
 def test_gemm_pair_ln_fold_matches_the_two_launches(T, K_out, ks, p_drop):
     """univl_gemm_pair_ln (gemm.hip: ln_fold_bwd): the LayerNorm BACKWARD fed by a pair launch's dgrad product, finished by the dgrad's
     last workgroups per 64-row block -- dx32 / dxd16 rows and the dgamma / dbeta / dbias column sums against univl_gemm_pair +

@@ -486,6 +486,41 @@ def test_default_atomic_mode_matches_deterministic(name, dtype):
     assert rel < (1e-4 if f32 else 4e-2), (name, rel)
 
 
+def test_layernorm_folds_at_576_tokens_match_the_plans_without_them(ab):
+    """Round 6 moved the upper end of the LayerNorm folds from 512 to 640 tokens (12 pairs x 48: -2.6 % per step).  No BASELINE golden
+    sits in that range, so: 12 rows of the joint configuration in the default (atomic) mode with the folds against the same step with
+    ln_fold = 0 -- same sums in another order (aggregate difference at the bf16 reordering level, every position row within it) -- and
+    the folded plan really holds the fold launches."""
+    import dataclasses
+    cfg, _, dseed = case_config("joint_b16")
+    cfg = dataclasses.replace(cfg, batch_size=12)
+    batch = O.synthetic_batch(cfg, 12, seed=dseed)
+
+    def run():
+        model, _ = build(cfg, torch.bfloat16)
+        model.train()
+        loss = call(model, batch)
+        loss.backward()
+        g = {n: p.grad.detach().double().cpu() for n, p in model.named_parameters() if p.grad is not None}
+        return float(loss), g, set(plan_ops(model))
+
+    with atomic_mode():
+        l1, g1, ops1 = run()
+        ab(ln_fold=0)
+        l0, g0, ops0 = run()
+        ab(ln_fold=None)
+    assert "univl_gemm_ln" in ops1 and "univl_gemm_pair_ln" in ops1 and "univl_gemm_ln" not in ops0 and "univl_gemm_pair_ln" not in ops0
+    assert abs(l1 - l0) < 2e-3 * max(1.0, abs(l0))
+    num = sum(float((g1[k] - g0[k]).norm()) ** 2 for k in g0)
+    den = sum(float(g0[k].norm()) ** 2 for k in g0)
+    assert (num / den) ** 0.5 < 4e-2, (num / den) ** 0.5
+    for k in ("bert.embeddings.position_embeddings.weight", "visual.embeddings.position_embeddings.weight"):
+        rn = g0[k].norm(dim=1)
+        live = rn > 1e-3 * float(rn.max())
+        rd = ((g1[k] - g0[k]).norm(dim=1) / rn.clamp_min(1e-30))[live]
+        assert int(live.sum()) > 0 and float(rd.max()) < 6e-2, (k, float(rd.max()))
+
+
 def test_large_batch_backward_paths_match_the_default_ones(ab):
     """Two backward forms that only switch on at large per-GPU batch -- position-table gradients by a gather over per-token rows
     (dpos_gather_min, default 32 rows per position) and the grouped weight gradients on the 128 tile with their bias gradients
