@@ -242,7 +242,8 @@ int univl_attention_bwd_fused(const UnivlAttention* at, const UnivlGemm* odgrad,
 
 /* univl_attention_fwd with the query / key / value projection (module_bert.py:172-174) computed INSIDE the launch: every workgroup
  * multiplies the 64 x 192 block of q | k | v that belongs to its (batch row, head), stores it to the qkv buffer (bit-identical to
- * univl_gemm(qkv)) and attends on it from LDS -- self-attention over at most 64 positions, bf16.  adam / chunk_*: BertAdam chunks
+ * univl_gemm(qkv)) and attends on it from LDS -- self-attention over at most 128 positions (65 .. 128: two workgroups per (batch row,
+ * head), one per block of 64 queries, each multiplying the whole sequence's q | k | v), bf16; the projection may carry operand pairs (A_lo / B_lo).  adam / chunk_*: BertAdam chunks
  * riding in the launch like in univl_gemm_rider (NULL / 0: none).  UNIVL_EUNSUPPORTED where the launch does not carry the pair. */
 int univl_attention_fwd_fused(const UnivlAttention* at, const UnivlGemm* qkv, const struct UnivlAdam* adam, int32_t chunk_begin,
                               int32_t chunk_count, int32_t max_blocks, int32_t dry_run, hipStream_t stream);
