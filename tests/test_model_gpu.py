@@ -1170,12 +1170,12 @@ def _grad_errors(model, batch, g):
     return err
 
 
-@pytest.mark.parametrize("name", ["joint_full", "pretrain_full"])
+@pytest.mark.parametrize("name", ["joint_full", "joint_b16", "pretrain_full"])
 def test_operand_pairs_tighten_the_bf16_step(golden_dir, name):
     """model.operand_pairs = 'xw' (round 6): the forward products of stacks up to 768 tokens take both operands as bf16 PAIRS
     (UnivlGemm.A_lo / B_lo; every producer of such an activation writes the lo half, the optimizer keeps the lo half of the weight shadow).
-    Against the real reference's fp32 gradients the median per-tensor error drops by a third or more and every statistic stays inside
-    the unchanged gates; the plans really carry the lo halves; setting the attribute back restores the plain plans bit for bit.
+    Against the real reference's fp32 gradients the median per-tensor error drops by a third or more, the global error is inside
+    north_star's 1e-2 (the plain step sits AT it) and every statistic stays inside the unchanged gates; the plans really carry the lo halves; setting the attribute back restores the plain plans bit for bit.
     (Measured: joint_full gmedian 8.9e-3 -> 5.7e-3, gglobal 9.8e-3 -> 9.0e-3 -- that statistic is 72 % one tensor, the token-type table;
     pretrain_full gglobal 1.19e-2 -> 7.3e-3, gmedian 1.07e-2 -> 5.1e-3; +22 % step time at 4 pairs: profiles/r06p_*.)"""
     g = np.load(os.path.join(golden_dir, name + ".npz"))
@@ -1198,6 +1198,9 @@ def test_operand_pairs_tighten_the_bf16_step(golden_dir, name):
     _record(name + "@pairs_xw", torch.bfloat16, **e1)
     assert e1["gmedian"] < 0.72 * e0["gmedian"], (e0, e1)
     assert e1["gglobal"] < e0["gglobal"] and e1["loss"] < 1e-3
+    # north_star's bf16 tolerance on the relative gradient error, met with margin in this mode at every BASELINE configuration up to 16 pairs
+    # (cfg1/2 0.90e-2, cfg3's share 0.71e-2, cfg5 0.73e-2; cfg4 is at 0.43e-2 without pairs) -- the default mode trades it for 22 % step time
+    assert e1["gglobal"] <= 1.0e-2, e1["gglobal"]
     check_gates(name + "@pairs_xw", e1, gates_for(name, torch.bfloat16))
     with pytest.raises(ValueError):
         model.operand_pairs = "y"

@@ -48,8 +48,13 @@ extern "C" int univl_trace_set(unsigned long long* buf, int cap_workgroups) {
 #define UNIVL_TRACE_AT(phase)
 #endif
 
+// UNIVL_GELU_FAST=1 (A/B build: univl_amd/build.py --variant fastgelu -DUNIVL_GELU_FAST=1): the branch-free erf-GELU of the 256 body in
+// gemm_tile's bf16 GELU / GELU' epilogues too.  Measured -0.8 % per step at 4 / 16 pairs (profiles/r06q_ab_gelu.txt) -- and NOT taken: any
+// change of the FFN arithmetic re-draws the bf16 rounding noise of the whole backward, and the one parity statistic that sits at
+// north_star's 1e-2 (the global gradient error, 72 % one tensor: DESIGN.md section 2) moved from 0.977e-2 to 1.124e-2 in the deterministic
+// mode with medians unchanged (profiles/r06_final3_parity_errors.json vs r05_final2): 0.8 % is not worth a different draw of a validated result.
 #ifndef UNIVL_GELU_FAST
-#define UNIVL_GELU_FAST 1      // 0: libm erff in the bf16 GELU epilogues of gemm_tile (A/B build: univl_amd/build.py --variant)
+#define UNIVL_GELU_FAST 0
 #endif
 
 namespace {
@@ -501,8 +506,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                         if (aux_f32) auxf32[orow[a][r] * p.ldaux + ocol[b]] = ev[b][r];
                         else aux[orow[a][r] * p.ldaux + ocol[b]] = from_f32<T>(ev[b][r]);
                     }
-                    // bf16: the branch-free form (common.h; |erf error| <= 1.5e-7 in front of a bf16 rounding) -- libm's erff is two divergent
-                    // branches of ~35 VALU instructions, 1.2 us of the FFN1 epilogue at 192 rows (phase trace: epi 2.7 vs 1.3 us)
+                    // (UNIVL_GELU_FAST: the branch-free form of common.h -- libm's erff is two divergent branches of ~35 VALU instructions,
+                    // 1.2 us of the FFN1 epilogue at 192 rows; see the macro's comment for why the default keeps erff)
                     ev[b][r] = (sizeof(T) == 2 && UNIVL_GELU_FAST) ? g256_gelu(ev[b][r]) : gelu_f(ev[b][r]);
                 }
         }
