@@ -18,7 +18,10 @@ template <bool NT> __device__ __forceinline__ void adam_st4(float* p, int i, f32
     else *q = v;
 }
 
-template <bool NT, int NTH>
+// LO: the instantiation also keeps the lo half of the shadow pair (UnivlAdam.p16_lo).  The rider kernel of the 64 x 128 tile is built for
+// <= 80 VGPRs (three workgroups per unit) and spilled two more with it: it instantiates LO = false and the host keeps an update that carries
+// p16_lo out of that kernel (univl_gemm_rider).
+template <bool NT, int NTH, bool LO = true>
 __device__ __forceinline__ void adam_chunk(const UnivlAdam& a, int c) {
     const int seg = a.chunk_seg[c];
     const UnivlSeg sg = a.segs[seg];
@@ -29,7 +32,7 @@ __device__ __forceinline__ void adam_chunk(const UnivlAdam& a, int c) {
     const int len = a.chunk_len[c];
     float* p = a.p + off; const float* g = a.g + off; float* m = a.m + off; float* v = a.v + off;
     __bf16* p16 = a.p16 ? reinterpret_cast<__bf16*>(a.p16) + off : nullptr;
-    __bf16* p16lo = (a.p16 && a.p16_lo) ? reinterpret_cast<__bf16*>(a.p16_lo) + off : nullptr;      // lo half of the shadow pair
+    __bf16* p16lo = (LO && a.p16 && a.p16_lo) ? reinterpret_cast<__bf16*>(a.p16_lo) + off : nullptr;      // lo half of the shadow pair
     const int nv = ((off & 3) == 0) ? len / 4 : 0;
     auto update = [&](int i, f32x4_t pp, const f32x4_t gg, f32x4_t mm, f32x4_t vv) {
 #pragma unroll

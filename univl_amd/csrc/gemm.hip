@@ -272,7 +272,11 @@ __device__ __forceinline__ void tile_mma(const unsigned char* cA, const unsigned
 // Two LDS stages: tile t+1 streams in while tile t is multiplied (one wait + barrier per K step).  WGM x WGN waves; every wave owns a
 // (BM / WGM) x (BN / WGN) sub-tile.  (Measured and removed in round 4, numbers in DESIGN.md section 8: a three-stage ring with counted
 // waits, a 256 x 128 tile on that ring, a "burst" form with the whole contraction slice in one DMA burst.)
-template <typename T, bool TA, bool TB, int BM, int BN, int NC, int WGM = 2, int WGN = 2>
+// PAIRS: the instantiation carries operand pairs (UnivlGemm.A_lo / B_lo / C16_lo).  Only the bf16 64 x 64 tile with 128-deep K steps does
+// (the tile of every product up to 768 tokens, where the plans pair operands; `prepare` forces it for a paired descriptor): every other
+// instantiation compiles to exactly the code it had before pairs existed (the 64 x 128 rider kernel spilled two more VGPRs with the
+// term walk compiled in: +0.6 .. +1.4 % per step at 32 - 128 pairs, profiles/r06_like_for_like_r05_vs_r06.txt).
+template <typename T, bool TA, bool TB, int BM, int BN, int NC, int WGM = 2, int WGN = 2, bool PAIRS = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const int by, const int bz, const int nz) {
     constexpr int CH = Mma<T>::CH;
     constexpr int BK = NC * CH;          // contraction depth of one LDS stage (NC chunks of CH)
@@ -295,7 +299,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     // Operand pairs (UnivlGemm.A_lo / B_lo): the slices divide the CONCATENATED contraction  A.B | A.B_lo | A_lo.B  (nseg terms of K
     // each; K and the slice length are multiples of BK then, host).  A workgroup whose slice crosses a term boundary re-points its
     // DMA source pointers there (`wrap`, in K tiles from the slice start) and keeps its two-stage pipeline running across it.
-    const int nseg = 1 + (p.B_lo != nullptr ? 1 : 0) + (p.A_lo != nullptr ? 1 : 0);
+    const int nseg = PAIRS ? 1 + (p.B_lo != nullptr ? 1 : 0) + (p.A_lo != nullptr ? 1 : 0) : 1;
     int kbeg = bz * p.ksplit_len;
     int kspan, seg = 0, wrap = 0x7fffffff;
     if (nseg > 1) {
@@ -417,7 +421,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         for (int t = 0; t < nfull; ++t) {
             const int cur = t & 1;
             if (t + 1 < nfull) {
-                if (t + 1 == wrap) next_term();
+                if constexpr (PAIRS) { if (t + 1 == wrap) next_term(); }
                 TileA::issue(pa, sA + (cur ^ 1) * TileA::BYTES, tid);
                 issue_b(sB + (cur ^ 1) * TileB::BYTES);
                 TileA::advance(pa, stepA);
@@ -445,7 +449,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     const bool atomic = (p.flags & UNIVL_GEMM_ATOMIC) != 0;
     const bool nt_out = (p.flags & UNIVL_GEMM_NT_OUT) != 0;
     T* C16 = reinterpret_cast<T*>(p.C16);
-    T* C16lo = reinterpret_cast<T*>(p.C16_lo);
+    T* C16lo = PAIRS ? reinterpret_cast<T*>(p.C16_lo) : nullptr;
     T* aux = reinterpret_cast<T*>(p.aux);
     float* auxf32 = reinterpret_cast<float*>(p.aux);
     const bool aux_f32 = (p.flags & UNIVL_GEMM_AUX_F32) != 0;
@@ -550,7 +554,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 } else {
                     if (p.C32) { if (nt_out) __builtin_nontemporal_store(ev[b][r], p.C32 + o); else p.C32[o] = ev[b][r]; }
                     if (C16) C16[o] = from_f32<T>(ev[b][r]);
-                    if (C16lo) C16lo[o] = from_f32<T>(ev[b][r] - to_f32<T>(from_f32<T>(ev[b][r])));
+                    if constexpr (PAIRS) { if (C16lo) C16lo[o] = from_f32<T>(ev[b][r] - to_f32<T>(from_f32<T>(ev[b][r]))); }
                     ssq += ev[b][r] * ev[b][r];
                 }
             }
@@ -635,7 +639,8 @@ template <typename T, bool TA, bool TB, int BM, int BN, int NC, int WGM, int WGN
 __global__ __launch_bounds__(64 * WGM * WGN, (BM != BN && BM * BN == 128 * 64) ? (WGM * WGN == 8 ? 6 : 3) : 2) void gemm_kernel(GemmArgs p) {
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (p.flags & UNIVL_GEMM_XCD_MAP) xcd_tile(bx, by, bz, p.gm);
-    gemm_tile<T, TA, TB, BM, BN, NC, WGM, WGN>(p, bx, by, bz, gridDim.z);
+    constexpr bool PAIRS = sizeof(T) == 2 && !TA && BM == 64 && BN == 64 && NC == 4;      // forward / dgrad products on the small tile
+    gemm_tile<T, TA, TB, BM, BN, NC, WGM, WGN, PAIRS>(p, bx, by, bz, gridDim.z);
 }
 
 #include "gemm256.h"
@@ -1164,7 +1169,7 @@ __global__ __launch_bounds__(512, 2) void gemm_adam_kernel(GemmArgs g, int nd, i
         if (w0 >= nd) return;                                  // padding workgroup
         int bx, by, bz;
         pair_tile(w0, nd, nx, ny, nz, g.flags, g.gm, bx, by, bz);
-        gemm_tile<__bf16, false, false, 64, 64, 4, 2, 4>(g, bx, by, bz, nz);
+        gemm_tile<__bf16, false, false, 64, 64, 4, 2, 4, true>(g, bx, by, bz, nz);
     } else {
         const int nb = (int)gridDim.x - nd_pad;
         for (int c = c0 + (w0 - nd_pad); c < c1; c += nb) adam_chunk<NT, 512>(a, c);
@@ -1192,7 +1197,7 @@ __global__ __launch_bounds__(512, 6) void gemm_adam_rect_kernel(GemmArgs g, int 
     int t;
     if (rect_rider_role((int)blockIdx.x, (int)gridDim.x, nd_pad, t)) {
         const int nb = (int)gridDim.x - nd_pad;
-        for (int c = c0 + t; c < c1; c += nb) adam_chunk<NT, 512>(a, c);
+        for (int c = c0 + t; c < c1; c += nb) adam_chunk<NT, 512, false>(a, c);
     } else {
         if (t >= nd) return;                                   // padding workgroup
         int bx, by, bz;
@@ -1225,7 +1230,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_kernel(GemmArgs g, int nd, int
         if (w0 >= nd) return;                                  // padding workgroup
         int bx, by, bz;
         pair_tile(w0, nd, nx, ny, nz, g.flags, g.gm, bx, by, bz);
-        gemm_tile<__bf16, false, false, 64, 64, 4, 2, 4>(g, bx, by, bz, nz);
+        gemm_tile<__bf16, false, false, 64, 64, 4, 2, 4, true>(g, bx, by, bz, nz);
         ln_fold(f, by, nx * nz, g.M);
     } else {
         const int nb = (int)gridDim.x - nd_pad;
@@ -1414,7 +1419,11 @@ static int prepare(const UnivlGemm* d, GemmArgs& a, int& ksplit, Choice& c, int 
     // tile choice: 128x128 once the grid fills the chip (>= 256 tiles, measured: +6 % at bs 128 over 384, same at bs 16), else
     // 64x64 for parallelism.  The small tile stages 4 chunks (128 bf16 / 64 f32) per barrier: at M <= a few hundred the kernel
     // is a latency chain of K steps (DMA -> barrier -> ds_read -> MFMA), so fewer, deeper steps win.
-    c = choose(d, forced_tile, forced_nc, allow_rect, in_group);
+    const bool paired = d->A_lo || d->B_lo || d->C16_lo;
+    // operand pairs: only the bf16 64 x 64 tile with 128-deep steps carries them (gemm_tile<..., PAIRS>), in the single / rider / fold launches
+    UNIVL_CHECK_ARG(!(paired && (in_group || d->trans_a || (forced_tile != 0 && forced_tile != 64) || forced_nc == 2)), UNIVL_EUNSUPPORTED,
+                    "univl_gemm: operand pairs only on K-major-A products of the single, rider and LayerNorm-fold launches");
+    c = paired ? choose(d, 64, 0, false, false) : choose(d, forced_tile, forced_nc, allow_rect, in_group);
     // deterministic mode (common.h): no split-K -- the slices of a split product meet in fp32 atomics whose order is the hardware's;
     // one workgroup per output tile walks the whole contraction in order (the pre-zeroed arena is simply overwritten)
     ksplit = (d->ksplit < 1 || univl_deterministic()) ? 1 : d->ksplit;
@@ -1550,9 +1559,12 @@ extern "C" int univl_gemm(const UnivlGemm* d, hipStream_t stream) {
     return dispatch_trans<float, 64, 64, 4>(a, ta, tb, ksplit, stream);
 }
 
+static bool has_pairs(const UnivlGemm* d) { return d->A_lo != nullptr || d->B_lo != nullptr || d->C16_lo != nullptr; }
+
 static int pair_impl(const UnivlGemm* dgrad, const UnivlGemm* wgrad, const UnivlLayerNorm* ln, int32_t* counters, int32_t dry_run,
                      hipStream_t stream) {
     UNIVL_CHECK_ARG(dgrad != nullptr && wgrad != nullptr, UNIVL_EINVAL, "univl_gemm_pair: null descriptor");
+    UNIVL_CHECK_ARG(!has_pairs(dgrad) && !has_pairs(wgrad), UNIVL_EUNSUPPORTED, "univl_gemm_pair: operand pairs are carried by univl_gemm / the rider and fold launches only");
     PairArgs a;
     int ksd, ksw;
     Choice cd, cw;
@@ -1829,8 +1841,9 @@ extern "C" int univl_gemm_rider(const UnivlGemm* gemm, const UnivlAdam* adam, in
                     UNIVL_EINVAL, "univl_gemm_rider: chunks [%d, +%d) of %d", chunk_begin, chunk_count, adam ? adam->nchunk : 0);
     GemmArgs a;
     int ks, fits;
-    const int rc = rider_prepare(gemm, a, ks, fits);
+    int rc = rider_prepare(gemm, a, ks, fits);
     if (rc != UNIVL_OK) return rc;
+    if (fits == 2 && adam->p16_lo != nullptr) fits = 0;      // the 64 x 128 rider kernel does not keep the lo half of the shadow pair (adam_chunk<.., LO = false>)
     if (!fits || chunk_count == 0) {          // not a product these kernels carry: the two launches one after the other (same result)
         const int r1 = univl_gemm(gemm, stream);
         if (r1 != UNIVL_OK || chunk_count == 0) return r1;
@@ -2021,6 +2034,7 @@ extern "C" int univl_gemm_group_limited(const UnivlGemm* d, int n, int max_block
         if (i >= n) { g.p[i] = g.p[0]; g.nx[i] = g.nxy[i] = g.nz[i] = 1; continue; }
         int ksplit;
         Choice ci;
+        UNIVL_CHECK_ARG(!(d[i].A_lo || d[i].B_lo || d[i].C16_lo), UNIVL_EUNSUPPORTED, "univl_gemm_group: member %d carries operand pairs (univl_gemm only)", i);
         const int rc = prepare(&d[i], g.p[i], ksplit, ci, tile_all, forced_nc, false, tile_all == 256);
         if (rc != UNIVL_OK) return rc;
         if (g.cs[i].x) g.p[i].dbias = nullptr;
