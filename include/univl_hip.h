@@ -127,8 +127,10 @@ typedef struct UnivlGemm {
     /* Round 6, bf16 only -- operand PAIRS.  A bf16 operand carries 8 mantissa bits; x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
      * carries 16.  A_lo / B_lo (optional, same layout and leading dimension as A / B) hold the lo halves; the product then walks the
      * contraction once per term in a FIXED order --  A.B,  A.B_lo (if B_lo),  A_lo.B (if A_lo)  -- into the same fp32 accumulators
-     * (the lo.lo term is below fp32 resolution of the sum and is dropped).  ksplit divides that concatenated contraction.  Needs K a
-     * multiple of the K step (128; 64 on the 128-wide tiles); never on the 256 x 256 body.  The plans pair the forward products'
+     * (the lo.lo term is below fp32 resolution of the sum and is dropped).  ksplit divides that concatenated contraction.  A paired
+     * product runs on the 64 x 64 tile whatever `tile` says (the only body that carries the term walk), needs K-major A and K a
+     * multiple of 128, and is carried by univl_gemm, univl_gemm_rider, univl_gemm_ln and univl_attention_fwd_fused; univl_gemm_pair /
+     * univl_gemm_group / univl_attention_bwd_fused return UNIVL_EUNSUPPORTED for it.  The plans pair the forward products'
      * operands up to 768 tokens, where the matrix pipe is idle (what it buys in gradient error).
      * C16_lo (optional): the epilogue also stores lo = bf16(result - bf16(result)) there (same ldc) -- the A_lo of the next product. */
     const void* A_lo; const void* B_lo; void* C16_lo;
