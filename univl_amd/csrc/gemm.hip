@@ -1934,6 +1934,107 @@ extern "C" int univl_gemm_rider_prime(hipStream_t stream) {
     return UNIVL_OK;
 }
 
+#ifdef UNIVL_PROTO
+// ---------------------------------------------------------------------------------------------------------------------------------
+// MEASUREMENT PROTOTYPE (round 6; `python univl_amd/build.py --variant proto -DUNIVL_PROTO`, scripts/mb_layer_proto.py; never in the product
+// library): the FFN half of an encoder layer's forward -- attention-output product + LayerNorm, FFN1 + GELU, FFN2 + LayerNorm
+// (module_bert.py:207-211, 233-250), three launches in the plans -- as ONE launch whose later products wait on row-block flags instead of
+// kernel boundaries (VERDICT r5 next 2 asked for a one-layer prototype with a kill criterion).  Workgroup roles in dispatch order: the
+// attention-output tiles (their last arrivals per 64-row block finish LayerNorm 1 and raise flags1[block] once per sharer), the FFN1 tiles
+// (wait for flags1[block] == LN_SHARE, raise flags2[block]), the FFN2 tiles (wait for flags2[block] == FFN1 column tiles, fold LayerNorm
+// 2).  Producers always have lower workgroup ids than their consumers and the whole grid is resident (<= 512 workgroups), so the waits
+// cannot deadlock; every wait gives up after 2^22 polls.  The hand-offs carry NO write-through / L2-bypass: a consumer on another XCD may
+// read stale operand lines, the RESULTS ARE NOT VALID -- the timing is a lower bound on what a correct version (sc1 stores of the operands
+// + sc1 LDS-DMA) would take.
+struct ProtoArgs {
+    int n_o, n_o_pad, onx, ony, onz;
+    int n_f1, n_f1_pad, f1nx, f1ny;
+    int n_f2, f2nx, f2ny, f2nz;
+    int* flags1; int* flags2;
+};
+
+__device__ __forceinline__ void proto_raise(int* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void proto_wait(int* flag, int need) {
+    if (threadIdx.x == 0) {
+        int polls = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && ++polls < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(512, 2) void layer_ffn_proto_kernel(GemmArgs o, GemmArgs f1, GemmArgs f2, LnFold ln1, LnFold ln2, ProtoArgs q) {
+    const int w0 = blockIdx.x;
+    int bx, by, bz;
+    if (w0 < q.n_o_pad) {
+        if (w0 >= q.n_o) return;
+        pair_tile(w0, q.n_o, q.onx, q.ony, q.onz, o.flags, o.gm, bx, by, bz);
+        gemm_tile<__bf16, false, false, 64, 64, 4, 2, 4>(o, bx, by, bz, q.onz);
+        int* cnt = ln1.counters + 2 * by;
+        const int slab = fold_arrive(cnt, q.onx * q.onz);
+        if (slab < 0) return;
+        const int row = by * 64 + slab * 8 + (int)(threadIdx.x >> 6);
+        if (row < o.M) ln_fwd_row<768, __bf16, false, true>(ln1.ln, row, (int)(threadIdx.x & 63));
+        proto_raise(q.flags1 + by);
+        fold_leave(cnt);
+    } else if (w0 < q.n_o_pad + q.n_f1_pad) {
+        const int t = w0 - q.n_o_pad;
+        if (t >= q.n_f1) return;
+        pair_tile(t, q.n_f1, q.f1nx, q.f1ny, 1, f1.flags, f1.gm, bx, by, bz);
+        proto_wait(q.flags1 + by, LN_SHARE);
+        gemm_tile<__bf16, false, false, 64, 64, 4, 2, 4>(f1, bx, by, 0, 1);
+        proto_raise(q.flags2 + by);
+    } else {
+        const int t = w0 - q.n_o_pad - q.n_f1_pad;
+        if (t >= q.n_f2) return;
+        pair_tile(t, q.n_f2, q.f2nx, q.f2ny, q.f2nz, f2.flags, f2.gm, bx, by, bz);
+        proto_wait(q.flags2 + by, q.f1nx);
+        gemm_tile<__bf16, false, false, 64, 64, 4, 2, 4>(f2, bx, by, bz, q.f2nz);
+        ln_fold(ln2, by, q.f2nx * q.f2nz, f2.M);
+    }
+}
+
+// o / f2: fp32 outputs into zeroed buffers (= ln1->x / ln2->x), f1: the GELU product; ctr1 / ctr2: the folds' arrival counters (zero);
+// flags: 2 * ceil(M / 64) ints, ZERO before every launch.
+extern "C" int univl_proto_layer_ffn(const UnivlGemm* o, const UnivlLayerNorm* ln1, const UnivlGemm* f1, const UnivlGemm* f2,
+                                     const UnivlLayerNorm* ln2, int32_t* ctr1, int32_t* ctr2, int32_t* flags, hipStream_t stream) {
+    UNIVL_ON_STREAM_DEVICE(stream);
+    GemmArgs ao, a1, a2;
+    int kso, ks1, ks2;
+    Choice co, c1, c2;
+    int rc = prepare(o, ao, kso, co);
+    if (rc) return rc;
+    rc = prepare(f1, a1, ks1, c1);
+    if (rc) return rc;
+    rc = prepare(f2, a2, ks2, c2);
+    if (rc) return rc;
+    UNIVL_CHECK_ARG(co.tile == 64 && c1.tile == 64 && c2.tile == 64 && co.nc == 4 && c1.nc == 4 && c2.nc == 4 && ks1 == 1 && o->N == 768 && f2->N == 768 &&
+                        o->M == f1->M && o->M == f2->M && o->M <= 64 * LN_FOLD_MAX_BLOCKS && ctr1 && ctr2 && flags, UNIVL_EUNSUPPORTED,
+                    "univl_proto_layer_ffn: shapes");
+    ao.flags |= UNIVL_GEMM_ATOMIC;
+    a2.flags |= UNIVL_GEMM_ATOMIC;
+    ProtoArgs q;
+    const int ny = (o->M + 63) / 64;
+    q.onx = 12; q.ony = ny; q.onz = kso; q.n_o = 12 * ny * kso; q.n_o_pad = (q.n_o + 7) / 8 * 8;
+    q.f1nx = (f1->N + 63) / 64; q.f1ny = ny; q.n_f1 = q.f1nx * ny; q.n_f1_pad = (q.n_f1 + 7) / 8 * 8;
+    q.f2nx = 12; q.f2ny = ny; q.f2nz = ks2; q.n_f2 = 12 * ny * ks2;
+    q.flags1 = flags; q.flags2 = flags + ny;
+    UNIVL_CHECK_ARG(q.n_o_pad + q.n_f1_pad + q.n_f2 <= 512, UNIVL_EUNSUPPORTED, "univl_proto_layer_ffn: %d workgroups do not fit one resident round",
+                    q.n_o_pad + q.n_f1_pad + q.n_f2);
+    LnFold l1, l2;
+    l1.ln = *ln1; l1.counters = ctr1;
+    l2.ln = *ln2; l2.counters = ctr2;
+    static bool done[UNIVL_MAX_DEVICES] = {};
+    univl_allow_lds(layer_ffn_proto_kernel, RIDER_SMEM, done);
+    hipLaunchKernelGGL(layer_ffn_proto_kernel, dim3(q.n_o_pad + q.n_f1_pad + q.n_f2), dim3(512), RIDER_SMEM, stream, ao, a1, a2, l1, l2, q);
+    UNIVL_LAUNCH_CHECK();
+    return UNIVL_OK;
+}
+#endif  // UNIVL_PROTO
+
 static int vocab_ce_prepare(const UnivlVocabCE* d, VocabCeArgs& a, const char* who, bool bwd) {
     UNIVL_CHECK_ARG(d != nullptr, UNIVL_EINVAL, "%s: null descriptor", who);
     UNIVL_CHECK_ARG(d->dtype == UNIVL_F32 || d->dtype == UNIVL_BF16, UNIVL_EUNSUPPORTED, "%s: dtype %d", who, d->dtype);
