@@ -1230,6 +1230,48 @@ def test_operand_pairs_follow_the_optimizer(ab):
     assert l0 != l1 and all(abs(a - b) < 2e-3 * max(1.0, abs(a)) for a, b in zip(l0, l1)), (l0, l1)
 
 
+def test_lo_shadow_is_kept_where_the_rider_kernel_does_not_carry_it():
+    """The rider kernel of the 64 x 128 tile (1536+ tokens) is built without the lo-shadow write (adam_chunk<.., LO = false>: two spilled
+    registers in a <= 80-VGPR kernel); univl_gemm_rider therefore runs product and update as two launches when the update carries
+    UnivlAdam.p16_lo.  A model whose lo shadow exists (operand pairs were used at a smaller batch) and which trains at 32 pairs: losses and
+    parameters of the riding step are bit-identical to the eager loop, and hi + lo still tracks the fp32 master."""
+    from univl_amd.graphed import GraphedTrainStep
+    cfg, rows, dseed = case_config("joint_b32")
+    b = {k: v.to(DEV) for k, v in O.synthetic_batch(cfg, rows, seed=dseed).items()}
+    args = (b["input_ids"], b["token_type_ids"], b["attention_mask"], b["video"], b["video_mask"])
+    kw = dict(pairs_masked_text=b["pairs_masked_text"], pairs_token_labels=b["pairs_token_labels"], masked_video=b["masked_video"],
+              video_labels_index=b["video_labels_index"])
+
+    def run(graph):
+        model, _ = build(cfg, torch.bfloat16)
+        model.train()
+        assert model.flat.ensure_lo() and model.operand_pairs == ""
+        opt = BertAdam(model.parameters(), lr=1e-5, warmup=-1, t_total=-1, weight_decay=0.01, max_grad_norm=1.0)
+        losses = []
+        if graph:
+            gs = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=1, pipeline_optimizer=True)
+            for _ in range(3):
+                losses.append(float(gs(*args, **kw)))
+            gs.flush()
+        else:
+            for _ in range(3):
+                loss = model(*args, **kw)
+                loss.backward()
+                clip_grad_norm_(model.parameters(), 1.0)
+                opt.step()
+                opt.zero_grad()
+                losses.append(float(loss))
+            opt.flush()
+        fl = model.flat
+        assert torch.equal(fl.p16, fl.p32.to(torch.bfloat16)) and torch.equal(fl.p16lo, (fl.p32 - fl.p16.float()).to(torch.bfloat16))
+        return losses, fl.p32.detach().clone()
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert l0 == l1, (l0, l1)
+    assert torch.equal(p0, p1)
+
+
 def test_lazy_word_rows_update_is_bit_identical(ab):
     """UnivlAdam.row_flags (adam_lazy_rows, default on): chunks of word-table rows that never held a gradient take the
     weight-decay-only form of the BertAdam update (10 instead of 30 bytes per parameter).  Same bits as the full update, over
