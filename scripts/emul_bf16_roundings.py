@@ -171,6 +171,9 @@ def variants():
     out.append(("x (forward A operand) AND xw (weight-gradient operand) hi+lo", dict(allb, x="hilo", xw="hilo")))
     out.append(("x, xw and dy hi+lo", dict(allb, x="hilo", xw="hilo", dy="hilo")))
     out.append(("xw and dy hi+lo (both weight-gradient operands; off the critical path)", dict(allb, xw="hilo", dy="hilo")))
+    out.append(("operand pairs as built (forward w and x hi+lo), rest bf16", dict(allb, w="hilo", x="hilo")))
+    out.append(("operand pairs as built + dY hi+lo", dict(allb, w="hilo", x="hilo", dy="hilo")))
+    out.append(("operand pairs as built + every backward operand and the dgrad weights hi+lo", dict(allb, w="hilo", x="hilo", wb="hilo", **{c: "hilo" for c in bwd})))
     for c in CLASSES:                      # leave-one-out: which single class is worth carrying as a pair
         out.append(("leave-one-out: %s hi+lo, rest bf16" % c, dict(allb, **{c: "hilo"})))
     if os.environ.get("EMUL_ONLY"):
